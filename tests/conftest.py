@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    import oracle_lib as ol
+
+    ol.build()
+    return ol
+
+
+@pytest.fixture(scope="session")
+def seq50():
+    from openekfmonoslam_amd.synth import SyntheticSequence
+
+    return SyntheticSequence(50, 6)
+
+
+@pytest.fixture(scope="session")
+def seq12():
+    from openekfmonoslam_amd.synth import SyntheticSequence
+
+    return SyntheticSequence(12, 6)

@@ -1,0 +1,273 @@
+"""Independent checks of the CPU oracle (no GPU): numerical differentiation, numpy linear algebra and the
+host-side numpy map seeding are used as second opinions on the C restatement."""
+import numpy as np
+import pytest
+
+from openekfmonoslam_amd import synth
+from openekfmonoslam_amd.types import PREDICTION_DTYPE, s3_camera, s3_params
+
+
+def _measure(o, x13, fpos):
+    R = synth.quat_to_rot(x13[3:7])
+    p = o.predict_measurement_state(x13, R, fpos)
+    out = np.full((o.N, 2), np.nan)
+    out[p["featureIndex"]] = p["imagePos"]
+    return out
+
+
+def _numeric_jacobians(o, x13, fpos, eps=1e-6):
+    N = o.N
+    Js = np.zeros((N, 2, 13))
+    for a in range(13):
+        xp, xm = x13.copy(), x13.copy()
+        xp[a] += eps
+        xm[a] -= eps
+        Js[:, :, a] = (_measure(o, xp, fpos) - _measure(o, xm, fpos)) / (2 * eps)
+    Jf = np.zeros((N, 2, 6))
+    for a in range(6):
+        fp, fm = fpos.copy(), fpos.copy()
+        fp[:, a] += eps
+        fm[:, a] -= eps
+        Jf[:, :, a] = (_measure(o, x13, fp) - _measure(o, x13, fm)) / (2 * eps)
+    return Js, Jf
+
+
+def _load(ol, seq, q=None, r=None):
+    o = ol.Oracle(seq.cam, seq.par, seq.n_features + 4)
+    x = seq.x13.copy()
+    if q is not None:
+        x[3:7] = q
+    if r is not None:
+        x[0:3] = r
+    o.set_state(x, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    return o
+
+
+def test_add_feature_matches_numpy_seeding(oracle_lib, seq12):
+    """orc_add_feature (C) vs synth.seed_map (independent numpy) on the same pixels."""
+    seq = seq12
+    o = oracle_lib.Oracle(seq.cam, seq.par, 16)
+    o.reset()
+    rng = np.random.default_rng(3)
+    uvs = np.stack([rng.uniform(20, 620, 12), rng.uniform(20, 460, 12)], -1)
+    x0, P13 = synth.initial_state_and_covariance(seq.par)
+    np.testing.assert_array_equal(o.x13(), x0)
+    np.testing.assert_array_equal(o.P(), P13)
+    for uv in uvs:
+        assert o.add_feature(uv) >= 0
+    pos, P = synth.seed_map(seq.cam, seq.par, x0, P13, uvs)
+    np.testing.assert_allclose(o.feature_pos(), pos, rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(o.P(), P, rtol=1e-12, atol=1e-30)
+    assert list(o.feature_covpos()) == [13 + 6 * i for i in range(12)]
+
+
+def test_jacobians_match_numeric_at_identity_orientation(oracle_lib, seq50):
+    """With R = I the reference's two Jacobian quirks are inert, so Hs and Hf must equal the numerical
+    derivative of the measurement function (EKF/MeasurementPrediction.cpp:203-265 vs :273-589)."""
+    o = _load(oracle_lib, seq50)
+    preds, Hs, Hf = o.predict_measurements()
+    assert len(preds) == 50
+    Js, Jf = _numeric_jacobians(o, o.x13(), o.feature_pos())
+    idx = preds["featureIndex"]
+    np.testing.assert_allclose(Hs[:, :, 0:7], Js[idx][:, :, 0:7], rtol=2e-6, atol=2e-6)
+    assert np.all(Hs[:, :, 7:13] == 0.0)
+    np.testing.assert_allclose(Hf, Jf[idx], rtol=2e-6, atol=2e-6)
+
+
+def test_jacobian_quirks_at_general_orientation(oracle_lib, seq50):
+    """At a rotated camera only the entries touched by the two reference quirks may deviate from the numerical
+    derivative: d h/d r (carp[1] never written, carp[2] scaled rho^2: MeasurementPrediction.cpp:371-373,392-394)
+    and d h/d rho (un-rotated (y - r), :579)."""
+    q = synth.angles_to_quat(np.array([0.05, -0.2, 0.1]))
+    o = _load(oracle_lib, seq50, q=q, r=[0.3, -0.2, 0.1])  # y - r != 0 so the rho column is live
+    preds, Hs, Hf = o.predict_measurements()
+    assert len(preds) > 20
+    Js, Jf = _numeric_jacobians(o, o.x13(), o.feature_pos())
+    idx = preds["featureIndex"]
+    np.testing.assert_allclose(Hs[:, :, 3:7], Js[idx][:, :, 3:7], rtol=5e-6, atol=5e-6)
+    np.testing.assert_allclose(Hf[:, :, 0:5], Jf[idx][:, :, 0:5], rtol=5e-6, atol=5e-6)
+    assert np.abs(Hs[:, :, 0:3] - Js[idx][:, :, 0:3]).max() > 1e-2
+    assert np.abs(Hf[:, :, 5] - Jf[idx][:, :, 5]).max() > 1e-2
+
+
+def test_innovation_covariance_matches_numpy(oracle_lib, seq50):
+    o = _load(oracle_lib, seq50)
+    o.predict()
+    P = o.P()
+    preds, Hs, Hf, HP = o.predict_measurements(want_HP=True)
+    n = o.n
+    for k in range(len(preds)):
+        fi = preds["featureIndex"][k]
+        H = np.zeros((2, n))
+        H[:, 0:13] = Hs[k]
+        H[:, 13 + 6 * fi : 19 + 6 * fi] = Hf[k]
+        np.testing.assert_allclose(HP[k], H @ P, rtol=1e-11, atol=1e-14)
+        np.testing.assert_allclose(preds["covarianceMatrix"][k].reshape(2, 2), H @ P @ H.T + np.eye(2),
+                                   rtol=1e-11, atol=1e-13)
+
+
+def test_predict_F_matches_numeric_and_covariance_matches_numpy(oracle_lib, seq12):
+    o = _load(oracle_lib, seq12)
+    x0, P0 = o.x13(), o.P()
+    F, GQG = o.predict(want_F=True)
+    x1, P1 = o.x13(), o.P()
+    # state: r += v, q = q * quat(w)
+    np.testing.assert_allclose(x1[0:3], x0[0:3] + x0[7:10])
+    np.testing.assert_allclose(x1[3:7], synth.quat_mul(x0[3:7], synth.angles_to_quat(x0[10:13])), rtol=1e-15)
+    # F against the numerical derivative of the dynamic model
+    def f(x):
+        y = x.copy()
+        y[0:3] += x[7:10]
+        y[3:7] = synth.quat_mul(x[3:7], synth.angles_to_quat(x[10:13]))
+        return y
+    Fn = np.zeros((13, 13))
+    for a in range(13):
+        e = np.zeros(13)
+        e[a] = 1e-7
+        Fn[:, a] = (f(x0 + e) - f(x0 - e)) / 2e-7
+    np.testing.assert_allclose(F, Fn, rtol=1e-6, atol=1e-8)
+    # covariance: full-matrix F_full P F_full' + Q_full equals the strip update
+    n = o.n
+    Ff = np.eye(n)
+    Ff[:13, :13] = F
+    Qf = np.zeros((n, n))
+    Qf[:13, :13] = GQG
+    np.testing.assert_allclose(P1, Ff @ P0 @ Ff.T + Qf, rtol=1e-12, atol=1e-18)
+    par = seq12.par
+    Gn = np.zeros((13, 6))
+    Gn[7:10, 0:3] = np.eye(3)
+    Gn[10:13, 3:6] = np.eye(3)
+    Gn[0:3, 0:3] = np.eye(3)
+    Gn[3:7, 3:6] = F[3:7, 10:13]
+    Q = np.diag([par.linearAccelSD**2] * 3 + [par.angularAccelSD**2] * 3)
+    np.testing.assert_allclose(GQG, Gn @ Q @ Gn.T, rtol=1e-13, atol=1e-30)
+
+
+def test_predict_zero_angular_velocity_branch(oracle_lib, seq12):
+    """|w_i| < EPSILON for all i: F[10+i][10+i] = 0 and G's quaternion block stays zero
+    (StateAndCovariancePrediction.cpp:176-184, 211-212)."""
+    seq = seq12
+    o = oracle_lib.Oracle(seq.cam, seq.par, 16)
+    x = seq.x13.copy()
+    x[10:13] = 1e-17
+    o.set_state(x, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    F, GQG = o.predict(want_F=True)
+    assert np.all(np.diag(F)[10:13] == 0.0)
+    assert np.all(F[3:7, 10:13] == 0.0)
+    np.testing.assert_array_equal(F[3:7, 3:7], np.eye(4))
+    assert np.all(GQG[3:7, :] == 0.0) and np.all(GQG[:, 3:7] == 0.0)
+    np.testing.assert_allclose(np.diag(GQG)[10:13], seq.par.angularAccelSD**2)
+
+
+def test_ellipse_axes_and_angle_convention(oracle_lib, seq12):
+    o = oracle_lib.Oracle(seq12.cam, seq12.par, 4)
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        A = rng.normal(size=(2, 2))
+        S = A @ A.T + np.eye(2)
+        ax, ang = o.ellipse(S)
+        w = np.linalg.eigvalsh(S)[::-1]
+        np.testing.assert_allclose(ax, (2 * np.sqrt(w * 5.9915)).astype(np.float32), rtol=1e-6)
+        # documented convention (cv::eigen Jacobi, rows = eigenvectors): S11 > S00 -> true major-axis
+        # angle, S00 > S11 -> its mirror image
+        true_ang = 0.5 * np.arctan2(2 * S[0, 1], S[0, 0] - S[1, 1])
+        true_ang = np.arctan(np.tan(true_ang))
+        if S[1, 1] > S[0, 0]:
+            np.testing.assert_allclose(np.tan(ang), np.tan(true_ang), rtol=1e-8, atol=1e-10)
+        else:
+            np.testing.assert_allclose(np.tan(ang), -np.tan(true_ang), rtol=1e-8, atol=1e-10)
+    ax, ang = o.ellipse(np.array([[4.0, 3.0], [3.0, 4.0]]))
+    np.testing.assert_allclose(ang, np.pi / 4)  # recollected OpenCV code gives +45 deg
+    ax, ang = o.ellipse(np.eye(2))
+    assert ang == 0.0 and abs(ax[0] - 4.8955) < 1e-3
+
+
+def _first_frame(o, seq):
+    o.predict()
+    preds, Hs, Hf = o.predict_measurements()
+    kps, desc = seq.frames[0]
+    matches = o.match(preds, kps, desc)
+    return preds, Hs, Hf, matches
+
+
+def test_update_literal_equals_algorithmic_and_numpy(oracle_lib, seq50):
+    ol = oracle_lib
+    o1, o2 = _load(ol, seq50), _load(ol, seq50)
+    preds, Hs, Hf, matches = _first_frame(o1, seq50)
+    _first_frame(o2, seq50)
+    mp, mHs, mHf = ol.align_to_matches(preds, Hs, Hf, matches)
+    x0, P0, f0 = o1.x13(), o1.P(), o1.feature_pos()
+    assert o1.update(matches, mp, mHs, mHf, ol.LITERAL) == 0
+    assert o2.update(matches, mp, mHs, mHf, ol.ALGORITHMIC) == 0
+    np.testing.assert_allclose(o2.x13(), o1.x13(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(o2.feature_pos(), o1.feature_pos(), rtol=1e-9, atol=1e-12)
+    P1 = o1.P()
+    assert np.abs(o2.P() - P1).max() <= 1e-10 * np.abs(P1).max()
+    # textbook numpy EKF update, then the reference's symmetrisation + quaternion normalisation
+    n, M = o1.n, len(matches)
+    H = np.zeros((2 * M, n))
+    for i in range(M):
+        fi = mp["featureIndex"][i]
+        H[2 * i : 2 * i + 2, 0:13] = mHs[i]
+        H[2 * i : 2 * i + 2, 13 + 6 * fi : 19 + 6 * fi] = mHf[i]
+    S = H @ P0 @ H.T + np.eye(2 * M) * seq50.cam.pixelErrorX
+    K = P0 @ H.T @ np.linalg.inv(S)
+    nu = (matches["imagePos"] - mp["imagePos"]).reshape(-1)
+    dx = K @ nu
+    xs = np.concatenate([x0, f0.reshape(-1)]) + dx
+    Pn = (np.eye(n) - K @ H) @ P0
+    Pn = 0.5 * Pn + 0.5 * Pn.T
+    q = xs[3:7]
+    r, x, y, z = q
+    nq = np.linalg.norm(q)
+    J = np.array([[x * x + y * y + z * z, -r * x, -r * y, -r * z], [-x * r, r * r + y * y + z * z, -x * y, -x * z],
+                  [-y * r, -y * x, r * r + x * x + z * z, -y * z], [-z * r, -z * x, -z * y, r * r + x * x + y * y]]) / nq**3
+    D = np.eye(n)
+    D[3:7, 3:7] = J
+    Pn = D @ Pn @ D.T
+    xs[3:7] = q / nq
+    np.testing.assert_allclose(o1.x13(), xs[:13], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(o1.feature_pos().reshape(-1), xs[13:], rtol=1e-8, atol=1e-11)
+    assert np.abs(P1 - Pn).max() <= 1e-9 * np.abs(Pn).max()
+    # exact except the 4x4 quaternion block, where (J C) J' is not bitwise symmetric (Update.cpp:76)
+    assert np.abs(P1 - P1.T).max() <= 1e-15 * np.abs(P1).max()
+    assert np.linalg.eigvalsh(P1).min() > -1e-12 * np.abs(P1).max()
+
+
+def test_ransac_consistent_with_bruteforce(oracle_lib, seq50):
+    """Replays 1PointRansac.cpp:101-234 in numpy for each hypothesis the oracle evaluated."""
+    ol = oracle_lib
+    o = _load(ol, seq50)
+    preds, Hs, Hf, matches = _first_frame(o, seq50)
+    mp, mHs, mHf = ol.align_to_matches(preds, Hs, Hf, matches)
+    mask, counts = o.ransac(mp, mHs, mHf, matches)
+    assert len(counts) >= 1 and mask.sum() == counts.max()
+    P, x0, f0, n = o.P(), o.x13(), o.feature_pos(), o.n
+    match_of = {int(m["featureIndex"]): i for i, m in enumerate(matches)}
+    for h in range(len(counts)):
+        fi = mp["featureIndex"][h]
+        H = np.zeros((2, n))
+        H[:, :13] = mHs[h]
+        H[:, 13 + 6 * fi : 19 + 6 * fi] = mHf[h]
+        G = P @ H.T
+        S = H @ G + np.eye(2) * seq50.cam.pixelErrorX
+        dx = G @ np.linalg.inv(S) @ (matches["imagePos"][h] - mp["imagePos"][h])
+        xs = np.concatenate([x0, f0.reshape(-1)]) + dx
+        uv = _measure(o, xs[:13], xs[13:].reshape(-1, 6))
+        cnt = 0
+        for f_idx, i in match_of.items():
+            if not np.isnan(uv[f_idx, 0]) and np.linalg.norm(matches["imagePos"][i] - uv[f_idx]) < 1.0:
+                cnt += 1
+        assert cnt == counts[h]
+
+
+def test_step_runs_and_tracks(oracle_lib, seq50):
+    o = _load(oracle_lib, seq50)
+    for kps, desc in seq50.frames:
+        info = o.step(kps, desc, oracle_lib.LITERAL)
+        assert info.status == 0
+        assert info.n_predicted == 50 and info.n_matches >= 30
+        assert info.n_inliers + info.n_rescued >= 0.6 * info.n_matches
+    P = o.P()
+    assert np.abs(P - P.T).max() <= 1e-15 * np.abs(P).max() and np.isfinite(P).all()
+    assert abs(np.linalg.norm(o.x13()[3:7]) - 1.0) < 1e-12
