@@ -1,0 +1,158 @@
+/*
+ * ekf_engine.h -- C ABI of the MI355X-native EKF engine (libekf_engine.so).
+ *
+ * Drop-in boundary for the per-frame hot path of segeschecho/OpenEKFMonoSLAM.  The reference has no FFI or
+ * plugin interface; its seam is the set of free functions in kalmanFilter/modules/1PointRansacEKF/ headers that
+ * EKF::step calls.  Each entry point below replaces one of them (file:line given per function, relative to
+ * /root/reference/kalmanFilter/modules/, EKF/ = 1PointRansacEKF/).  The C++ headers under
+ * openekfmonoslam_amd/compat/ re-create the reference's own signatures on top of this ABI.
+ *
+ * Conventions
+ *  - plain pointers and sizes only, caller-owned buffers, int status codes (ekf_types.h), no exceptions;
+ *  - one engine = one host thread + its own HIP stream; several engines may coexist (no globals);
+ *  - state, covariance P, the map and all per-frame intermediates stay resident in HBM between calls;
+ *    ekf_set_state / ekf_get_state are the explicit host<->device synchronisation points;
+ *  - predictions, Jacobian blocks and the H*P row pairs produced by ekf_predict_measurements stay on the
+ *    device, keyed by featureIndex; ekf_match / ekf_ransac / ekf_update / ekf_rescue consume them, which is how
+ *    the reference's index-aligned (prediction, Jacobian, match) vectors (EKF/Update.h:47) are expressed here.
+ *  - there is no CPU fallback: every compute entry point returns EKF_ERR_NO_DEVICE without a usable GPU.
+ */
+#ifndef EKF_ENGINE_H
+#define EKF_ENGINE_H
+
+#include "ekf_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct EkfEngine EkfEngine;
+
+enum {
+    EKF_PRECISION_F64 = 0, /* covariance and work matrices in fp64 (reference arithmetic)                   */
+    EKF_PRECISION_F32 = 1  /* covariance, H*P and the rank-m downdate in fp32 (MFMA f32); S, its Cholesky     */
+                           /* factor, the state and all Jacobians stay fp64                                   */
+};
+
+typedef struct EkfEngineConfig {
+    EkfCamera cam;
+    EkfParams par;
+    int32_t max_features;  /* map capacity N_max; state capacity is 13 + 6 N_max                            */
+    int32_t max_keypoints; /* per-frame keypoint capacity                                                    */
+    int32_t precision;     /* EKF_PRECISION_*                                                                */
+    int32_t device;        /* HIP device ordinal, or -1 for the current device                               */
+    int32_t ransac_batch;  /* hypotheses evaluated per launch (0 = default 32)                               */
+    int32_t flags;         /* reserved, 0                                                                    */
+} EkfEngineConfig;
+
+/* Per-step counters; same layout as the oracle's OrcStepInfo. */
+typedef struct EkfStepInfo {
+    int32_t n_predicted;
+    int32_t n_matches;
+    int32_t n_hypotheses;
+    int32_t n_inliers;
+    int32_t n_outliers;
+    int32_t n_rescued;
+    int32_t status;
+    int32_t _pad;
+} EkfStepInfo;
+
+/* Accumulated GPU time per stage, in milliseconds, under the reference's own stage names
+ * (EKF/EKF.cpp:291,344,410,437,513,539) plus the dominant kernel on its own. */
+typedef struct EkfStageTimes {
+    double prediction_ms;
+    double matching_ms;
+    double ransac_ms;
+    double update_li_ms;
+    double rescue_ms;
+    double update_hi_ms;
+    double p_update_kernel_ms; /* sum over launches of the P <- P - B'B kernel (HIP events on the engine stream) */
+    int64_t p_update_launches;
+    double p_update_flops;     /* algorithmic flops of those launches: n^2 * m each (upper triangle)          */
+    double p_update_bytes;     /* algorithmic bytes: 2 * n^2 * w / 2 ... see DESIGN.md                        */
+    int64_t steps;
+} EkfStageTimes;
+
+/* -- life cycle ------------------------------------------------------------------------------------------ */
+/* Replaces EKF::EKF (EKF/EKF.cpp:124-165) minus file I/O: the two config PODs are passed by value. */
+int ekf_engine_create(const EkfEngineConfig *cfg, EkfEngine **out);
+void ekf_engine_destroy(EkfEngine *e);
+const char *ekf_last_error(const EkfEngine *e);
+int ekf_abi_version(void);
+/* Number of usable HIP devices (0 when none); never fails. */
+int ekf_device_count(void);
+
+/* -- host <-> device synchronisation --------------------------------------------------------------------- */
+/* Loads State (EKF/State.h:40-81: position, orientation, linearVelocity, angularVelocity as x13 =
+ * r(3) q(4: w x y z) v(3) w(3); mapFeatures as 6 doubles per feature + type + 32-byte descriptor) and
+ * EKF::stateCovarianceMatrix (n x n row-major doubles, leading dimension n).  Covariance positions are assigned
+ * in map order exactly as MapFeature::covarianceMatrixPos (EKF/MapFeature.h:68). */
+int ekf_set_state(EkfEngine *e, const double x13[13], int n_features, const double *feature_pos,
+                  const int32_t *feature_type, const uint8_t *desc32, const double *P);
+/* Any output pointer may be NULL.  P is written as n x n doubles. */
+int ekf_get_state(EkfEngine *e, double x13[13], double *feature_pos, double *P);
+int ekf_state_dim(const EkfEngine *e);
+int ekf_num_features(const EkfEngine *e);
+
+/* -- stages ---------------------------------------------------------------------------------------------- */
+/* stateAndCovariancePrediction(State&, Matd&)            EKF/StateAndCovariancePrediction.h:41 (.cpp:244-253) */
+int ekf_predict(EkfEngine *e);
+
+/* predictCameraMeasurements(state, P, features, featureIndexes, preds, jacobians, notPredicted)
+ *                                                        EKF/MeasurementPrediction.h:59 (.cpp:705-719)
+ * feat_idx == NULL / count == 0 predicts every map feature.  Outputs (all optional): predictions in input order,
+ * Hs (2x13 doubles each) and Hf (2x6 doubles each) Jacobian blocks. */
+int ekf_predict_measurements(EkfEngine *e, const int32_t *feat_idx, int count, EkfPrediction *preds, int *n_preds,
+                             double *Hs, double *Hf);
+
+/* predictMeasurementState(state, features, featureIndexes, preds, notPredicted)
+ *                                                        EKF/MeasurementPrediction.h:41 (.cpp:203-265)
+ * on the engine's current state, all features; no Jacobians, device tables untouched. */
+int ekf_predict_measurement_state(EkfEngine *e, EkfPrediction *preds, int *n_preds);
+
+/* matchPredictedFeatures(image, features, predictions, matches)   EKF/Matching.h:66 (.cpp:181-264),
+ * the stage downstream of the detector/descriptor (ellipse gate + descriptor distance + 2-best selection,
+ * .cpp:217-262) for the keypoints of this frame, against the predictions of the last full
+ * ekf_predict_measurements call. */
+int ekf_match(EkfEngine *e, const EkfKeypoint *kps, const uint8_t *desc32, int n_kp, EkfMatch *matches,
+              int *n_matches);
+
+/* ransac(state, P, preds, jacobians, matches, inliers, inlierPreds, inlierJacobians, outliers)
+ *                                                        EKF/1PointRansac.h:42 (.cpp:101-234)
+ * inlier_mask[i] = 1 for matches kept as low-innovation inliers.  n_hypotheses (optional) = hypotheses the
+ * sequential reference loop would have evaluated. */
+int ekf_ransac(EkfEngine *e, const EkfMatch *matches, int M, uint8_t *inlier_mask, int *n_hypotheses);
+
+/* update(state, P, matches, preds, jacobians)            EKF/Update.h:48 (.cpp:282-319) */
+int ekf_update(EkfEngine *e, const EkfMatch *matches, int M);
+
+/* updateOnlyState(preds, matches, jacobians, state, P)   EKF/Update.h:42 (.cpp:269-275) */
+int ekf_update_only_state(EkfEngine *e, const EkfMatch *matches, int M);
+
+/* rescueOutliers(outlierMatches, preds, jacobians, rescued...)    EKF/EKF.cpp:68-119
+ * against the predictions of the last ekf_predict_measurements call that covered those features. */
+int ekf_rescue(EkfEngine *e, const EkfMatch *outliers, int M, uint8_t *rescued_mask);
+
+/* EKF::step(image) with a fixed map                      EKF/EKF.h:57 (.cpp:242-556), fed the frame's keypoints. */
+int ekf_step(EkfEngine *e, const EkfKeypoint *kps, const uint8_t *desc32, int n_kp, EkfStepInfo *info);
+
+/* -- pre-staged sequences (inputs resident in HBM before a timed region) ---------------------------------- */
+int ekf_frames_upload(EkfEngine *e, int n_frames, const int32_t *kp_counts, const EkfKeypoint *kps_concat,
+                      const uint8_t *desc_concat);
+int ekf_step_frame(EkfEngine *e, int frame, EkfStepInfo *info);
+
+/* -- instrumentation ------------------------------------------------------------------------------------- */
+int ekf_timing_enable(EkfEngine *e, int on); /* HIP-event timing of stages and of the P-update kernel */
+int ekf_timing_reset(EkfEngine *e);
+int ekf_timing_get(EkfEngine *e, EkfStageTimes *out);
+int ekf_synchronize(EkfEngine *e);
+
+/* -- partition of the covariance rows across ranks (multi-GPU); pure host arithmetic -------- */
+/* Row block [row_begin, row_end) of P owned by `rank` of `world` for a map of n_features inverse-depth features:
+ * the 13 camera rows go to rank 0, features are split contiguously. */
+int ekf_shard_rows(int n_features, int world, int rank, int *row_begin, int *row_end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EKF_ENGINE_H */

@@ -1,0 +1,702 @@
+// engine.cpp -- C ABI of the MI355X EKF engine (see include/ekf_engine.h).  Host orchestration only: every
+// number is produced by the HIP kernels in kernels_*.hip; there is no CPU compute path.
+#include "engine.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+using namespace ekf;
+
+namespace ekf {
+void launch_partition(EkfEngine *e, const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0,
+                      int *cnt1);
+void launch_outlier_idx(EkfEngine *e, const EkfMatch *src, int M, int *idx);
+} // namespace ekf
+
+#define HIPCHK(call)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _st = (call);                                                                              \
+        if (_st != hipSuccess) {                                                                              \
+            e->err = std::string(#call) + ": " + hipGetErrorString(_st);                                      \
+            return EKF_ERR_HIP;                                                                               \
+        }                                                                                                     \
+    } while (0)
+
+template <typename T>
+static hipError_t dalloc(T **p, size_t count, bool zero = true)
+{
+    if (count == 0) count = 1;
+    hipError_t st = hipMalloc((void **)p, count * sizeof(T));
+    if (st == hipSuccess && zero) st = hipMemset(*p, 0, count * sizeof(T));
+    return st;
+}
+
+extern "C" {
+
+int ekf_abi_version(void) { return 1; }
+
+int ekf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ekf_shard_rows(int n_features, int world, int rank, int *row_begin, int *row_end)
+{
+    if (world <= 0 || rank < 0 || rank >= world || n_features < 0 || !row_begin || !row_end) return EKF_ERR_INVALID_ARG;
+    const int per = n_features / world, extra = n_features % world;
+    const int f0 = rank * per + (rank < extra ? rank : extra);
+    const int f1 = f0 + per + (rank < extra ? 1 : 0);
+    *row_begin = (rank == 0) ? 0 : 13 + 6 * f0;
+    *row_end = 13 + 6 * f1;
+    return EKF_OK;
+}
+
+const char *ekf_last_error(const EkfEngine *e) { return e ? e->err.c_str() : "null engine"; }
+
+void ekf_engine_destroy(EkfEngine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    DeviceArrays &d = e->d;
+    void *ptrs[] = {d.state,     d.feat_pos,  d.feat_type, d.feat_covpos, d.feat_desc, d.P,        d.pred_vis,
+                    d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,
+                    d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
+                    d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
+                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Linv,
+                    d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out,
+                    e->frames.kps, e->frames.desc};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto &ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto &pr : e->pu_events) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int ekf_engine_create(const EkfEngineConfig *cfg, EkfEngine **out)
+{
+    if (!cfg || !out || cfg->max_features <= 0) return EKF_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return EKF_ERR_NO_DEVICE;
+    EkfEngine *e = new (std::nothrow) EkfEngine();
+    if (!e) return EKF_ERR_CAPACITY;
+    e->cfg = *cfg;
+    if (e->cfg.ransac_batch <= 0) e->cfg.ransac_batch = 32;
+    if (cfg->device >= 0) e->device = cfg->device;
+    else if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
+    const EkfCamera &c = cfg->cam;
+    e->cam = CamD{c.fx, c.fy, c.k1, c.k2, c.cx, c.cy, c.dx, c.dy, c.pixelErrorX, c.pixelErrorY, c.angularVisionX,
+                  c.angularVisionY, c.pixelsX, c.pixelsY};
+    const EkfParams &p = cfg->par;
+    e->par = ParD{p.linearAccelSD, p.angularAccelSD, p.matchingCompCoefSecondBestVSFirst,
+                  p.ransacThresholdPredictDistance, p.ransacAllInliersProbability, p.ransacChi2Threshold};
+    e->f32 = cfg->precision == EKF_PRECISION_F32;
+    e->cap = cfg->max_features;
+    e->ncap = 13 + 6 * e->cap;
+    e->mcap = round_up(2 * e->cap, NB);
+    e->kcap = cfg->max_keypoints > 0 ? cfg->max_keypoints : 4 * e->cap;
+    e->ldP = round_up(e->ncap, LD_ALIGN);
+    e->ldS = round_up(e->mcap, 32);
+    auto fail = [&](hipError_t st, const char *what) {
+        e->err = std::string(what) + ": " + hipGetErrorString(st);
+        std::fprintf(stderr, "ekf_engine_create: %s\n", e->err.c_str());
+        ekf_engine_destroy(e);
+        return EKF_ERR_HIP;
+    };
+    hipError_t st;
+    if ((st = hipSetDevice(e->device)) != hipSuccess) return fail(st, "hipSetDevice");
+    if ((st = hipStreamCreate(&e->stream)) != hipSuccess) return fail(st, "hipStreamCreate");
+    DeviceArrays &d = e->d;
+    const size_t w = e->f32 ? 4 : 8;
+    const size_t cap = e->cap, mcap = e->mcap;
+#define ALLOC(ptr, count)                                                        \
+    if ((st = dalloc(&(ptr), (count))) != hipSuccess) return fail(st, "hipMalloc " #ptr)
+    ALLOC(d.state, ST_COUNT);
+    ALLOC(d.feat_pos, 6 * cap);
+    ALLOC(d.feat_type, cap);
+    ALLOC(d.feat_covpos, cap);
+    ALLOC(d.feat_desc, EKF_DESC_BYTES * cap);
+    {
+        uint8_t *raw = nullptr;
+        if ((st = dalloc(&raw, (size_t)round_up(e->ncap, LD_ALIGN) * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc P");
+        d.P = raw;
+        if ((st = dalloc(&raw, (size_t)mcap * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc HP");
+        d.HP = raw;
+        if ((st = dalloc(&raw, (size_t)mcap * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc A");
+        d.A = raw;
+    }
+    ALLOC(d.pred_vis, cap);
+    ALLOC(d.pred_uv, 2 * cap);
+    ALLOC(d.pred_vis2, cap);
+    ALLOC(d.pred_uv2, 2 * cap);
+    ALLOC(d.pred_S, 4 * cap);
+    ALLOC(d.Hs, 14 * cap);
+    ALLOC(d.Hf, 12 * cap);
+    ALLOC(d.work_idx, cap);
+    ALLOC(d.work_flag, cap);
+    ALLOC(d.plist, cap);
+    ALLOC(d.plist_sub, cap);
+    ALLOC(d.counts, CNT_COUNT);
+    ALLOC(d.kps, (size_t)e->kcap);
+    ALLOC(d.kdesc, (size_t)e->kcap * EKF_DESC_BYTES);
+    ALLOC(d.mt_valid, cap);
+    ALLOC(d.mt_kp, cap);
+    ALLOC(d.mt_dist, cap);
+    ALLOC(d.matches, cap);
+    ALLOC(d.msel, cap);
+    ALLOC(d.mout, cap);
+    ALLOC(d.match_of_feat, cap);
+    ALLOC(d.hyp_count, (size_t)e->cfg.ransac_batch);
+    ALLOC(d.hyp_flags, (size_t)e->cfg.ransac_batch * mcap);
+    ALLOC(d.best_flags, mcap);
+    ALLOC(d.S, (size_t)mcap * e->ldS);
+    ALLOC(d.nu, mcap);
+    ALLOC(d.Linv, NB * NB);
+    ALLOC(d.mHs, 14 * cap);
+    ALLOC(d.mHf, 12 * cap);
+    ALLOC(d.mpos, cap);
+    ALLOC(d.mdim, cap);
+    ALLOC(d.dx_part, (size_t)DX_SPLIT * e->ldP);
+    ALLOC(d.mask, mcap);
+    ALLOC(d.preds_out, cap);
+#undef ALLOC
+    for (auto &ev : e->ev)
+        if ((st = hipEventCreate(&ev)) != hipSuccess) return fail(st, "hipEventCreate");
+    e->h_counts.assign(CNT_COUNT, 0);
+    *out = e;
+    return EKF_OK;
+}
+
+int ekf_state_dim(const EkfEngine *e) { return e ? e->n : 0; }
+int ekf_num_features(const EkfEngine *e) { return e ? e->N : 0; }
+
+int ekf_synchronize(EkfEngine *e)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return EKF_OK;
+}
+
+// ------------------------------------------------------------------------------------------- state transfer
+int ekf_set_state(EkfEngine *e, const double x13[13], int n_features, const double *feature_pos,
+                  const int32_t *feature_type, const uint8_t *desc32, const double *P)
+{
+    if (!e || !x13 || n_features < 0 || (n_features > 0 && !feature_pos)) return EKF_ERR_INVALID_ARG;
+    if (n_features > e->cap) return EKF_ERR_CAPACITY;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    std::vector<int> type(n_features), covpos(n_features);
+    int pos = 13;
+    for (int i = 0; i < n_features; ++i) {
+        const int t = feature_type ? feature_type[i] : EKF_FEATURE_INVERSE_DEPTH;
+        if (t != EKF_FEATURE_DEPTH && t != EKF_FEATURE_INVERSE_DEPTH) return EKF_ERR_INVALID_ARG;
+        type[i] = t;
+        covpos[i] = pos;
+        pos += (t == EKF_FEATURE_INVERSE_DEPTH) ? 6 : 3;
+    }
+    const int n = pos;
+    double st[ST_R + 9];
+    std::memcpy(st, x13, 13 * sizeof(double));
+    {
+        const double r = x13[3], x = x13[4], y = x13[5], z = x13[6];
+        double *M = st + ST_R;
+        M[0] = r * r + x * x - y * y - z * z; M[1] = 2 * (x * y - r * z); M[2] = 2 * (z * x + r * y);
+        M[3] = 2 * (x * y + r * z); M[4] = r * r - x * x + y * y - z * z; M[5] = 2 * (y * z - r * x);
+        M[6] = 2 * (z * x - r * y); M[7] = 2 * (y * z + r * x); M[8] = r * r - x * x - y * y + z * z;
+    }
+    HIPCHK(hipMemcpy(e->d.state, st, sizeof(st), hipMemcpyHostToDevice));
+    if (n_features > 0) {
+        HIPCHK(hipMemcpy(e->d.feat_pos, feature_pos, (size_t)6 * n_features * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d.feat_type, type.data(), (size_t)n_features * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d.feat_covpos, covpos.data(), (size_t)n_features * sizeof(int), hipMemcpyHostToDevice));
+        if (desc32)
+            HIPCHK(hipMemcpy(e->d.feat_desc, desc32, (size_t)n_features * EKF_DESC_BYTES, hipMemcpyHostToDevice));
+        else
+            HIPCHK(hipMemset(e->d.feat_desc, 0, (size_t)n_features * EKF_DESC_BYTES));
+    }
+    if (P) {
+        const size_t w = e->f32 ? 4 : 8;
+        HIPCHK(hipMemset(e->d.P, 0, (size_t)round_up(e->ncap, LD_ALIGN) * e->ldP * w));
+        if (e->f32) {
+            std::vector<float> tmp((size_t)n * n);
+            for (size_t i = 0; i < (size_t)n * n; ++i) tmp[i] = (float)P[i];
+            HIPCHK(hipMemcpy2D(e->d.P, (size_t)e->ldP * 4, tmp.data(), (size_t)n * 4, (size_t)n * 4, n,
+                               hipMemcpyHostToDevice));
+        } else {
+            HIPCHK(hipMemcpy2D(e->d.P, (size_t)e->ldP * 8, P, (size_t)n * 8, (size_t)n * 8, n, hipMemcpyHostToDevice));
+        }
+        e->p_exact_sym = false;
+    }
+    HIPCHK(hipMemset(e->d.pred_vis, 0, (size_t)e->cap * sizeof(int)));
+    e->N = n_features;
+    e->n = n;
+    e->n_pred = 0;
+    return EKF_OK;
+}
+
+int ekf_get_state(EkfEngine *e, double x13[13], double *feature_pos, double *P)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (x13) HIPCHK(hipMemcpy(x13, e->d.state, 13 * sizeof(double), hipMemcpyDeviceToHost));
+    if (feature_pos && e->N > 0)
+        HIPCHK(hipMemcpy(feature_pos, e->d.feat_pos, (size_t)6 * e->N * sizeof(double), hipMemcpyDeviceToHost));
+    if (P) {
+        const int n = e->n;
+        if (e->f32) {
+            std::vector<float> tmp((size_t)n * n);
+            HIPCHK(hipMemcpy2D(tmp.data(), (size_t)n * 4, e->d.P, (size_t)e->ldP * 4, (size_t)n * 4, n,
+                               hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < (size_t)n * n; ++i) P[i] = (double)tmp[i];
+        } else {
+            HIPCHK(hipMemcpy2D(P, (size_t)n * 8, e->d.P, (size_t)e->ldP * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost));
+        }
+    }
+    return EKF_OK;
+}
+
+// ----------------------------------------------------------------------------------------------- utilities
+static int read_counts(EkfEngine *e)
+{
+    HIPCHK(hipMemcpyAsync(e->h_counts.data(), e->d.counts, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return EKF_OK;
+}
+
+static int check_async(EkfEngine *e)
+{
+    HIPCHK(hipGetLastError());
+    return EKF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- stages
+int ekf_predict(EkfEngine *e)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    launch_predict(e);
+    return check_async(e);
+}
+
+// device-side core of predictCameraMeasurements; leaves the count in h_counts
+static int predict_measurements_dev(EkfEngine *e, const int *d_idx, int count, int *n_out)
+{
+    launch_predict_features(e, d_idx, d_idx ? count : e->N, false);
+    int rc = read_counts(e);
+    if (rc) return rc;
+    const int np = e->h_counts[d_idx ? CNT_NPRED_SUB : CNT_NPRED];
+    launch_hp_rows(e, d_idx ? e->d.plist_sub : e->d.plist, np);
+    if (!d_idx) e->n_pred = np;
+    *n_out = np;
+    return check_async(e);
+}
+
+static int download_predictions(EkfEngine *e, const int *d_list, int np, EkfPrediction *preds, double *Hs, double *Hf)
+{
+    if (np <= 0) return EKF_OK;
+    const int N = e->N;
+    std::vector<int> list(np);
+    std::vector<double> uv(2 * (size_t)N), S(4 * (size_t)N), hs(14 * (size_t)N), hf(12 * (size_t)N);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(list.data(), d_list, np * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(uv.data(), e->d.pred_uv, uv.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(S.data(), e->d.pred_S, S.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hs.data(), e->d.Hs, hs.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hf.data(), e->d.Hf, hf.size() * 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < np; ++k) {
+        const int fi = list[k];
+        if (preds) {
+            preds[k].featureIndex = fi;
+            preds[k]._pad = 0;
+            preds[k].imagePos[0] = uv[2 * fi];
+            preds[k].imagePos[1] = uv[2 * fi + 1];
+            for (int i = 0; i < 4; ++i) preds[k].covarianceMatrix[i] = S[4 * fi + i];
+        }
+        if (Hs)
+            for (int r = 0; r < 2; ++r)
+                for (int c = 0; c < 13; ++c) Hs[(size_t)26 * k + r * 13 + c] = c < 7 ? hs[14 * fi + r * 7 + c] : 0.0;
+        if (Hf)
+            for (int i = 0; i < 12; ++i) Hf[(size_t)12 * k + i] = hf[12 * fi + i];
+    }
+    return EKF_OK;
+}
+
+int ekf_predict_measurements(EkfEngine *e, const int32_t *feat_idx, int count, EkfPrediction *preds, int *n_preds,
+                             double *Hs, double *Hf)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    const bool sub = feat_idx && count > 0;
+    if (sub) {
+        if (count > e->cap) return EKF_ERR_CAPACITY;
+        for (int i = 0; i < count; ++i)
+            if (feat_idx[i] < 0 || feat_idx[i] >= e->N) return EKF_ERR_INVALID_ARG;
+        HIPCHK(hipMemcpyAsync(e->d.work_idx, feat_idx, (size_t)count * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    }
+    int np = 0;
+    int rc = predict_measurements_dev(e, sub ? e->d.work_idx : nullptr, count, &np);
+    if (rc) return rc;
+    if (n_preds) *n_preds = np;
+    if (preds || Hs || Hf) return download_predictions(e, sub ? e->d.plist_sub : e->d.plist, np, preds, Hs, Hf);
+    return EKF_OK;
+}
+
+int ekf_predict_measurement_state(EkfEngine *e, EkfPrediction *preds, int *n_preds)
+{
+    if (!e || !preds || !n_preds) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    launch_state_only_predict(e, e->d.preds_out);
+    int rc = read_counts(e);
+    if (rc) return rc;
+    const int np = e->h_counts[CNT_NPRED_SUB];
+    if (np > 0) HIPCHK(hipMemcpy(preds, e->d.preds_out, (size_t)np * sizeof(EkfPrediction), hipMemcpyDeviceToHost));
+    *n_preds = np;
+    return EKF_OK;
+}
+
+static int upload_keypoints(EkfEngine *e, const EkfKeypoint *kps, const uint8_t *desc32, int n_kp)
+{
+    if (n_kp > e->kcap) return EKF_ERR_CAPACITY;
+    if (n_kp > 0) {
+        HIPCHK(hipMemcpyAsync(e->d.kps, kps, (size_t)n_kp * sizeof(EkfKeypoint), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->d.kdesc, desc32, (size_t)n_kp * EKF_DESC_BYTES, hipMemcpyHostToDevice, e->stream));
+    }
+    e->n_kp = n_kp;
+    return EKF_OK;
+}
+
+static int match_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_desc, int n_kp, int *n_matches)
+{
+    // kernels read e->d.kps / kdesc; staged frames alias them in
+    EkfKeypoint *save_k = e->d.kps;
+    uint8_t *save_d = e->d.kdesc;
+    e->d.kps = const_cast<EkfKeypoint *>(d_kps);
+    e->d.kdesc = const_cast<uint8_t *>(d_desc);
+    launch_match(e, e->n_pred, n_kp);
+    e->d.kps = save_k;
+    e->d.kdesc = save_d;
+    int rc = read_counts(e);
+    if (rc) return rc;
+    *n_matches = e->h_counts[CNT_NMATCH];
+    return check_async(e);
+}
+
+int ekf_match(EkfEngine *e, const EkfKeypoint *kps, const uint8_t *desc32, int n_kp, EkfMatch *matches,
+              int *n_matches)
+{
+    if (!e || n_kp < 0 || (n_kp > 0 && (!kps || !desc32))) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    int rc = upload_keypoints(e, kps, desc32, n_kp);
+    if (rc) return rc;
+    int M = 0;
+    rc = match_dev(e, e->d.kps, e->d.kdesc, n_kp, &M);
+    if (rc) return rc;
+    if (n_matches) *n_matches = M;
+    if (matches && M > 0) HIPCHK(hipMemcpy(matches, e->d.matches, (size_t)M * sizeof(EkfMatch), hipMemcpyDeviceToHost));
+    return EKF_OK;
+}
+
+// RANSAC over e->d.matches[0..M); on return best_flags holds the inlier mask, h_counts the loop state
+static int ransac_dev(EkfEngine *e, int M)
+{
+    launch_match_index(e, M);
+    launch_ransac_init(e, M);
+    const int batch = e->cfg.ransac_batch;
+    for (int h0 = 0; h0 < M; h0 += batch) {
+        launch_ransac_batch(e, M, h0, batch);
+        int rc = read_counts(e);
+        if (rc) return rc;
+        if (e->h_counts[CNT_RS_DONE]) break;
+    }
+    return check_async(e);
+}
+
+static int validate_matches(const EkfEngine *e, const EkfMatch *m, int M)
+{
+    if (M < 0 || M > e->cap || (M > 0 && !m)) return EKF_ERR_INVALID_ARG;
+    for (int i = 0; i < M; ++i)
+        if (m[i].featureIndex < 0 || m[i].featureIndex >= e->N) return EKF_ERR_INVALID_ARG;
+    return EKF_OK;
+}
+
+int ekf_ransac(EkfEngine *e, const EkfMatch *matches, int M, uint8_t *inlier_mask, int *n_hypotheses)
+{
+    if (!e || !inlier_mask) return EKF_ERR_INVALID_ARG;
+    int rc = validate_matches(e, matches, M);
+    if (rc) return rc;
+    if (n_hypotheses) *n_hypotheses = 0;
+    if (M == 0) return EKF_OK;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->d.matches, matches, (size_t)M * sizeof(EkfMatch), hipMemcpyHostToDevice, e->stream));
+    rc = ransac_dev(e, M);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(inlier_mask, e->d.best_flags, (size_t)M, hipMemcpyDeviceToHost));
+    if (n_hypotheses) *n_hypotheses = e->h_counts[CNT_RS_NEXT];
+    return EKF_OK;
+}
+
+// update with the matches in e->d.msel[0..M)
+static int update_dev(EkfEngine *e, int M, bool update_cov)
+{
+    if (M <= 0) return EKF_OK; // Update.cpp:292
+    EkfMatch *save = e->d.matches;
+    e->d.matches = e->d.msel;
+    launch_update(e, M, update_cov);
+    e->d.matches = save;
+    return check_async(e);
+}
+
+static int finish_update(EkfEngine *e)
+{
+    int rc = read_counts(e);
+    if (rc) return rc;
+    if (e->h_counts[CNT_ERR]) {
+        const int code = e->h_counts[CNT_ERR];
+        HIPCHK(hipMemsetAsync(e->d.counts + CNT_ERR, 0, sizeof(int), e->stream));
+        e->err = "S = H P H' + R is not positive definite";
+        return code;
+    }
+    return EKF_OK;
+}
+
+int ekf_update(EkfEngine *e, const EkfMatch *matches, int M)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    int rc = validate_matches(e, matches, M);
+    if (rc) return rc;
+    if (M == 0) return EKF_OK;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->d.msel, matches, (size_t)M * sizeof(EkfMatch), hipMemcpyHostToDevice, e->stream));
+    rc = update_dev(e, M, true);
+    if (rc) return rc;
+    return finish_update(e);
+}
+
+int ekf_update_only_state(EkfEngine *e, const EkfMatch *matches, int M)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    int rc = validate_matches(e, matches, M);
+    if (rc) return rc;
+    if (M == 0) return EKF_OK;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->d.msel, matches, (size_t)M * sizeof(EkfMatch), hipMemcpyHostToDevice, e->stream));
+    rc = update_dev(e, M, false);
+    if (rc) return rc;
+    return finish_update(e);
+}
+
+int ekf_rescue(EkfEngine *e, const EkfMatch *outliers, int M, uint8_t *rescued_mask)
+{
+    if (!e || !rescued_mask) return EKF_ERR_INVALID_ARG;
+    int rc = validate_matches(e, outliers, M);
+    if (rc) return rc;
+    if (M == 0) return EKF_OK;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->d.mout, outliers, (size_t)M * sizeof(EkfMatch), hipMemcpyHostToDevice, e->stream));
+    EkfMatch *save = e->d.matches;
+    e->d.matches = e->d.mout;
+    launch_rescue(e, M);
+    e->d.matches = save;
+    HIPCHK(hipMemcpyAsync(rescued_mask, e->d.mask, (size_t)M, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return check_async(e);
+}
+
+// ------------------------------------------------------------------------------------------------------ step
+static void harvest_pu_events(EkfEngine *e)
+{
+    for (size_t i = 0; i < e->pu_events.size(); ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->pu_events[i].first, e->pu_events[i].second) == hipSuccess) {
+            e->times.p_update_kernel_ms += ms;
+            e->times.p_update_launches += 1;
+            e->times.p_update_flops += e->pu_work[i];
+            e->times.p_update_bytes += 0.0;
+        }
+        (void)hipEventDestroy(e->pu_events[i].first);
+        (void)hipEventDestroy(e->pu_events[i].second);
+    }
+    e->pu_events.clear();
+    e->pu_work.clear();
+}
+
+struct StageTimer {
+    EkfEngine *e;
+    std::vector<hipEvent_t> evs;
+    explicit StageTimer(EkfEngine *eng) : e(eng) {}
+    void mark()
+    {
+        if (!e->timing) return;
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return;
+        (void)hipEventRecord(ev, e->stream);
+        evs.push_back(ev);
+    }
+    void finish()
+    {
+        if (!e->timing || evs.size() < 7) {
+            for (auto ev : evs) (void)hipEventDestroy(ev);
+            return;
+        }
+        (void)hipStreamSynchronize(e->stream);
+        double *dst[6] = {&e->times.prediction_ms, &e->times.matching_ms, &e->times.ransac_ms,
+                          &e->times.update_li_ms,  &e->times.rescue_ms,   &e->times.update_hi_ms};
+        for (int i = 0; i < 6; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, evs[i], evs[i + 1]) == hipSuccess) *dst[i] += ms;
+        }
+        for (auto ev : evs) (void)hipEventDestroy(ev);
+        e->times.steps += 1;
+        harvest_pu_events(e);
+    }
+};
+
+// EKF::step (EKF.cpp:242-556) with keypoints already on the device
+static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_desc, int n_kp, EkfStepInfo *info)
+{
+    EkfStepInfo li;
+    std::memset(&li, 0, sizeof(li));
+    int status = EKF_OK, rc;
+    StageTimer tm(e);
+    tm.mark();
+    // 1-2. prediction (:273-284)
+    launch_predict(e);
+    int np = 0;
+    if ((rc = predict_measurements_dev(e, nullptr, e->N, &np))) return rc;
+    li.n_predicted = np;
+    tm.mark();
+    // 4. matching (:337)
+    int M = 0;
+    if ((rc = match_dev(e, d_kps, d_desc, n_kp, &M))) return rc;
+    li.n_matches = M;
+    tm.mark();
+    // 6. 1-point RANSAC (:402); predictions/Jacobians are looked up by featureIndex (:368-392)
+    int ni = 0, no = 0;
+    if (M > 0) {
+        if ((rc = ransac_dev(e, M))) return rc;
+        li.n_hypotheses = e->h_counts[CNT_RS_NEXT];
+        ni = e->h_counts[CNT_RS_BEST];
+        no = M - ni;
+        launch_partition(e, e->d.matches, M, e->d.best_flags, e->d.msel, e->d.mout, nullptr);
+    }
+    li.n_inliers = ni;
+    li.n_outliers = no;
+    tm.mark();
+    // 7. low-innovation update (:430)
+    if ((rc = update_dev(e, ni, true))) return rc;
+    tm.mark();
+    // 8-9. re-predict the outliers with the updated state / covariance, rescue (:473-506)
+    int nr = 0;
+    if (no > 0) {
+        launch_outlier_idx(e, e->d.mout, no, e->d.work_idx);
+        int nop = 0;
+        if ((rc = predict_measurements_dev(e, e->d.work_idx, no, &nop))) return rc;
+        if (e->h_counts[CNT_ERR]) status = e->h_counts[CNT_ERR];
+        if (nop > 0) {
+            EkfMatch *save = e->d.matches;
+            e->d.matches = e->d.mout;
+            launch_rescue(e, no);
+            e->d.matches = save;
+            launch_partition(e, e->d.mout, no, e->d.mask, e->d.msel, nullptr, e->d.counts + CNT_NRESC);
+            if ((rc = read_counts(e))) return rc;
+            nr = e->h_counts[CNT_NRESC];
+        }
+    }
+    li.n_rescued = nr;
+    tm.mark();
+    // 10. high-innovation update (:529-532)
+    if ((rc = update_dev(e, nr, true))) return rc;
+    tm.mark();
+    if ((rc = read_counts(e))) return rc;
+    if (e->h_counts[CNT_ERR]) {
+        status = e->h_counts[CNT_ERR];
+        HIPCHK(hipMemsetAsync(e->d.counts + CNT_ERR, 0, sizeof(int), e->stream));
+        e->err = "S = H P H' + R is not positive definite";
+    }
+    tm.finish();
+    li.status = status;
+    if (info) *info = li;
+    return status;
+}
+
+int ekf_step(EkfEngine *e, const EkfKeypoint *kps, const uint8_t *desc32, int n_kp, EkfStepInfo *info)
+{
+    if (!e || n_kp < 0 || (n_kp > 0 && (!kps || !desc32))) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    int rc = upload_keypoints(e, kps, desc32, n_kp);
+    if (rc) return rc;
+    return step_dev(e, e->d.kps, e->d.kdesc, n_kp, info);
+}
+
+int ekf_frames_upload(EkfEngine *e, int n_frames, const int32_t *kp_counts, const EkfKeypoint *kps_concat,
+                      const uint8_t *desc_concat)
+{
+    if (!e || n_frames < 0 || (n_frames > 0 && (!kp_counts || !kps_concat || !desc_concat))) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->frames.kps) (void)hipFree(e->frames.kps);
+    if (e->frames.desc) (void)hipFree(e->frames.desc);
+    e->frames = Frames();
+    size_t total = 0;
+    for (int i = 0; i < n_frames; ++i) {
+        if (kp_counts[i] < 0) return EKF_ERR_INVALID_ARG;
+        e->frames.offset.push_back((int)total);
+        e->frames.count.push_back(kp_counts[i]);
+        total += (size_t)kp_counts[i];
+    }
+    e->frames.n = n_frames;
+    if (total == 0) return EKF_OK;
+    HIPCHK(hipMalloc((void **)&e->frames.kps, total * sizeof(EkfKeypoint)));
+    HIPCHK(hipMalloc((void **)&e->frames.desc, total * EKF_DESC_BYTES));
+    HIPCHK(hipMemcpy(e->frames.kps, kps_concat, total * sizeof(EkfKeypoint), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->frames.desc, desc_concat, total * EKF_DESC_BYTES, hipMemcpyHostToDevice));
+    return EKF_OK;
+}
+
+int ekf_step_frame(EkfEngine *e, int frame, EkfStepInfo *info)
+{
+    if (!e || frame < 0 || frame >= e->frames.n) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t off = (size_t)e->frames.offset[frame];
+    return step_dev(e, e->frames.kps + off, e->frames.desc + off * EKF_DESC_BYTES, e->frames.count[frame], info);
+}
+
+// -------------------------------------------------------------------------------------------------- timing
+int ekf_timing_enable(EkfEngine *e, int on)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    e->timing = on != 0;
+    return EKF_OK;
+}
+
+int ekf_timing_reset(EkfEngine *e)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    (void)hipStreamSynchronize(e->stream);
+    harvest_pu_events(e);
+    std::memset(&e->times, 0, sizeof(e->times));
+    return EKF_OK;
+}
+
+int ekf_timing_get(EkfEngine *e, EkfStageTimes *out)
+{
+    if (!e || !out) return EKF_ERR_INVALID_ARG;
+    (void)hipStreamSynchronize(e->stream);
+    harvest_pu_events(e);
+    *out = e->times;
+    return EKF_OK;
+}
+
+} // extern "C"

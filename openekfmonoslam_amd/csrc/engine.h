@@ -1,0 +1,140 @@
+// engine.h -- internal layout of the device-resident filter and the kernel launchers (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ekf_engine.h"
+#include "device_math.h"
+
+namespace ekf {
+
+constexpr int NB = 32;          // Cholesky panel width
+constexpr int LD_ALIGN = 128;   // leading dimensions are multiples of this many elements
+constexpr int DX_SPLIT = 16;    // k-splits of the dx = B' z reduction
+
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// integer slots of the device counter block
+enum {
+    CNT_NPRED = 0,    // predictions of the last full prediction
+    CNT_NPRED_SUB,    // predictions of the last subset prediction
+    CNT_NMATCH,       // matches produced by k_match
+    CNT_ERR,          // sticky error flag (Cholesky breakdown, ...)
+    CNT_RS_BEST,      // RANSAC: best support size
+    CNT_RS_BESTH,     // RANSAC: hypothesis index of the best
+    CNT_RS_NHYP,      // RANSAC: adaptive hypothesis bound
+    CNT_RS_NEXT,      // RANSAC: next hypothesis to examine
+    CNT_RS_DONE,      // RANSAC: loop finished
+    CNT_NRESC,        // rescued count
+    CNT_COUNT = 16
+};
+
+// doubles in the device state block
+enum { ST_X = 0, ST_R = 13, ST_F = 32, ST_GQG = 32 + 169, ST_JN = 32 + 338, ST_COUNT = 32 + 338 + 16 };
+
+struct DeviceArrays {
+    // map + state
+    double *state = nullptr;    // ST_COUNT doubles: x13, R, F, GQG, Jnorm
+    double *feat_pos = nullptr; // 6 per feature
+    int *feat_type = nullptr;
+    int *feat_covpos = nullptr;
+    uint8_t *feat_desc = nullptr;
+    void *P = nullptr; // T [ncap x ldP]
+    // prediction tables, keyed by feature index
+    int *pred_vis = nullptr;
+    double *pred_uv = nullptr; // 2 per feature
+    int *pred_vis2 = nullptr;    // scratch copies for state-only predictions
+    double *pred_uv2 = nullptr;
+    double *pred_S = nullptr;  // 4 per feature
+    double *Hs = nullptr;      // 2x7 per feature
+    double *Hf = nullptr;      // 2x6 per feature
+    void *HP = nullptr;        // T [2*cap x ldP]: rows 2f, 2f+1 = H_f P
+    // work lists
+    int *work_idx = nullptr;   // input feature indices of a subset prediction
+    int *work_flag = nullptr;  // per work item: predicted?
+    int *plist = nullptr;      // compacted feature indices, full prediction
+    int *plist_sub = nullptr;  // compacted feature indices, subset prediction
+    int *counts = nullptr;     // CNT_COUNT ints
+    // keypoints of the current frame
+    EkfKeypoint *kps = nullptr;
+    uint8_t *kdesc = nullptr;
+    // matching
+    int *mt_valid = nullptr;  // per prediction slot
+    int *mt_kp = nullptr;
+    float *mt_dist = nullptr;
+    EkfMatch *matches = nullptr; // compacted matches (prediction order) / uploaded matches
+    EkfMatch *msel = nullptr;    // matches selected for an update (inliers / rescued), update order
+    EkfMatch *mout = nullptr;    // outlier matches
+    EkfPrediction *preds_out = nullptr; // staging for prediction downloads
+    int *match_of_feat = nullptr;
+    // RANSAC
+    int *hyp_count = nullptr;
+    uint8_t *hyp_flags = nullptr;  // batch x mcap
+    uint8_t *best_flags = nullptr; // mcap
+    // update
+    void *A = nullptr;   // T [mcap x ldP] : rows of H P for the selected matches, overwritten by B = inv(L) A
+    double *S = nullptr; // mcap x ldS (lower triangle used)
+    double *nu = nullptr;
+    double *Linv = nullptr; // NB x NB of the current diagonal block
+    double *mHs = nullptr;  // per selected match
+    double *mHf = nullptr;
+    int *mpos = nullptr;
+    int *mdim = nullptr;
+    double *dx_part = nullptr; // DX_SPLIT x ldP
+    uint8_t *mask = nullptr;   // generic byte mask output (rescue)
+};
+
+struct Frames {
+    int n = 0;
+    std::vector<int> offset, count;
+    EkfKeypoint *kps = nullptr;
+    uint8_t *desc = nullptr;
+};
+
+} // namespace ekf
+
+struct EkfEngine {
+    EkfEngineConfig cfg;
+    ekf::CamD cam;
+    ekf::ParD par;
+    int device = 0;
+    int cap = 0, ncap = 0, mcap = 0, kcap = 0;
+    int ldP = 0, ldS = 0;
+    int N = 0, n = 0;
+    bool f32 = false;
+    bool p_exact_sym = false; // P known to be bitwise symmetric (engine-maintained invariant)
+    int n_pred = 0;           // predictions of the last full prediction
+    int n_kp = 0;
+    hipStream_t stream = nullptr;
+    ekf::DeviceArrays d;
+    ekf::Frames frames;
+    std::string err;
+    // timing
+    bool timing = false;
+    EkfStageTimes times{};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pu_events; // P-update kernel brackets not yet harvested
+    std::vector<double> pu_work;                               // n^2 m of each bracket
+    // host scratch
+    std::vector<int> h_counts;
+};
+
+namespace ekf {
+
+// ---- launchers (kernels_*.hip) ; T selected by e->f32 ----------------------------------------------------
+void launch_predict(EkfEngine *e);
+// full (idx == nullptr) or subset prediction; fills tables, compacted list and CNT_NPRED / CNT_NPRED_SUB
+void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool tables_only_state);
+void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list);
+void launch_match(EkfEngine *e, int n_pred, int n_kp);
+void launch_match_index(EkfEngine *e, int M);
+void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch);
+void launch_ransac_init(EkfEngine *e, int M);
+void launch_update(EkfEngine *e, int M, bool update_cov);
+void launch_rescue(EkfEngine *e, int M);
+void launch_state_only_predict(EkfEngine *e, EkfPrediction *d_out); // predictMeasurementState on current state
+
+} // namespace ekf

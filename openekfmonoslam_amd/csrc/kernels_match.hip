@@ -1,0 +1,263 @@
+// kernels_match.hip -- A5, the stage of matchPredictedFeatures downstream of the detector
+// (EKF/Matching.cpp:217-262): per prediction, gate the frame's keypoints with the uncertainty ellipse
+// (Core/EKFMath.cpp:271-351), Hamming distance on the 32-byte descriptors (Matching.cpp:74-90) and the reference's
+// 2-element "best" list (Matching.cpp:116-144, 169-175).  Integer/byte work, a few KB per block, all L2-resident:
+// one workgroup per prediction, keypoints strided over the lanes, candidates replayed in keypoint order so the
+// order-dependent list logic gives the reference's answer.
+#include "engine.h"
+
+namespace ekf {
+
+// cv::eigen of a symmetric 2x2 (Jacobi, eigenvalues descending, eigenvectors as rows) + the ellipse of
+// matrix2x2ToUncertaintyEllipse2D: float semi-axes, angle = atan(V[1][0] / V[0][0]).
+__device__ void ellipse_from_cov(const double *S, float *axes, double *angle)
+{
+    double A01 = S[1], W0 = S[0], W1 = S[3];
+    double V[4] = {1, 0, 0, 1};
+    for (int it = 0; it < 120; ++it) {
+        const double p = A01;
+        if (fabs(p) <= 2.220446049250313e-16) break;
+        const double y = (W1 - W0) * 0.5;
+        double t = fabs(y) + hypot(p, y);
+        double s = hypot(p, t);
+        const double c = t / s;
+        s = p / s;
+        t = (p / t) * p;
+        if (y < 0) { s = -s; t = -t; }
+        A01 = 0;
+        W0 -= t;
+        W1 += t;
+        for (int i = 0; i < 2; ++i) {
+            const double a0 = V[i], b0 = V[2 + i];
+            V[i] = a0 * c - b0 * s;
+            V[2 + i] = a0 * s + b0 * c;
+        }
+    }
+    if (W0 < W1) {
+        double t = W0; W0 = W1; W1 = t;
+        for (int i = 0; i < 2; ++i) { t = V[i]; V[i] = V[2 + i]; V[2 + i] = t; }
+    }
+    axes[0] = (float)(2.0 * sqrt(W0 * EKF_CHISQ_95_2));
+    axes[1] = (float)(2.0 * sqrt(W1 * EKF_CHISQ_95_2));
+    *angle = atan(V[2] / V[0]);
+}
+
+struct Gate {
+    double f1x, f1y, f2x, f2y, two_major;
+};
+
+// foci of the integer-axes ellipse (pointIsInsideEllipse, Core/EKFMath.cpp:302-334)
+__device__ void gate_from_ellipse(float cx, float cy, int aw, int ah, double angle, Gate *g)
+{
+    const double major = aw > ah ? aw : ah;
+    const double minor = aw < ah ? aw : ah;
+    const double fo = sqrt(major * major - minor * minor);
+    if (ah < aw) {
+        g->f1x = fo * cos(angle) + cx;  g->f1y = fo * sin(angle) + cy;
+        g->f2x = -fo * cos(angle) + cx; g->f2y = -fo * sin(angle) + cy;
+    } else {
+        g->f1x = fo * (-sin(angle)) + cx;  g->f1y = fo * cos(angle) + cy;
+        g->f2x = -fo * (-sin(angle)) + cx; g->f2y = -fo * cos(angle) + cy;
+    }
+    g->two_major = 2 * major;
+}
+
+__global__ void __launch_bounds__(256)
+k_match(const int *plist, const double *uv_tab, const double *S_tab, const uint8_t *feat_desc,
+        const EkfKeypoint *kps, const uint8_t *kdesc, int n_kp, double coef, int *mt_valid, int *mt_kp,
+        float *mt_dist)
+{
+    __shared__ Gate g;
+    __shared__ uint32_t qd[8];
+    __shared__ int c_idx[256];
+    __shared__ int c_dist[256];
+    __shared__ int wave_cnt[4];
+    // list state (thread 0)
+    __shared__ int s_list_n, s_front, s_dfront, s_dback, s_min;
+
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int fi = plist[k];
+    if (tid == 0) {
+        float axes[2];
+        double angle;
+        ellipse_from_cov(S_tab + 4 * fi, axes, &angle);
+        const int aw = (int)rintf(axes[0]), ah = (int)rintf(axes[1]); // cv::Size(Size2f): round half to even
+        gate_from_ellipse((float)uv_tab[2 * fi], (float)uv_tab[2 * fi + 1], aw, ah, angle, &g);
+        s_list_n = 0; s_front = -1; s_dfront = 0; s_dback = 0; s_min = -1;
+    }
+    if (tid < 8) qd[tid] = ((const uint32_t *)(feat_desc + (size_t)fi * EKF_DESC_BYTES))[tid];
+    __syncthreads();
+
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int base = 0; base < n_kp; base += 256) {
+        const int j = base + tid;
+        bool inside = false;
+        int dist = 0;
+        if (j < n_kp) {
+            const double px = (double)kps[j].x, py = (double)kps[j].y;
+            const double a1x = px - g.f1x, a1y = py - g.f1y, a2x = px - g.f2x, a2y = py - g.f2y;
+            const double ns = sqrt(a1x * a1x + a1y * a1y) + sqrt(a2x * a2x + a2y * a2y);
+            inside = ns <= g.two_major;
+            if (inside) {
+                const uint32_t *cd = (const uint32_t *)(kdesc + (size_t)j * EKF_DESC_BYTES);
+#pragma unroll
+                for (int w = 0; w < 8; ++w) dist += __popc(cd[w] ^ qd[w]);
+            }
+        }
+        // ordered compaction of this chunk's candidates
+        const unsigned long long bal = __ballot(inside);
+        const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wv; ++w) off += wave_cnt[w];
+        if (inside) {
+            c_idx[off + rank] = j;
+            c_dist[off + rank] = dist;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int nc = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            // findBestNMatches, nBest = 2: push_front when (dist < min) or fewer than two entries
+            for (int c = 0; c < nc; ++c) {
+                const int dc = c_dist[c];
+                if ((s_min >= 0 && dc < s_min) || s_list_n < 2) {
+                    s_min = s_min < 0 ? dc : min(s_min, dc);
+                    s_dback = s_dfront;
+                    s_front = c_idx[c];
+                    s_dfront = dc;
+                    if (s_list_n < 2) ++s_list_n;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        // matchICDescriptors: accept a lone candidate, or front <= back * coef (distances are floats in DMatch)
+        const bool ok = s_list_n == 1 || (s_list_n >= 2 && (double)(float)s_dfront <= (double)(float)s_dback * coef);
+        mt_valid[k] = ok ? 1 : 0;
+        mt_kp[k] = ok ? s_front : -1;
+        mt_dist[k] = (float)s_dfront;
+    }
+}
+
+// compacted match list in prediction order (matches.push_back order, Matching.cpp:247-262)
+__global__ void __launch_bounds__(1024)
+k_match_compact(const int *plist, int n_pred, const int *mt_valid, const int *mt_kp, const float *mt_dist,
+                const EkfKeypoint *kps, EkfMatch *out, int *out_count)
+{
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n_pred + 1023) / 1024;
+    const int b = tid * per, e = min(n_pred, b + per);
+    int c = 0;
+    for (int i = b; i < e; ++i) c += mt_valid[i];
+    part[tid] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int pos = part[tid] - c;
+    for (int i = b; i < e; ++i)
+        if (mt_valid[i]) {
+            EkfMatch m;
+            m.featureIndex = plist[i];
+            m.keypointIndex = mt_kp[i];
+            m.imagePos[0] = (double)kps[mt_kp[i]].x;
+            m.imagePos[1] = (double)kps[mt_kp[i]].y;
+            m.distance = mt_dist[i];
+            m._pad = 0.f;
+            out[pos++] = m;
+        }
+    if (tid == 1023) *out_count = part[1023];
+}
+
+void launch_match(EkfEngine *e, int n_pred, int n_kp)
+{
+    if (n_pred <= 0) {
+        (void)hipMemsetAsync(e->d.counts + CNT_NMATCH, 0, sizeof(int), e->stream);
+        return;
+    }
+    k_match<<<n_pred, 256, 0, e->stream>>>(e->d.plist, e->d.pred_uv, e->d.pred_S, e->d.feat_desc, e->d.kps,
+                                           e->d.kdesc, n_kp, e->cfg.par.matchingCompCoefSecondBestVSFirst,
+                                           e->d.mt_valid, e->d.mt_kp, e->d.mt_dist);
+    k_match_compact<<<1, 1024, 0, e->stream>>>(e->d.plist, n_pred, e->d.mt_valid, e->d.mt_kp, e->d.mt_dist,
+                                               e->d.kps, e->d.matches, e->d.counts + CNT_NMATCH);
+}
+
+// match_of_feat[f] = smallest match index whose featureIndex is f, or -1 (the linear searches of
+// 1PointRansac.cpp:58-82 stop at the first hit)
+__global__ void __launch_bounds__(256) k_match_index(const EkfMatch *m, int M, int *match_of_feat, int N)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int f = m[i].featureIndex;
+    if (f >= 0 && f < N) atomicMin(&match_of_feat[f], i);
+}
+
+__global__ void __launch_bounds__(256) k_fill_int(int *p, int n, int v)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+void launch_match_index(EkfEngine *e, int M)
+{
+    if (e->N <= 0) return;
+    k_fill_int<<<(e->N + 255) / 256, 256, 0, e->stream>>>(e->d.match_of_feat, e->N, 0x7fffffff);
+    if (M > 0) k_match_index<<<(M + 255) / 256, 256, 0, e->stream>>>(e->d.matches, M, e->d.match_of_feat, e->N);
+}
+
+// Stable partition of src[0..M) by flags: dst1 receives the flagged matches, dst0 (optional) the others, both in
+// the original order (1PointRansac.cpp:213-227, EKF.cpp:110-117).
+__global__ void __launch_bounds__(1024)
+k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0, int *cnt1)
+{
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (M + 1023) / 1024;
+    const int b = tid * per, e = min(M, b + per);
+    int c = 0;
+    for (int i = b; i < e; ++i) c += flags[i] ? 1 : 0;
+    part[tid] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int p1 = part[tid] - c;
+    int p0 = b - p1;
+    for (int i = b; i < e; ++i) {
+        if (flags[i]) dst1[p1++] = src[i];
+        else if (dst0) dst0[p0++] = src[i];
+    }
+    if (tid == 1023 && cnt1) *cnt1 = part[1023];
+}
+
+void launch_partition(EkfEngine *e, const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0,
+                      int *cnt1)
+{
+    if (M <= 0) {
+        if (cnt1) (void)hipMemsetAsync(cnt1, 0, sizeof(int), e->stream);
+        return;
+    }
+    k_partition<<<1, 1024, 0, e->stream>>>(src, M, flags, dst1, dst0, cnt1);
+}
+
+__global__ void __launch_bounds__(256) k_outlier_idx(const EkfMatch *src, int M, int *idx)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < M) idx[i] = src[i].featureIndex;
+}
+
+void launch_outlier_idx(EkfEngine *e, const EkfMatch *src, int M, int *idx)
+{
+    if (M > 0) k_outlier_idx<<<(M + 255) / 256, 256, 0, e->stream>>>(src, M, idx);
+}
+
+} // namespace ekf

@@ -1,0 +1,327 @@
+// kernels_predict.hip -- prediction stages on gfx950:
+//   A1/A2  stateAndCovariancePrediction   EKF/StateAndCovariancePrediction.cpp:43-65,154-253
+//   A3     predictMeasurementState         EKF/MeasurementPrediction.cpp:203-265
+//   A4     predictMeasurementCovariance    EKF/MeasurementPrediction.cpp:595-700
+// All of it is HBM/latency-bound strip work over the (13+6N)-wide covariance: coalesced row reads, fp64 math,
+// no GEMM shapes.
+#include "engine.h"
+
+namespace ekf {
+
+// ------------------------------------------------------------------------------------------------ A1 + A2
+// One thread: F (13x13), G Q G' (13x13) from the PRE-prediction state, then the state prediction itself
+// (covariance is predicted before the state, :251-252; dt = 1, :246).
+__global__ void k_predict_prepare(double *st, ParD par)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double dt = 1.0;
+    double *x = st + ST_X;
+    double *F = st + ST_F, *GQG = st + ST_GQG;
+    for (int i = 0; i < 169; ++i) F[i] = 0.0;
+    for (int i = 0; i < 13; ++i) F[i * 13 + i] = 1.0;
+    for (int i = 0; i < 3; ++i) F[i * 13 + i + 7] = dt;
+    // d q_new / d q = right-multiplication matrix of quat(w dt)  (:71-92)
+    double w[3] = {x[10] * dt, x[11] * dt, x[12] * dt};
+    double nw = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    double qr[4];
+    if (nw < EKF_EPSILON) {
+        qr[0] = 1; qr[1] = 0; qr[2] = 0; qr[3] = 0;
+    } else {
+        const double s = sin(nw / 2);
+        qr[0] = cos(nw / 2); qr[1] = s * w[0] / nw; qr[2] = s * w[1] / nw; qr[3] = s * w[2] / nw;
+    }
+    {
+        const double qw = qr[0], qx = qr[1], qy = qr[2], qz = qr[3];
+        const double Fq[16] = {qw, -qx, -qy, -qz, qx, qw, qz, -qy, qy, -qz, qw, qx, qz, qy, -qx, qw};
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) F[(3 + i) * 13 + 3 + j] = Fq[i * 4 + j];
+    }
+    double G[13 * 6];
+    for (int i = 0; i < 78; ++i) G[i] = 0.0;
+    if (fabs(x[10]) < EKF_EPSILON && fabs(x[11]) < EKF_EPSILON && fabs(x[12]) < EKF_EPSILON) {
+        for (int i = 0; i < 3; ++i) F[(i + 10) * 13 + i + 10] = 0.0; // :176-184, G quaternion block stays 0
+    } else {
+        const double om = sqrt(x[10] * x[10] + x[11] * x[11] + x[12] * x[12]);
+        const double *q = x + 3;
+        const double Qm[16] = {q[0], -q[1], -q[2], -q[3], q[1], q[0], -q[3], q[2],
+                               q[2], q[3], q[0], -q[1], q[3], -q[2], q[1], q[0]};
+        const double sh = sin(om * dt / 2.0), ch = cos(om * dt / 2.0);
+        double D[12];
+        for (int a = 0; a < 3; ++a) {
+            const double wa = x[10 + a];
+            D[a] = (-dt / 2.0) * (wa / om) * sh; // :100-103
+            for (int b = 0; b < 3; ++b) {
+                const double wb = x[10 + b];
+                double v;
+                if (a == b) // :107-111
+                    v = (dt / 2.0) * wa * wa / (om * om) * ch + (1.0 / om) * (1.0 - wa * wa / (om * om)) * sh;
+                else // :115-119
+                    v = (wa * wb / (om * om)) * ((dt / 2.0) * ch - (1.0 / om) * sh);
+                D[3 + a * 3 + b] = v;
+            }
+        }
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < 4; ++k) s += Qm[i * 4 + k] * D[k * 3 + j];
+                F[(3 + i) * 13 + 10 + j] = s;
+                G[(3 + i) * 6 + 3 + j] = s;
+            }
+    }
+    for (int i = 0; i < 3; ++i) {
+        G[(i + 7) * 6 + i] = 1.0;
+        G[(i + 10) * 6 + i + 3] = 1.0;
+        G[i * 6 + i] = 1.0 * dt;
+    }
+    const double ln = par.linearAccelSD * par.linearAccelSD * dt * dt;
+    const double an = par.angularAccelSD * par.angularAccelSD * dt * dt;
+    for (int i = 0; i < 13; ++i)
+        for (int j = 0; j < 13; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 6; ++k) s += (G[i * 6 + k] * (k < 3 ? ln : an)) * G[j * 6 + k];
+            GQG[i * 13 + j] = s;
+        }
+    // predictState :43-65
+    for (int i = 0; i < 3; ++i) x[i] += x[7 + i] * dt;
+    {
+        const double q1w = x[3], q1x = x[4], q1y = x[5], q1z = x[6];
+        const double q2w = qr[0], q2x = qr[1], q2y = qr[2], q2z = qr[3];
+        x[3] = q1w * q2w - q1x * q2x - q1y * q2y - q1z * q2z;
+        x[4] = q1w * q2x + q1x * q2w + q1y * q2z - q1z * q2y;
+        x[5] = q1w * q2y - q1x * q2z + q1y * q2w + q1z * q2x;
+        x[6] = q1w * q2z + q1x * q2y - q1y * q2x + q1z * q2w;
+    }
+    quat_to_rot(x + 3, st + ST_R);
+}
+
+// P[0:13,0:13] = F P F' + G Q G'; P[0:13,13:] = F P[0:13,13:]; P[13:,0:13] = P[13:,0:13] F'  (:226-239).
+// Block 0 owns the corner; every other thread owns one column j of the row strip and row j of the column strip
+// (13 coalesced loads + 13 contiguous loads).  The three regions are disjoint, so one launch updates in place.
+template <typename T>
+__global__ void __launch_bounds__(256) k_predict_cov(T *P, int ld, int n, const double *st)
+{
+    __shared__ double sF[169];
+    __shared__ double sC[169];
+    __shared__ double sFP[169];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 169; i += 256) sF[i] = st[ST_F + i];
+    if (blockIdx.x == 0) {
+        for (int i = tid; i < 169; i += 256) sC[i] = (double)P[(size_t)(i / 13) * ld + (i % 13)];
+        __syncthreads();
+        if (tid < 169) {
+            const int i = tid / 13, j = tid % 13;
+            double s = 0.0;
+            for (int k = 0; k < 13; ++k) s += sF[i * 13 + k] * sC[k * 13 + j];
+            sFP[tid] = s;
+        }
+        __syncthreads();
+        if (tid < 169) {
+            const int i = tid / 13, j = tid % 13;
+            double s = 0.0;
+            for (int k = 0; k < 13; ++k) s += sFP[i * 13 + k] * sF[j * 13 + k];
+            P[(size_t)i * ld + j] = (T)(s + st[ST_GQG + tid]);
+        }
+        return;
+    }
+    __syncthreads();
+    const int j = 13 + (blockIdx.x - 1) * 256 + tid;
+    if (j >= n) return;
+    double col[13], row[13];
+#pragma unroll
+    for (int a = 0; a < 13; ++a) col[a] = (double)P[(size_t)a * ld + j];
+#pragma unroll
+    for (int a = 0; a < 13; ++a) row[a] = (double)P[(size_t)j * ld + a];
+#pragma unroll
+    for (int a = 0; a < 13; ++a) {
+        double s = 0.0, t = 0.0;
+#pragma unroll
+        for (int b = 0; b < 13; ++b) {
+            s += sF[a * 13 + b] * col[b];
+            t += row[b] * sF[a * 13 + b];
+        }
+        P[(size_t)a * ld + j] = (T)s;
+        P[(size_t)j * ld + a] = (T)t;
+    }
+}
+
+void launch_predict(EkfEngine *e)
+{
+    k_predict_prepare<<<1, 64, 0, e->stream>>>(e->d.state, e->par);
+    const int nb = 1 + (e->n > 13 ? (e->n - 13 + 255) / 256 : 0);
+    if (e->f32)
+        k_predict_cov<float><<<nb, 256, 0, e->stream>>>((float *)e->d.P, e->ldP, e->n, e->d.state);
+    else
+        k_predict_cov<double><<<nb, 256, 0, e->stream>>>((double *)e->d.P, e->ldP, e->n, e->d.state);
+}
+
+// ------------------------------------------------------------------------------------------------------ A3
+// One thread per work item: pixel prediction, visibility, and (when predicted) the Jacobian blocks.
+__global__ void __launch_bounds__(256)
+k_predict_features(const double *st, CamD cam, const double *feat_pos, const int *feat_type, const int *idx,
+                   int count, int *flag, int *vis, double *uv_tab, double *Hs_tab, double *Hf_tab)
+{
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= count) return;
+    const int fi = idx ? idx[w] : w;
+    const double *x = st + ST_X;
+    const double *R = st + ST_R;
+    double Rt[9], Rinv[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rt[j * 3 + i] = R[i * 3 + j];
+    inv3(R, Rinv);
+    double fp[6];
+    for (int i = 0; i < 6; ++i) fp[i] = feat_pos[6 * fi + i];
+    const int type = feat_type[fi];
+    double uv[2];
+    const bool ok = predict_pixel(cam, x, Rt, Rinv, fp, type, uv);
+    flag[w] = ok ? 1 : 0;
+    vis[fi] = ok ? 1 : 0;
+    if (ok) {
+        uv_tab[2 * fi] = uv[0];
+        uv_tab[2 * fi + 1] = uv[1];
+        if (Hs_tab) {
+            double Hs[14], Hf[12];
+            measurement_jacobians(cam, x, Rinv, fp, type, uv, Hs, Hf);
+            for (int i = 0; i < 14; ++i) Hs_tab[14 * fi + i] = Hs[i];
+            for (int i = 0; i < 12; ++i) Hf_tab[12 * fi + i] = Hf[i];
+        }
+    }
+}
+
+// Ordered compaction of flag[0..count) by one 1024-thread block: list[k] = feature index of the k-th predicted
+// work item (input order, as the reference's push_back order), *out_count = how many.
+__global__ void __launch_bounds__(1024) k_compact(const int *flag, const int *idx, int count, int *list, int *out_count)
+{
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (count + 1023) / 1024;
+    const int b = tid * per, e = min(count, b + per);
+    int c = 0;
+    for (int i = b; i < e; ++i) c += flag[i] ? 1 : 0;
+    part[tid] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) { // Hillis-Steele inclusive scan
+        int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int pos = part[tid] - c;
+    for (int i = b; i < e; ++i)
+        if (flag[i]) list[pos++] = idx ? idx[i] : i;
+    if (tid == 1023) *out_count = part[1023];
+}
+
+// state_only: pixel predictions into the scratch tables (vis2/uv2, list plist_sub, counter CNT_NPRED_SUB) so the
+// tables the following stages consume stay untouched.
+void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool state_only)
+{
+    const bool sub = state_only || d_idx != nullptr;
+    if (count <= 0) {
+        hipMemsetAsync(e->d.counts + (sub ? CNT_NPRED_SUB : CNT_NPRED), 0, sizeof(int), e->stream);
+        return;
+    }
+    const int nb = (count + 255) / 256;
+    k_predict_features<<<nb, 256, 0, e->stream>>>(e->d.state, e->cam, e->d.feat_pos, e->d.feat_type, d_idx, count,
+                                                  e->d.work_flag, state_only ? e->d.pred_vis2 : e->d.pred_vis,
+                                                  state_only ? e->d.pred_uv2 : e->d.pred_uv,
+                                                  state_only ? nullptr : e->d.Hs, state_only ? nullptr : e->d.Hf);
+    k_compact<<<1, 1024, 0, e->stream>>>(e->d.work_flag, d_idx, count, sub ? e->d.plist_sub : e->d.plist,
+                                         e->d.counts + (sub ? CNT_NPRED_SUB : CNT_NPRED));
+}
+
+// ------------------------------------------------------------------------------------------------------ A4
+// One workgroup per predicted feature: the 2 x n row pair  H_f P = Hf P[pos:pos+d,:] + Hs P[0:7,:]  (:644, columns
+// 7..12 of Hs are structurally zero), streamed with coalesced reads of 7+d rows of P, and the 2x2 innovation
+// covariance S_f = (H_f P) H_f' + I (:651-653) from the fp64 values of the 13 columns H_f touches.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, const int *feat_covpos,
+          const double *Hs_tab, const double *Hf_tab, T *HP, double *S_tab)
+{
+    __shared__ double sH[26];     // Hs (2x7) then Hf (2x6)
+    __shared__ double sHP[2][13]; // fp64 H P at columns 0..6 and pos..pos+d-1
+    const int fi = list[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int d = feat_dim(feat_type[fi]);
+    const int pos = feat_covpos[fi];
+    if (tid < 14) sH[tid] = Hs_tab[14 * fi + tid];
+    else if (tid < 26) sH[tid] = Hf_tab[12 * fi + tid - 14];
+    __syncthreads();
+    T *o0 = HP + (size_t)(2 * fi) * ld;
+    T *o1 = o0 + ld;
+    for (int j = tid; j < n; j += 256) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int a = 0; a < d; ++a) {
+            const double p = (double)P[(size_t)(pos + a) * ld + j];
+            a0 += sH[14 + a] * p;
+            a1 += sH[20 + a] * p;
+        }
+        double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 7; ++a) {
+            const double p = (double)P[(size_t)a * ld + j];
+            b0 += sH[a] * p;
+            b1 += sH[7 + a] * p;
+        }
+        a0 += b0;
+        a1 += b1;
+        o0[j] = (T)a0;
+        o1[j] = (T)a1;
+        if (j < 7) {
+            sHP[0][j] = a0;
+            sHP[1][j] = a1;
+        } else if (j >= pos && j < pos + d) {
+            sHP[0][7 + j - pos] = a0;
+            sHP[1][7 + j - pos] = a1;
+        }
+    }
+    __syncthreads();
+    if (tid < 4) {
+        const int r = tid >> 1, c = tid & 1;
+        double s1 = 0.0, s2 = 0.0;
+        for (int a = 0; a < 7; ++a) s1 += sHP[r][a] * sH[c * 7 + a];
+        for (int a = 0; a < d; ++a) s2 += sHP[r][7 + a] * sH[14 + c * 6 + a];
+        S_tab[4 * fi + tid] = s1 + s2 + (r == c ? 1.0 : 0.0);
+    }
+}
+
+void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list)
+{
+    if (n_list <= 0) return;
+    if (e->f32)
+        k_hp_rows<float><<<n_list, 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
+                                                        e->d.feat_covpos, e->d.Hs, e->d.Hf, (float *)e->d.HP,
+                                                        e->d.pred_S);
+    else
+        k_hp_rows<double><<<n_list, 256, 0, e->stream>>>((const double *)e->d.P, e->ldP, e->n, d_list,
+                                                         e->d.feat_type, e->d.feat_covpos, e->d.Hs, e->d.Hf,
+                                                         (double *)e->d.HP, e->d.pred_S);
+}
+
+// predictMeasurementState on the current state into an EkfPrediction array (device), all features.
+__global__ void __launch_bounds__(256)
+k_pack_predictions(const int *list, const int *count, const double *uv_tab, const double *S_tab, EkfPrediction *out,
+                   int with_S)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= *count) return;
+    const int fi = list[k];
+    EkfPrediction p;
+    p.featureIndex = fi;
+    p._pad = 0;
+    p.imagePos[0] = uv_tab[2 * fi];
+    p.imagePos[1] = uv_tab[2 * fi + 1];
+    for (int i = 0; i < 4; ++i) p.covarianceMatrix[i] = with_S ? S_tab[4 * fi + i] : 0.0;
+    out[k] = p;
+}
+
+void launch_state_only_predict(EkfEngine *e, EkfPrediction *d_out)
+{
+    launch_predict_features(e, nullptr, e->N, true);
+    if (e->N > 0)
+        k_pack_predictions<<<(e->N + 255) / 256, 256, 0, e->stream>>>(e->d.plist_sub, e->d.counts + CNT_NPRED_SUB,
+                                                                      e->d.pred_uv2, e->d.pred_S, d_out, 0);
+}
+
+} // namespace ekf

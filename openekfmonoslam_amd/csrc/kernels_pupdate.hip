@@ -1,0 +1,195 @@
+// kernels_pupdate.hip -- the covariance downdate  P <- sym(P) - B' B  (B = inv(L) H P, m x n, k-major).
+//
+// Replaces covarianceUpdate + symmetrisation (EKF/Update.cpp:214-218, 303): the reference multiplies the dense
+// n x n (I - K H) by P (2 n^3 + 2 n^2 m flops); (I - K H) P = P - (P H') inv(S) (H P) = P - B' B, a rank-m
+// symmetric downdate: n^2 m flops on the upper triangle, 2 n^2 w bytes of P traffic.  At m = 2000 that is
+// ~500 flop/B, so the kernel is MFMA-bound (fp32: v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s peak; fp64:
+// v_mfma_f64_16x16x4_f64).
+//
+// Layout / tiling (gfx950):
+//   * B is stored k-major (row k = all n columns), so BOTH MFMA operands of a tile (I, J) are row slabs
+//     B[k0:k0+BK, I] and B[k0:k0+BK, J]: coalesced 16-byte global loads, LDS image [k][column], and the
+//     operand fetch "lane l reads [k + l / MB][c + l % MB]" is a conflict-free ds_read (consecutive lanes,
+//     consecutive banks).
+//   * workgroup = 256 threads = 2 x 2 wavefronts, each wavefront owns 2 x 2 MFMA blocks (fp32: 64 x 64 outputs,
+//     64 accumulator VGPRs), workgroup tile TM x TM with TM = 4 MB (fp32 128, fp64 64), k-slab BK = 16,
+//     register-staged double buffering through LDS (32 KB).
+//   * only tiles with I <= J are launched; the epilogue subtracts from P, writes the tile and its mirror image,
+//     so P stays bitwise symmetric.
+#include "engine.h"
+
+namespace ekf {
+
+template <typename T>
+struct Mma;
+
+template <>
+struct Mma<float> {
+    static constexpr int MB = 32, NACC = 16;
+    typedef float acc_t __attribute__((ext_vector_type(16)));
+    typedef float4 vec_t; // 16-byte global/LDS vector
+    static constexpr int VEC = 4;
+    __device__ static __forceinline__ acc_t mma(float a, float b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    // C/D layout of the 32x32 f32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    __device__ static __forceinline__ int row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+    __device__ static __forceinline__ int col(int lane) { return lane & 31; }
+};
+
+template <>
+struct Mma<double> {
+    static constexpr int MB = 16, NACC = 4;
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    typedef double2 vec_t;
+    static constexpr int VEC = 2;
+    __device__ static __forceinline__ acc_t mma(double a, double b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    // C/D layout of the 16x16 f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 reg
+    __device__ static __forceinline__ int row(int reg, int lane) { return (lane >> 4) + 4 * reg; }
+    __device__ static __forceinline__ int col(int lane) { return lane & 15; }
+};
+
+constexpr int PU_BK = 16;
+
+template <typename T, bool AVG>
+__global__ void __launch_bounds__(256)
+k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int nt)
+{
+    using M = Mma<T>;
+    constexpr int MB = M::MB, TM = 4 * MB, KI = 64 / MB, VEC = M::VEC;
+    constexpr int LOADS = PU_BK * TM / (256 * VEC);
+    __shared__ __attribute__((aligned(16))) T sI[2][PU_BK][TM];
+    __shared__ __attribute__((aligned(16))) T sJ[2][PU_BK][TM];
+
+    // upper-triangle tile decode: row ti has nt - ti tiles
+    int ti = 0, rem = blockIdx.x;
+    while (rem >= nt - ti) {
+        rem -= nt - ti;
+        ++ti;
+    }
+    const int tj = ti + rem;
+    const bool diag = (ti == tj);
+    const int I0 = ti * TM, J0 = tj * TM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int klane = lane / MB, idx = lane % MB;
+
+    typename M::acc_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < M::NACC; ++r) acc[a][b][r] = (T)0;
+
+    typename M::vec_t rI[LOADS], rJ[LOADS];
+    const int nk = m_pad / PU_BK;
+
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int it = 0; it < LOADS; ++it) {
+            const int e = (tid + it * 256) * VEC;
+            const int k = e / TM, c = e % TM;
+            const T *src = B + (size_t)(kt * PU_BK + k) * ldb;
+            rI[it] = *(const typename M::vec_t *)(src + I0 + c);
+            if (!diag) rJ[it] = *(const typename M::vec_t *)(src + J0 + c);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < LOADS; ++it) {
+            const int e = (tid + it * 256) * VEC;
+            const int k = e / TM, c = e % TM;
+            *(typename M::vec_t *)(&sI[buf][k][c]) = rI[it];
+            if (!diag) *(typename M::vec_t *)(&sJ[buf][k][c]) = rJ[it];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const T(*pJ)[TM] = diag ? sI[buf] : sJ[buf];
+#pragma unroll
+        for (int kk = 0; kk < PU_BK; kk += KI) {
+            T a[2], b[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                a[x] = sI[buf][kk + klane][wr * 2 * MB + x * MB + idx];
+                b[x] = pJ[kk + klane][wc * 2 * MB + x * MB + idx];
+            }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = M::mma(a[x], b[y], acc[x][y]);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: P(i, j) = [sym] P(i, j) - acc for i <= j, mirrored
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < M::NACC; ++r) {
+                const int gi = I0 + wr * 2 * MB + x * MB + M::row(r, lane);
+                const int gj = J0 + wc * 2 * MB + y * MB + M::col(lane);
+                if (gi < n && gj < n && gi <= gj) {
+                    T *pu = P + (size_t)gi * ldp + gj;
+                    T *pl = P + (size_t)gj * ldp + gi;
+                    T v = *pu;
+                    if (AVG) v = (T)0.5 * v + (T)0.5 * (*pl);
+                    v -= acc[x][y][r];
+                    *pu = v;
+                    *pl = v;
+                }
+            }
+}
+
+void launch_p_update(EkfEngine *e, int m_pad)
+{
+    hipStream_t s = e->stream;
+    const int n = e->n;
+    const int TM = e->f32 ? 128 : 64;
+    const int nt = (n + TM - 1) / TM;
+    const int ntiles = nt * (nt + 1) / 2;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (e->timing) {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, s);
+    }
+    const bool avg = !e->p_exact_sym;
+    if (e->f32) {
+        if (avg)
+            k_p_update<float, true><<<ntiles, 256, 0, s>>>((float *)e->d.P, e->ldP, n, (const float *)e->d.A, e->ldP,
+                                                          m_pad, nt);
+        else
+            k_p_update<float, false><<<ntiles, 256, 0, s>>>((float *)e->d.P, e->ldP, n, (const float *)e->d.A,
+                                                           e->ldP, m_pad, nt);
+    } else {
+        if (avg)
+            k_p_update<double, true><<<ntiles, 256, 0, s>>>((double *)e->d.P, e->ldP, n, (const double *)e->d.A,
+                                                           e->ldP, m_pad, nt);
+        else
+            k_p_update<double, false><<<ntiles, 256, 0, s>>>((double *)e->d.P, e->ldP, n, (const double *)e->d.A,
+                                                            e->ldP, m_pad, nt);
+    }
+    if (e->timing) {
+        (void)hipEventRecord(e1, s);
+        e->pu_events.emplace_back(e0, e1);
+        e->pu_work.push_back((double)n * (double)n * (double)m_pad);
+    }
+    e->p_exact_sym = true;
+}
+
+} // namespace ekf

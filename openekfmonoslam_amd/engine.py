@@ -1,0 +1,261 @@
+"""ctypes binding of libekf_engine.so (the HIP engine).  There is no CPU fallback: if the library is missing or
+no MI355X is visible, construction fails loudly.
+
+The names mirror the reference's stage functions (include/ekf_engine.h cites each reference file:line):
+``predict`` = stateAndCovariancePrediction, ``predict_measurements`` = predictCameraMeasurements,
+``match`` = matchPredictedFeatures (downstream of the detector), ``ransac``, ``update``, ``rescue``,
+``step`` = EKF::step.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .ekftypes import (DESC_BYTES, KEYPOINT_DTYPE, MATCH_DTYPE, PREDICTION_DTYPE, STATUS_NAMES, EkfCamera, EkfParams,
+                       EkfStepInfo)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libekf_engine.so")
+PRECISION_F64, PRECISION_F32 = 0, 1
+
+
+class EkfEngineConfig(C.Structure):
+    _fields_ = [
+        ("cam", EkfCamera),
+        ("par", EkfParams),
+        ("max_features", C.c_int32),
+        ("max_keypoints", C.c_int32),
+        ("precision", C.c_int32),
+        ("device", C.c_int32),
+        ("ransac_batch", C.c_int32),
+        ("flags", C.c_int32),
+    ]
+
+
+class EkfStageTimes(C.Structure):
+    _fields_ = [
+        ("prediction_ms", C.c_double),
+        ("matching_ms", C.c_double),
+        ("ransac_ms", C.c_double),
+        ("update_li_ms", C.c_double),
+        ("rescue_ms", C.c_double),
+        ("update_hi_ms", C.c_double),
+        ("p_update_kernel_ms", C.c_double),
+        ("p_update_launches", C.c_int64),
+        ("p_update_flops", C.c_double),
+        ("p_update_bytes", C.c_double),
+        ("steps", C.c_int64),
+    ]
+
+
+# every symbol include/ekf_engine.h declares: name -> (restype, argtypes)
+_vp, _i = C.c_void_p, C.c_int
+ABI = {
+    "ekf_engine_create": (_i, [C.POINTER(EkfEngineConfig), C.POINTER(_vp)]),
+    "ekf_engine_destroy": (None, [_vp]),
+    "ekf_last_error": (C.c_char_p, [_vp]),
+    "ekf_abi_version": (_i, []),
+    "ekf_device_count": (_i, []),
+    "ekf_set_state": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "ekf_get_state": (_i, [_vp, _vp, _vp, _vp]),
+    "ekf_state_dim": (_i, [_vp]),
+    "ekf_num_features": (_i, [_vp]),
+    "ekf_predict": (_i, [_vp]),
+    "ekf_predict_measurements": (_i, [_vp, _vp, _i, _vp, C.POINTER(_i), _vp, _vp]),
+    "ekf_predict_measurement_state": (_i, [_vp, _vp, C.POINTER(_i)]),
+    "ekf_match": (_i, [_vp, _vp, _vp, _i, _vp, C.POINTER(_i)]),
+    "ekf_ransac": (_i, [_vp, _vp, _i, _vp, C.POINTER(_i)]),
+    "ekf_update": (_i, [_vp, _vp, _i]),
+    "ekf_update_only_state": (_i, [_vp, _vp, _i]),
+    "ekf_rescue": (_i, [_vp, _vp, _i, _vp]),
+    "ekf_step": (_i, [_vp, _vp, _vp, _i, C.POINTER(EkfStepInfo)]),
+    "ekf_frames_upload": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "ekf_step_frame": (_i, [_vp, _i, C.POINTER(EkfStepInfo)]),
+    "ekf_timing_enable": (_i, [_vp, _i]),
+    "ekf_timing_reset": (_i, [_vp]),
+    "ekf_timing_get": (_i, [_vp, C.POINTER(EkfStageTimes)]),
+    "ekf_synchronize": (_i, [_vp]),
+    "ekf_shard_rows": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Loads libekf_engine.so.  torch (if installed) is imported first so that one HIP runtime serves both."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m openekfmonoslam_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback."
+        )
+    try:
+        import torch  # noqa: F401  (pulls in torch's libamdhip64 before ours resolves the same SONAME)
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    for name, (rt, at) in ABI.items():
+        fn = getattr(L, name)
+        fn.restype = rt
+        fn.argtypes = at
+    _lib = L
+    return L
+
+
+class EkfError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__(f"{STATUS_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def shard_rows(n_features, world, rank):
+    lo, hi = _i(0), _i(0)
+    rc = load_library().ekf_shard_rows(n_features, world, rank, C.byref(lo), C.byref(hi))
+    if rc:
+        raise EkfError(rc)
+    return lo.value, hi.value
+
+
+class EkfEngine:
+    """One device-resident filter (state, covariance, map, per-frame tables) on one MI355X."""
+
+    def __init__(self, cam, par, max_features, max_keypoints=0, precision=PRECISION_F64, device=-1, ransac_batch=0):
+        self.L = load_library()
+        cfg = EkfEngineConfig()
+        cfg.cam, cfg.par = cam, par
+        cfg.max_features, cfg.max_keypoints = int(max_features), int(max_keypoints)
+        cfg.precision, cfg.device, cfg.ransac_batch, cfg.flags = int(precision), int(device), int(ransac_batch), 0
+        h = _vp()
+        rc = self.L.ekf_engine_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise EkfError(rc, "ekf_engine_create failed (no MI355X visible?)")
+        self.h = h
+        self.cap = int(max_features)
+        self.precision = precision
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ekf_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc, allow=()):
+        if rc and rc not in allow:
+            raise EkfError(rc, (self.L.ekf_last_error(self.h) or b"").decode())
+        return rc
+
+    # ---- state
+    @property
+    def n(self):
+        return self.L.ekf_state_dim(self.h)
+
+    @property
+    def N(self):
+        return self.L.ekf_num_features(self.h)
+
+    def set_state(self, x13, feature_pos, feature_type, desc, P):
+        x13 = np.ascontiguousarray(x13, dtype=np.float64)
+        fp = np.ascontiguousarray(feature_pos, dtype=np.float64).reshape(-1, 6)
+        ft = None if feature_type is None else np.ascontiguousarray(feature_type, dtype=np.int32)
+        d = None if desc is None else np.ascontiguousarray(desc, dtype=np.uint8)
+        Pm = None if P is None else np.ascontiguousarray(P, dtype=np.float64)
+        self._chk(self.L.ekf_set_state(self.h, _p(x13), len(fp), _p(fp), _p(ft), _p(d), _p(Pm)))
+
+    def get_state(self, want_P=True):
+        x = np.zeros(13)
+        fp = np.zeros((max(self.N, 1), 6))
+        P = np.zeros((self.n, self.n)) if want_P else None
+        self._chk(self.L.ekf_get_state(self.h, _p(x), _p(fp), _p(P)))
+        return x, fp[: self.N], P
+
+    # ---- stages
+    def predict(self):
+        self._chk(self.L.ekf_predict(self.h))
+
+    def predict_measurements(self, feat_idx=None):
+        idx = None if feat_idx is None else np.ascontiguousarray(feat_idx, dtype=np.int32)
+        cnt = 0 if idx is None else len(idx)
+        cap = self.N if idx is None else max(cnt, 1)
+        preds = np.zeros(max(cap, 1), dtype=PREDICTION_DTYPE)
+        Hs = np.zeros((max(cap, 1), 2, 13))
+        Hf = np.zeros((max(cap, 1), 2, 6))
+        k = _i(0)
+        self._chk(self.L.ekf_predict_measurements(self.h, _p(idx), cnt, _p(preds), C.byref(k), _p(Hs), _p(Hf)))
+        return preds[: k.value].copy(), Hs[: k.value].copy(), Hf[: k.value].copy()
+
+    def predict_measurement_state(self):
+        preds = np.zeros(max(self.N, 1), dtype=PREDICTION_DTYPE)
+        k = _i(0)
+        self._chk(self.L.ekf_predict_measurement_state(self.h, _p(preds), C.byref(k)))
+        return preds[: k.value].copy()
+
+    def match(self, kps, desc):
+        kps = np.ascontiguousarray(kps, dtype=KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, DESC_BYTES)
+        out = np.zeros(max(self.N, 1), dtype=MATCH_DTYPE)
+        k = _i(0)
+        self._chk(self.L.ekf_match(self.h, _p(kps), _p(desc), len(kps), _p(out), C.byref(k)))
+        return out[: k.value].copy()
+
+    def ransac(self, matches):
+        matches = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
+        mask = np.zeros(max(len(matches), 1), dtype=np.uint8)
+        nh = _i(0)
+        self._chk(self.L.ekf_ransac(self.h, _p(matches), len(matches), _p(mask), C.byref(nh)))
+        return mask[: len(matches)].astype(bool), nh.value
+
+    def update(self, matches, allow_errors=()):
+        matches = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
+        return self._chk(self.L.ekf_update(self.h, _p(matches), len(matches)), allow_errors)
+
+    def update_only_state(self, matches):
+        matches = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
+        self._chk(self.L.ekf_update_only_state(self.h, _p(matches), len(matches)))
+
+    def rescue(self, outliers):
+        outliers = np.ascontiguousarray(outliers, dtype=MATCH_DTYPE)
+        mask = np.zeros(max(len(outliers), 1), dtype=np.uint8)
+        self._chk(self.L.ekf_rescue(self.h, _p(outliers), len(outliers), _p(mask)))
+        return mask[: len(outliers)].astype(bool)
+
+    def step(self, kps, desc):
+        kps = np.ascontiguousarray(kps, dtype=KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, dtype=np.uint8)
+        info = EkfStepInfo()
+        self._chk(self.L.ekf_step(self.h, _p(kps), _p(desc), len(kps), C.byref(info)))
+        return info
+
+    # ---- staged sequences
+    def upload_frames(self, frames):
+        counts = np.array([len(k) for k, _ in frames], dtype=np.int32)
+        kps = np.ascontiguousarray(np.concatenate([k for k, _ in frames]), dtype=KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(np.concatenate([d for _, d in frames]), dtype=np.uint8)
+        self._chk(self.L.ekf_frames_upload(self.h, len(frames), _p(counts), _p(kps), _p(desc)))
+
+    def step_frame(self, i):
+        info = EkfStepInfo()
+        self._chk(self.L.ekf_step_frame(self.h, int(i), C.byref(info)))
+        return info
+
+    # ---- instrumentation
+    def timing(self, on=True):
+        self._chk(self.L.ekf_timing_enable(self.h, 1 if on else 0))
+
+    def timing_reset(self):
+        self._chk(self.L.ekf_timing_reset(self.h))
+
+    def timing_get(self):
+        t = EkfStageTimes()
+        self._chk(self.L.ekf_timing_get(self.h, C.byref(t)))
+        return t
+
+    def synchronize(self):
+        self._chk(self.L.ekf_synchronize(self.h))

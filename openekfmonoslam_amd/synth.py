@@ -10,7 +10,7 @@ import math
 
 import numpy as np
 
-from .types import DESC_BYTES, FEATURE_INVERSE_DEPTH, KEYPOINT_DTYPE, s3_camera, s3_params
+from .ekftypes import DESC_BYTES, FEATURE_INVERSE_DEPTH, KEYPOINT_DTYPE, s3_camera, s3_params
 
 
 # ------------------------------------------------------------------------------------------------ camera model

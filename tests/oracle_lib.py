@@ -5,7 +5,7 @@ import subprocess
 
 import numpy as np
 
-from openekfmonoslam_amd.types import (DESC_BYTES, KEYPOINT_DTYPE, MATCH_DTYPE, PREDICTION_DTYPE, EkfCamera,
+from openekfmonoslam_amd.ekftypes import (DESC_BYTES, KEYPOINT_DTYPE, MATCH_DTYPE, PREDICTION_DTYPE, EkfCamera,
                                        EkfParams, EkfStepInfo)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -1,0 +1,67 @@
+"""CPU-only checks: the C-ABI library loads, exports every symbol include/ekf_engine.h declares, fails loudly
+without a GPU, and the pure-host helpers (row sharding, synthetic generator) behave."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from openekfmonoslam_amd import build, engine
+from openekfmonoslam_amd.ekftypes import EkfCamera, EkfParams, s3_camera, s3_params
+from openekfmonoslam_amd.synth import SyntheticSequence
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_engine()
+    return engine.load_library()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "ekf_engine.h")).read()
+    declared = set(re.findall(r"\b(ekf_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(engine.ABI), (declared ^ set(engine.ABI))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ekf_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    # sizes implied by include/ekf_types.h (no implicit padding surprises)
+    assert C.sizeof(EkfCamera) == 8 + 12 * 8
+    assert C.sizeof(EkfParams) == 10 * 8
+    assert C.sizeof(engine.EkfEngineConfig) == C.sizeof(EkfCamera) + C.sizeof(EkfParams) + 6 * 4
+    assert C.sizeof(engine.EkfStageTimes) == 11 * 8
+
+
+def test_no_gpu_fails_loudly(lib):
+    if lib.ekf_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(engine.EkfError) as ei:
+        engine.EkfEngine(s3_camera(), s3_params(), 8)
+    assert ei.value.code == 6  # EKF_ERR_NO_DEVICE
+
+
+def test_shard_rows_partition():
+    for N, world in [(2000, 4), (5000, 8), (7, 3), (1, 2)]:
+        edges = [engine.shard_rows(N, world, r) for r in range(world)]
+        assert edges[0][0] == 0 and edges[-1][1] == 13 + 6 * N
+        for a, b in zip(edges[:-1], edges[1:]):
+            assert a[1] == b[0]
+        sizes = [(hi - lo) for lo, hi in edges]
+        feats = [(s - (13 if r == 0 else 0)) // 6 for r, s in enumerate(sizes)]
+        assert sum(feats) == N and max(feats) - min(feats) <= 1
+
+
+def test_synthetic_sequence_is_deterministic_and_in_frame():
+    a, b = SyntheticSequence(20, 4), SyntheticSequence(20, 4)
+    np.testing.assert_array_equal(a.P0, b.P0)
+    np.testing.assert_array_equal(a.frames[3][0], b.frames[3][0])
+    np.testing.assert_array_equal(a.frames[3][1], b.frames[3][1])
+    assert a.P0.shape == (133, 133) and np.allclose(a.P0, a.P0.T, rtol=1e-12, atol=1e-18)
+    kps = a.frames[0][0]
+    assert len(kps) == 40 and kps["x"].min() > 0 and kps["x"].max() < 640

@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-from openekfmonoslam_amd.types import DESC_BYTES, KEYPOINT_DTYPE, PREDICTION_DTYPE, s3_camera, s3_params
+from openekfmonoslam_amd.ekftypes import DESC_BYTES, KEYPOINT_DTYPE, PREDICTION_DTYPE, s3_camera, s3_params
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "a5_selection_cases.json")
 

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from openekfmonoslam_amd import synth
-from openekfmonoslam_amd.types import PREDICTION_DTYPE, s3_camera, s3_params
+from openekfmonoslam_amd.ekftypes import PREDICTION_DTYPE, s3_camera, s3_params
 
 
 def _measure(o, x13, fpos):
