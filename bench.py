@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""EKF updates/s of the MI355X engine on a synthetic monocular sequence (BASELINE.json metric).
+
+One "step" = one full EKF frame (EKF::step with a fixed map: predict, measurement prediction + Jacobians,
+ellipse-gated matching, 1-point RANSAC, low-innovation update, outlier rescue, high-innovation update) on
+keypoints/descriptors that are already resident in HBM when the timed region starts.
+
+N = 1 (default) runs the workload the north-star target is quoted on: synthetic 640x480, N = 1000 inverse-depth
+features, fp32 covariance (BASELINE.json configs[2]).  For --gpus N > 1 the path runs as N independent replicas of
+that workload, one process per GPU (at this map size the path is "replicas only"; the row-sharded
+variant is for N >= 2000); value is the whole-job aggregate.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+WORKLOADS = {
+    # name: (features, width, height, precision, dtype label)
+    "n200_f64": (200, 640, 480, 0, "f64"),
+    "n1000_f32": (1000, 640, 480, 1, "f32"),
+    "n1000_f64": (1000, 640, 480, 0, "f64"),
+    "n2000_f32": (2000, 1280, 720, 1, "f32"),
+    "n5000_f32": (5000, 1920, 1080, 1, "f32"),
+}
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}  # f32: MI355X_MICROARCH.md; f64: AMD datasheet figure (not in the guide)
+
+
+def cpu_baseline(seq, workload):
+    """The oracle (CPU restatement of the reference algorithm) timed on this box's host cores, rank 0 only.
+    (a) one full frame of the SAME workload with the algorithmic update variant; (b) a row sample of the
+    reference's literal dense (I - K H) P products, to estimate what the literal algorithm would cost."""
+    import oracle_lib as ol
+
+    ol.build()
+    N = seq.n_features
+    o = ol.Oracle(seq.cam, seq.par, N + 8)
+    o.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    kps, desc = seq.frames[0]
+    t0 = time.perf_counter()
+    info = o.step(kps, desc, ol.ALGORITHMIC)
+    t_alg = time.perf_counter() - t0
+    n, m = seq.state_dim, 2 * max(info.n_inliers, info.n_rescued, 1)
+    rows = 16 if n > 3000 else 64
+    rng = np.random.default_rng(1)
+    K = rng.standard_normal((rows, m))
+    H = rng.standard_normal((m, n))
+    P = rng.standard_normal((n, n))
+    out = np.zeros((rows, n))
+    t_rows = ol.lib().orc_time_literal_rows(n, m, rows, K.ctypes.data, H.ctypes.data, P.ctypes.data, out.ctypes.data)
+    gflops = (2.0 * rows * m * n + 2.0 * rows * n * n) / t_rows / 1e9
+    lit_flops = 2.0 * n * n * m * 2 + 4.0 * n * m * m + (8.0 / 3.0) * m**3 + 2.0 * n**3
+    return {
+        "value": 1.0 / t_alg,
+        "unit": "EKF updates/s",
+        "cores": 1,
+        "host_cores_available": os.cpu_count(),
+        "kind": "port",
+        "sample": f"frame 1 of the same {workload} sequence (M={info.n_matches} matches, {info.n_inliers} LI inliers, "
+                  f"{info.n_rescued} rescued), oracle 'algorithmic' update (block-sparse H, Cholesky, P -= B'B), "
+                  f"1 thread, {t_alg:.1f} s",
+        "literal_reference_algorithm_estimate_s_per_update": lit_flops / (gflops * 1e9),
+        "literal_sample": f"dense i-k-j products K H and (I-KH) P restricted to {rows} of {n} rows: {t_rows:.2f} s, "
+                          f"{gflops:.2f} GFLOP/s; literal flop model of Update.cpp:92-109,214-218 at m={m}",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="n1000_f32", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-pass", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    torch.cuda.set_device(local_rank)
+
+    from openekfmonoslam_amd import engine
+    from openekfmonoslam_amd.synth import SyntheticSequence
+
+    N, W, H, precision, dtype = WORKLOADS[args.workload]
+    n_frames = args.warmup + args.steps
+    seq = SyntheticSequence(N, n_frames, width=W, height=H)
+    eng = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=precision,
+                           device=local_rank)
+    eng.upload_frames(seq.frames)
+
+    def run(timing):
+        eng.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+        eng.timing(timing)
+        infos = []
+        for t in range(args.warmup):
+            eng.step_frame(t)
+        eng.timing_reset()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(args.warmup, n_frames):
+            infos.append(eng.step_frame(t))
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, infos
+
+    elapsed, infos = run(False)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    roof, stages = None, None
+    if not args.no_roofline_pass:
+        _, _ = run(True)
+        tm = eng.timing_get()
+        if tm.p_update_launches > 0:
+            avg_ms = tm.p_update_kernel_ms / tm.p_update_launches
+            flops = tm.p_update_flops / tm.p_update_launches
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            roof = {
+                "kernel": "k_p_update (P <- sym(P) - B'B, upper-triangle tiles)",
+                "bound": "mfma",
+                "achieved": ach,
+                "peak": PEAK_TFLOPS[dtype],
+                "unit": "TFLOP/s",
+                "frac": ach / PEAK_TFLOPS[dtype],
+                "traffic": None,
+                "avg_launch_ms": avg_ms,
+                "launches": int(tm.p_update_launches),
+                "algorithmic_flops_per_launch": flops,
+            }
+        st = max(int(tm.steps), 1)
+        stages = {k: getattr(tm, k) / st for k in ("prediction_ms", "matching_ms", "ransac_ms", "update_li_ms",
+                                                   "rescue_ms", "update_hi_ms")}
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    value = world * args.steps / elapsed
+    out = {
+        "metric": "EKF updates/s (frames/s) at N features",
+        "value": value,
+        "unit": "EKF updates/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": f"synthetic {W}x{H} sequence, N={N} inverse-depth features (n={13 + 6 * N}), "
+                        f"{'fp32' if precision else 'fp64'} covariance, {len(seq.frames[0][0])} keypoints/frame, "
+                        "fixed map",
+            "name": args.workload,
+            "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (path does not shard at this N)",
+            "mean_matches": float(np.mean([i.n_matches for i in infos])),
+            "mean_li_inliers": float(np.mean([i.n_inliers for i in infos])),
+            "mean_rescued": float(np.mean([i.n_rescued for i in infos])),
+            "mean_ransac_hypotheses": float(np.mean([i.n_hypotheses for i in infos])),
+        },
+        "roofline": roof,
+        "stage_ms_per_step": stages,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(seq, args.workload)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -115,11 +115,15 @@ __global__ void __launch_bounds__(256) k_predict_cov(T *P, int ld, int n, const 
             sFP[tid] = s;
         }
         __syncthreads();
-        if (tid < 169) {
+        if (tid < 169) { // upper triangle, mirrored: F C F' + G Q G' is symmetric; this keeps P bitwise symmetric
             const int i = tid / 13, j = tid % 13;
-            double s = 0.0;
-            for (int k = 0; k < 13; ++k) s += sFP[i * 13 + k] * sF[j * 13 + k];
-            P[(size_t)i * ld + j] = (T)(s + st[ST_GQG + tid]);
+            if (i <= j) {
+                double s = 0.0;
+                for (int k = 0; k < 13; ++k) s += sFP[i * 13 + k] * sF[j * 13 + k];
+                const T v = (T)(s + st[ST_GQG + tid]);
+                P[(size_t)i * ld + j] = v;
+                P[(size_t)j * ld + i] = v;
+            }
         }
         return;
     }

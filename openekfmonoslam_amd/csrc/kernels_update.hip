@@ -341,15 +341,18 @@ __global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, cons
             double s = 0.0;
             for (int k = 0; k < 4; ++k) s += J[a * 4 + k] * C[3 + k][j];
             P[(size_t)(3 + a) * ld + j] = (T)s;
-        } else if (tid < 40) { // J P[3:7,3:7] J'
+        } else if (tid < 40) { // J P[3:7,3:7] J' : upper triangle, mirrored (keeps P bitwise symmetric)
             const int t = tid - 24, a = t / 4, b = t % 4;
-            double s = 0.0;
-            for (int l = 0; l < 4; ++l) {
-                double u = 0.0;
-                for (int k = 0; k < 4; ++k) u += J[a * 4 + k] * C[3 + k][3 + l];
-                s += u * J[b * 4 + l];
+            if (a <= b) {
+                double s = 0.0;
+                for (int l = 0; l < 4; ++l) {
+                    double u = 0.0;
+                    for (int k = 0; k < 4; ++k) u += J[a * 4 + k] * C[3 + k][3 + l];
+                    s += u * J[b * 4 + l];
+                }
+                P[(size_t)(3 + a) * ld + 3 + b] = (T)s;
+                P[(size_t)(3 + b) * ld + 3 + a] = (T)s;
             }
-            P[(size_t)(3 + a) * ld + 3 + b] = (T)s;
         }
         return;
     }
