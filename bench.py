@@ -154,6 +154,20 @@ def main():
                 "launches": int(tm.p_update_launches),
                 "algorithmic_flops_per_launch": flops,
             }
+        if roof is not None:
+            mm, mss = eng.p_update_launches()
+            n_state = 13 + 6 * N
+            big = mm >= 512
+            by_class = {}
+            for name, sel in (("m>=512", big), ("m<512", ~big)):
+                if sel.any():
+                    fl = float((n_state * n_state * mm[sel].astype(np.float64)).sum())
+                    tt = float(mss[sel].sum()) * 1e-3
+                    by_class[name] = {"launches": int(sel.sum()), "mean_m": float(mm[sel].mean()),
+                                      "avg_ms": 1e3 * tt / int(sel.sum()), "tflops": fl / tt / 1e12,
+                                      "algorithmic_GBps": 2.0 * n_state * n_state * (4 if precision else 8)
+                                      * int(sel.sum()) / tt / 1e9}
+            roof["by_launch_class"] = by_class
         st = max(int(tm.steps), 1)
         stages = {k: getattr(tm, k) / st for k in ("prediction_ms", "matching_ms", "ransac_ms", "update_li_ms",
                                                    "rescue_ms", "update_hi_ms")}

@@ -146,6 +146,9 @@ int ekf_timing_enable(EkfEngine *e, int on); /* HIP-event timing of stages and o
 int ekf_timing_reset(EkfEngine *e);
 int ekf_timing_get(EkfEngine *e, EkfStageTimes *out);
 int ekf_synchronize(EkfEngine *e);
+/* Per-launch record of the P-update kernel since the last ekf_timing_reset: rows m of B (k-depth) and the
+ * HIP-event duration in ms.  Writes at most `capacity` entries; *count receives the number available. */
+int ekf_timing_p_update_launches(EkfEngine *e, int capacity, int32_t *m_rows, float *ms, int *count);
 
 /* -- partition of the covariance rows across ranks (multi-GPU); pure host arithmetic -------- */
 /* Row block [row_begin, row_end) of P owned by `rank` of `world` for a map of n_features inverse-depth features:

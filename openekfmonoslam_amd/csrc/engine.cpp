@@ -67,7 +67,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,
                     d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
-                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Linv,
+                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.Tbuf,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out,
                     e->frames.kps, e->frames.desc};
     for (void *p : ptrs)
@@ -161,7 +161,8 @@ int ekf_engine_create(const EkfEngineConfig *cfg, EkfEngine **out)
     ALLOC(d.best_flags, mcap);
     ALLOC(d.S, (size_t)mcap * e->ldS);
     ALLOC(d.nu, mcap);
-    ALLOC(d.Linv, NB * NB);
+    ALLOC(d.Dinv, (size_t)round_up((int)mcap, TB) * TB);
+    ALLOC(d.Tbuf, (size_t)round_up((int)mcap, TB) * (TB / 2));
     ALLOC(d.mHs, 14 * cap);
     ALLOC(d.mHf, 12 * cap);
     ALLOC(d.mpos, cap);
@@ -523,13 +524,15 @@ static void harvest_pu_events(EkfEngine *e)
             e->times.p_update_kernel_ms += ms;
             e->times.p_update_launches += 1;
             e->times.p_update_flops += e->pu_work[i];
-            e->times.p_update_bytes += 0.0;
+            e->times.p_update_bytes += 2.0 * (double)e->n * (double)e->n * (e->f32 ? 4.0 : 8.0);
+            e->pu_log.emplace_back(e->pu_m[i], ms);
         }
         (void)hipEventDestroy(e->pu_events[i].first);
         (void)hipEventDestroy(e->pu_events[i].second);
     }
     e->pu_events.clear();
     e->pu_work.clear();
+    e->pu_m.clear();
 }
 
 struct StageTimer {
@@ -686,6 +689,7 @@ int ekf_timing_reset(EkfEngine *e)
     if (!e) return EKF_ERR_INVALID_ARG;
     (void)hipStreamSynchronize(e->stream);
     harvest_pu_events(e);
+    e->pu_log.clear();
     std::memset(&e->times, 0, sizeof(e->times));
     return EKF_OK;
 }
@@ -696,6 +700,19 @@ int ekf_timing_get(EkfEngine *e, EkfStageTimes *out)
     (void)hipStreamSynchronize(e->stream);
     harvest_pu_events(e);
     *out = e->times;
+    return EKF_OK;
+}
+
+int ekf_timing_p_update_launches(EkfEngine *e, int capacity, int32_t *m_rows, float *ms, int *count)
+{
+    if (!e || !count) return EKF_ERR_INVALID_ARG;
+    (void)hipStreamSynchronize(e->stream);
+    harvest_pu_events(e);
+    *count = (int)e->pu_log.size();
+    for (int i = 0; i < *count && i < capacity; ++i) {
+        if (m_rows) m_rows[i] = e->pu_log[i].first;
+        if (ms) ms[i] = e->pu_log[i].second;
+    }
     return EKF_OK;
 }
 

@@ -12,6 +12,7 @@
 namespace ekf {
 
 constexpr int NB = 32;          // Cholesky panel width
+constexpr int TB = 256;         // row block of the triangular solve B = inv(L) A
 constexpr int LD_ALIGN = 128;   // leading dimensions are multiples of this many elements
 constexpr int DX_SPLIT = 16;    // k-splits of the dx = B' z reduction
 
@@ -78,7 +79,8 @@ struct DeviceArrays {
     void *A = nullptr;   // T [mcap x ldP] : rows of H P for the selected matches, overwritten by B = inv(L) A
     double *S = nullptr; // mcap x ldS (lower triangle used)
     double *nu = nullptr;
-    double *Linv = nullptr; // NB x NB of the current diagonal block
+    double *Dinv = nullptr; // [mcap256 x TB]: inverses of the 256x256 diagonal blocks of L (row-wise)
+    double *Tbuf = nullptr; // [mcap256 x TB/2] scratch of the doubling steps
     double *mHs = nullptr;  // per selected match
     double *mHf = nullptr;
     int *mpos = nullptr;
@@ -118,6 +120,8 @@ struct EkfEngine {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pu_events; // P-update kernel brackets not yet harvested
     std::vector<double> pu_work;                               // n^2 m of each bracket
+    std::vector<int> pu_m;                                     // m of each bracket
+    std::vector<std::pair<int, float>> pu_log;                 // harvested (m, ms) per launch
     // host scratch
     std::vector<int> h_counts;
 };

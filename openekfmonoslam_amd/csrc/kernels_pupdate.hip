@@ -62,8 +62,11 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int nt)
     using M = Mma<T>;
     constexpr int MB = M::MB, TM = 4 * MB, KI = 64 / MB, VEC = M::VEC;
     constexpr int LOADS = PU_BK * TM / (256 * VEC);
-    __shared__ __attribute__((aligned(16))) T sI[2][PU_BK][TM];
-    __shared__ __attribute__((aligned(16))) T sJ[2][PU_BK][TM];
+    // one LDS block: [I-slab x2 | J-slab x2], re-used by the epilogue as per-wavefront transpose scratch
+    __shared__ __attribute__((aligned(16))) T smem[4 * PU_BK * TM];
+    T(*sI)[PU_BK][TM] = reinterpret_cast<T(*)[PU_BK][TM]>(smem);
+    T(*sJ)[PU_BK][TM] = reinterpret_cast<T(*)[PU_BK][TM]>(smem + 2 * PU_BK * TM);
+    static_assert(4 * MB * (MB + 1) <= 4 * PU_BK * TM, "transpose scratch must fit");
 
     // upper-triangle tile decode: row ti has nt - ti tiles
     int ti = 0, rem = blockIdx.x;
@@ -134,25 +137,58 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int nt)
         __syncthreads();
     }
 
-    // epilogue: P(i, j) = [sym] P(i, j) - acc for i <= j, mirrored
+    // epilogue.  P is bitwise symmetric on entry (engine invariant) unless AVG.
+    //  - diagonal tiles: every element (i, j) of the tile is computed (acc is bitwise symmetric), written in place;
+    //  - off-diagonal tiles: the tile is written with row-contiguous stores, and its mirror image through a
+    //    per-wavefront LDS transpose so that the mirrored stores are row-contiguous too (full 128-byte segments
+    //    instead of scattered 4-byte stores).
+    //  - AVG (first update after an arbitrary upload): P(i,j) <- 0.5 (P(i,j) + P(j,i)) - acc on i <= j, mirrored.
+    T *sT = smem + wv * MB * (MB + 1);
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int y = 0; y < 2; ++y)
+        for (int y = 0; y < 2; ++y) {
+            const int bi = I0 + wr * 2 * MB + x * MB, bj = J0 + wc * 2 * MB + y * MB;
+            if (AVG) {
+#pragma unroll
+                for (int r = 0; r < M::NACC; ++r) {
+                    const int gi = bi + M::row(r, lane), gj = bj + M::col(lane);
+                    if (gi < n && gj < n && gi <= gj) {
+                        T *pu = P + (size_t)gi * ldp + gj;
+                        T *pl = P + (size_t)gj * ldp + gi;
+                        const T v = ((T)0.5 * (*pu) + (T)0.5 * (*pl)) - acc[x][y][r];
+                        *pu = v;
+                        *pl = v;
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < M::NACC; ++r) {
-                const int gi = I0 + wr * 2 * MB + x * MB + M::row(r, lane);
-                const int gj = J0 + wc * 2 * MB + y * MB + M::col(lane);
-                if (gi < n && gj < n && gi <= gj) {
+                const int li = M::row(r, lane), lj = M::col(lane);
+                const int gi = bi + li, gj = bj + lj;
+                T v = (T)0;
+                if (gi < n && gj < n) {
                     T *pu = P + (size_t)gi * ldp + gj;
-                    T *pl = P + (size_t)gj * ldp + gi;
-                    T v = *pu;
-                    if (AVG) v = (T)0.5 * v + (T)0.5 * (*pl);
-                    v -= acc[x][y][r];
+                    v = *pu - acc[x][y][r];
                     *pu = v;
-                    *pl = v;
                 }
+                if (!diag) sT[li * (MB + 1) + lj] = v;
             }
+            if (!diag) {
+                __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < MB / KI; ++it) {
+                    const int c = it * KI + klane; // column of the block = row of the mirror
+                    const int gi = bi + idx, gj = bj + c;
+                    const T v = sT[idx * (MB + 1) + c];
+                    if (gi < n && gj < n) P[(size_t)gj * ldp + gi] = v;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
 }
 
 void launch_p_update(EkfEngine *e, int m_pad)
@@ -188,6 +224,7 @@ void launch_p_update(EkfEngine *e, int m_pad)
         (void)hipEventRecord(e1, s);
         e->pu_events.emplace_back(e0, e1);
         e->pu_work.push_back((double)n * (double)n * (double)m_pad);
+        e->pu_m.push_back(m_pad);
     }
     e->p_exact_sym = true;
 }

@@ -86,68 +86,78 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 }
 
 // -------------------------------------------------------------------------------------- blocked Cholesky sweep
-// Step k of the right-looking sweep over [ S | nu | A ], panel width NB = 32, rows k0..k0+kb-1:
-//   diag   : L_kk = chol(S_kk), Linv = inv(L_kk)                                     (one workgroup, LDS)
-//   panel  : L_ik = S_ik Linv' (i > k),  B_k = Linv A_k,  z_k = Linv nu_k
-//   trail  : S_ij -= L_ik L_jk' (i >= j > k),  A_i -= L_ik B_k,  nu_i -= L_ik z_k  (i > k)
-__global__ void __launch_bounds__(64) k_chol_diag(double *S, int ldS, int k0, int kb, double *Linv, int *counts)
+// Right-looking sweep over [ S | nu ], panel width NB = 32, rows k0..k0+kb-1.  Two launches per panel:
+//   panel : every workgroup first factorises the 32x32 diagonal block S_kk = L_kk L_kk' and inverts L_kk, entirely
+//           in the registers of its first wavefront (lane = row, cross-lane broadcasts; no LDS round trips), then
+//           forms its own 32-row block  L_ik = S_ik inv(L_kk)'  (i > k).  The extra workgroup stores inv(L_kk)
+//           into the block-diagonal inverse Dinv and solves z_k = inv(L_kk) nu_k.
+//   trail : S_ij -= L_ik L_jk' (i >= j > k),  nu_i -= L_ik z_k.
+// B = inv(L) A is NOT part of the sweep: it is independent per column of A and runs afterwards as one launch
+// (k_trsm) on the MFMA pipe.
+
+// broadcast of a double from a compile-time lane through SGPRs (v_readlane_b32 x2): no LDS round trip
+__device__ __forceinline__ double bcast_lane(double v, int src_lane)
 {
-    __shared__ double a[NB][NB + 1];
-    __shared__ double li[NB][NB + 1];
-    const int t = threadIdx.x;
-    for (int i = t; i < NB * NB; i += 64) {
-        const int r = i / NB, c = i % NB;
-        a[r][c] = (r < kb && c <= r) ? S[(size_t)(k0 + r) * ldS + k0 + c] : (r == c ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    for (int j = 0; j < kb; ++j) {
-        const double djj = a[j][j];
-        if (!(djj > 0.0)) {
-            if (t == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
-            return;
-        }
-        const double dj = sqrt(djj);
-        __syncthreads();
-        if (t == j) a[j][j] = dj;
-        if (t > j && t < kb) a[t][j] = a[t][j] / dj;
-        __syncthreads();
-        // trailing update of the lower triangle: element (r, c), j < c <= r < kb
-        for (int idx = t; idx < NB * NB; idx += 64) {
-            const int r = idx / NB, c = idx % NB;
-            if (c > j && c <= r && r < kb) a[r][c] -= a[r][j] * a[c][j];
-        }
-        __syncthreads();
-    }
-    // inverse of the lower-triangular factor: column c by forward substitution (lane c)
-    if (t < NB) {
-        const int c = t;
-        for (int r = 0; r < NB; ++r) {
-            double s = (r == c) ? 1.0 : 0.0;
-            for (int k2 = c; k2 < r; ++k2) s -= a[r][k2] * li[k2][c];
-            li[r][c] = (r >= c) ? s / a[r][r] : 0.0;
-        }
-    }
-    __syncthreads();
-    for (int i = t; i < NB * NB; i += 64) {
-        const int r = i / NB, c = i % NB;
-        if (r < kb && c <= r) S[(size_t)(k0 + r) * ldS + k0 + c] = a[r][c];
-        Linv[i] = li[r][c];
-    }
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
 }
 
-// grid.x = row blocks of S below the panel + column chunks of A (256 wide) + 1 block for nu
-template <typename T>
-__global__ void __launch_bounds__(256)
-k_chol_panel(double *S, int ldS, int m, int k0, int kb, const double *Linv, T *A, int ld, int n_pad, double *nu,
-             int n_sblocks)
+// Cholesky factor of a 32x32 block held one row per lane (lanes 0..31), in place; returns false on breakdown.
+__device__ __forceinline__ bool wave_chol32(double (&a)[NB], int lane)
 {
-    __shared__ double sL[NB][NB + 1];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double djj = bcast_lane(a[j], j);
+        ok = ok && (djj > 0.0);
+        const double dj = sqrt(djj > 0.0 ? djj : 1.0);
+        const double l = (lane > j) ? a[j] / dj : (lane == j ? dj : 0.0);
+        a[j] = l;
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) a[c] -= l * bcast_lane(l, c);
+    }
+    return ok;
+}
+
+// grid.x = nrb row blocks below the panel + 1 (diagonal bookkeeping, nu)
+__global__ void __launch_bounds__(256)
+k_chol_panel(double *S, int ldS, int m, int k0, int kb, double *Dinv, double *nu, int nrb, int *counts)
+{
+    __shared__ double sLi[NB][NB + 1]; // inv(L_kk)
     __shared__ double sS[NB][NB + 1];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < NB * NB; i += 256) sL[i / NB][i % NB] = Linv[i];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 64) {
+        double a[NB];
+        const int r = lane < NB ? lane : 0;
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+            a[c] = (lane < kb && c <= r && c < kb) ? S[(size_t)(k0 + r) * ldS + k0 + c] : ((c == r) ? 1.0 : 0.0);
+        const bool ok = wave_chol32(a, lane);
+        if (!ok && lane == 0 && blockIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
+        // L_kk to LDS (sS), then lane c solves column c of the inverse with broadcast LDS reads of L
+        if (lane < NB) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) sS[lane][c] = (c <= lane) ? a[c] : 0.0;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): single wavefront, LDS writes above are visible below
+        __builtin_amdgcn_wave_barrier();
+        if (lane < NB) {
+            double x[NB];
+#pragma unroll
+            for (int rr = 0; rr < NB; ++rr) {
+                double sacc = (rr == lane) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < rr; ++k) sacc -= sS[rr][k] * x[k];
+                x[rr] = sacc / sS[rr][rr];
+            }
+#pragma unroll
+            for (int rr = 0; rr < NB; ++rr) sLi[rr][lane] = (rr >= lane) ? x[rr] : 0.0;
+        }
+    }
+    __syncthreads();
     const int k1 = k0 + kb;
-    if ((int)blockIdx.x < n_sblocks) {
-        // L_ik = S_ik Linv'  : 32 x kb tile, 4 outputs per thread
+    if ((int)blockIdx.x < nrb) {
         const int i0 = k1 + blockIdx.x * NB;
         for (int i = tid; i < NB * NB; i += 256) {
             const int r = i / NB, c = i % NB;
@@ -158,55 +168,38 @@ k_chol_panel(double *S, int ldS, int m, int k0, int kb, const double *Linv, T *A
             const int r = i / NB, c = i % NB;
             if (i0 + r < m && c < kb) {
                 double s = 0.0;
-                for (int k2 = 0; k2 <= c; ++k2) s += sS[r][k2] * sL[c][k2];
+                for (int k2 = 0; k2 <= c; ++k2) s += sS[r][k2] * sLi[c][k2];
                 S[(size_t)(i0 + r) * ldS + k0 + c] = s;
             }
         }
-    } else if ((int)blockIdx.x == n_sblocks) {
-        // z_k = Linv nu_k
-        __syncthreads();
+    } else {
+        // block-diagonal inverse storage: Dinv is [m_pad256 x 256], row (k0 + r) holds its 256-block's row
+        const int cb = k0 % TB;
+        for (int i = tid; i < NB * NB; i += 256) {
+            const int r = i / NB, c = i % NB;
+            Dinv[(size_t)(k0 + r) * TB + cb + c] = sLi[r][c];
+        }
         __shared__ double sn[NB];
         if (tid < NB) sn[tid] = tid < kb ? nu[k0 + tid] : 0.0;
         __syncthreads();
         if (tid < kb) {
             double s = 0.0;
-            for (int c = 0; c <= tid; ++c) s += sL[tid][c] * sn[c];
+            for (int c = 0; c <= tid; ++c) s += sLi[tid][c] * sn[c];
             nu[k0 + tid] = s;
-        }
-    } else {
-        // B_k = Linv A_k : one column per thread, 32 rows in registers
-        __syncthreads();
-        const int j = (blockIdx.x - n_sblocks - 1) * 256 + tid;
-        if (j >= n_pad) return;
-        double v[NB];
-#pragma unroll
-        for (int r = 0; r < NB; ++r) v[r] = r < kb ? (double)A[(size_t)(k0 + r) * ld + j] : 0.0;
-#pragma unroll
-        for (int r = NB - 1; r >= 0; --r) {
-            if (r < kb) {
-                double s = 0.0;
-#pragma unroll
-                for (int c = 0; c <= r; ++c) s += sL[r][c] * v[c];
-                A[(size_t)(k0 + r) * ld + j] = (T)s;
-            }
         }
     }
 }
 
-// grid.x : [0, n_tiles) lower-triangular 32x32 tiles of the trailing S; then row-block x column-chunk tiles of A;
-// then one block for nu.
-template <typename T>
+// grid.x : [0, n_stiles) lower-triangular 32x32 tiles of the trailing S, then one block for nu.
 __global__ void __launch_bounds__(256)
-k_chol_trailing(double *S, int ldS, int m, int k0, int kb, T *A, int ld, int n_pad, double *nu, int nrb,
-                int n_stiles, int n_cchunks)
+k_chol_trailing(double *S, int ldS, int m, int k0, int kb, double *nu, int n_stiles)
 {
     __shared__ double sA[NB][NB + 1];
     __shared__ double sB[NB][NB + 1];
     const int tid = threadIdx.x;
     const int k1 = k0 + kb;
-    int b = blockIdx.x;
+    const int b = blockIdx.x;
     if (b < n_stiles) {
-        // decode (ti >= tj) from the linear lower-triangle index
         int ti = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
         while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
         while (ti * (ti + 1) / 2 > b) --ti;
@@ -229,34 +222,178 @@ k_chol_trailing(double *S, int ldS, int m, int k0, int kb, T *A, int ld, int n_p
         }
         return;
     }
-    b -= n_stiles;
-    if (b < nrb * n_cchunks) {
-        const int rb = b / n_cchunks, cc = b % n_cchunks;
-        const int i0 = k1 + rb * NB;
-        for (int i = tid; i < NB * NB; i += 256) {
-            const int r = i / NB, c = i % NB;
-            sA[r][c] = (i0 + r < m && c < kb) ? S[(size_t)(i0 + r) * ldS + k0 + c] : 0.0;
-        }
-        __syncthreads();
-        const int j = cc * 256 + tid;
-        if (j >= n_pad) return;
-        double bk[NB];
-#pragma unroll
-        for (int c = 0; c < NB; ++c) bk[c] = c < kb ? (double)A[(size_t)(k0 + c) * ld + j] : 0.0;
-        for (int r = 0; r < NB; ++r) {
-            if (i0 + r >= m) break;
-            double s = 0.0;
-#pragma unroll
-            for (int c = 0; c < NB; ++c) s += sA[r][c] * bk[c];
-            A[(size_t)(i0 + r) * ld + j] = (T)((double)A[(size_t)(i0 + r) * ld + j] - s);
-        }
-        return;
-    }
-    // nu_i -= L_ik z_k
     for (int i = k1 + tid; i < m; i += 256) {
         double s = 0.0;
         for (int c = 0; c < kb; ++c) s += S[(size_t)i * ldS + k0 + c] * nu[k0 + c];
         nu[i] -= s;
+    }
+}
+
+// ------------------------------------------------------------------------------ inverse of the 256-blocks of L
+// Doubling step s -> 2s inside each TB = 256 diagonal block of L:  inv([L11 0; L21 L22]) has the off-diagonal
+// block X21 = -X22 L21 X11.  Two batched small products per level (T = L21 X11, X21 = -X22 T), 32x32 output tile
+// per workgroup.  O(m s^2) flops per level: negligible.
+// mode 0: T[pair] = L21 * X11 ;  mode 1: X21 = -X22 * T
+__global__ void __launch_bounds__(256)
+k_triinv_level(const double *S, int ldS, int m, double *Dinv, double *Tbuf, int s, int mode)
+{
+    __shared__ double sA[NB][NB + 1];
+    __shared__ double sB[NB][NB + 1];
+    const int tiles = s / NB;
+    const int pair = blockIdx.x / (tiles * tiles);
+    const int t = blockIdx.x % (tiles * tiles);
+    const int tr = t / tiles, tc = t % tiles;
+    const int r0 = pair * 2 * s; // first row of the pair's 2s x 2s diagonal block
+    if (r0 + s >= m) return;     // no second half
+    const int cb = r0 % TB;      // column offset of the pair inside its 256-block
+    const int tid = threadIdx.x;
+    double acc[4] = {0, 0, 0, 0};
+    for (int kk = 0; kk < s; kk += NB) {
+        for (int i = tid; i < NB * NB; i += 256) {
+            const int r = i / NB, c = i % NB;
+            double av, bv;
+            if (mode == 0) {
+                const int gr = r0 + s + tr * NB + r, gc = r0 + kk + c; // L21
+                av = (gr < m) ? S[(size_t)gr * ldS + gc] : 0.0;
+                bv = Dinv[(size_t)(r0 + kk + r) * TB + cb + tc * NB + c]; // X11[kk + r][tc*32 + c]
+            } else {
+                av = Dinv[(size_t)(r0 + s + tr * NB + r) * TB + cb + s + kk + c]; // X22[tr*32 + r][kk + c]
+                bv = Tbuf[(size_t)(r0 + s + kk + r) * (TB / 2) + tc * NB + c];   // T[kk + r][tc*32 + c]
+            }
+            sA[r][c] = av;
+            sB[r][c] = bv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * 256;
+            const int r = i / NB, c = i % NB;
+            double sacc = 0.0;
+#pragma unroll
+            for (int k2 = 0; k2 < NB; ++k2) sacc += sA[r][k2] * sB[k2][c];
+            acc[q] += sacc;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid + q * 256;
+        const int r = i / NB, c = i % NB;
+        if (mode == 0) Tbuf[(size_t)(r0 + s + tr * NB + r) * (TB / 2) + tc * NB + c] = acc[q];
+        else Dinv[(size_t)(r0 + s + tr * NB + r) * TB + cb + tc * NB + c] = -acc[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ B = inv(L) A
+// Forward substitution in TB = 256 row blocks, independent per column of A: one workgroup owns a CT-column strip
+// (CT = MFMA block width) and walks the row blocks K = 0, 1, ...:
+//     C   = A_K - L[K, 0:K] B[0:K]      (GEMM, k-depth 256 K, MFMA; L read as fp64 and converted)
+//     B_K = inv(L_KK) C                  (GEMM, k-depth 256, triangular)
+// No inter-workgroup dependency, so the whole solve is ONE launch.  Each wavefront owns 64 of the 256 rows.
+template <typename T>
+struct MmaU;
+template <>
+struct MmaU<float> {
+    static constexpr int MB = 32, NACC = 16;
+    typedef float acc_t __attribute__((ext_vector_type(16)));
+    __device__ static __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+    __device__ static __forceinline__ int col(int lane) { return lane & 31; }
+};
+template <>
+struct MmaU<double> {
+    static constexpr int MB = 16, NACC = 4;
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    __device__ static __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int reg, int lane) { return (lane >> 4) + 4 * reg; }
+    __device__ static __forceinline__ int col(int lane) { return lane & 15; }
+};
+
+constexpr int TR_KS = 16; // k-slab
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_trsm(const double *L, int ldS, int m, int m_pad, const double *Dinv, T *A, int ld)
+{
+    using M = MmaU<T>;
+    constexpr int MB = M::MB, CT = MB, KI = 64 / MB, RB = 64 / MB; // RB row blocks per wavefront
+    __shared__ T sL[TR_KS][TB];
+    __shared__ T sB[TR_KS][CT];
+    __shared__ T sC[TB][CT];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int klane = lane / MB, idx = lane % MB;
+    const int col0 = blockIdx.x * CT;
+    const int nK = (m_pad + TB - 1) / TB;
+    for (int K = 0; K < nK; ++K) {
+        const int rows0 = K * TB;
+        typename M::acc_t acc[RB];
+#pragma unroll
+        for (int x = 0; x < RB; ++x)
+#pragma unroll
+            for (int r = 0; r < M::NACC; ++r) acc[x][r] = (T)0;
+        // phase 1: acc = L[rows0 + r, 0:rows0] * B[0:rows0, strip]
+        for (int kk = 0; kk < rows0; kk += TR_KS) {
+            {
+                const int gr = rows0 + tid;
+                const double *src = L + (size_t)gr * ldS + kk;
+#pragma unroll
+                for (int k = 0; k < TR_KS; ++k) sL[k][tid] = (gr < m) ? (T)src[k] : (T)0;
+            }
+            for (int i = tid; i < TR_KS * CT; i += 256) {
+                const int k = i / CT, c = i % CT;
+                sB[k][c] = A[(size_t)(kk + k) * ld + col0 + c];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < TR_KS; k += KI) {
+                const T b = sB[k + klane][idx];
+#pragma unroll
+                for (int x = 0; x < RB; ++x) acc[x] = M::mma(sL[k + klane][wv * 64 + x * MB + idx], b, acc[x]);
+            }
+            __syncthreads();
+        }
+        // C = A_K - acc
+#pragma unroll
+        for (int x = 0; x < RB; ++x)
+#pragma unroll
+            for (int r = 0; r < M::NACC; ++r) {
+                const int lr = wv * 64 + x * MB + M::row(r, lane), lc = M::col(lane);
+                const int gr = rows0 + lr;
+                const T a = (gr < m_pad) ? A[(size_t)gr * ld + col0 + lc] : (T)0;
+                sC[lr][lc] = a - acc[x][r];
+            }
+        __syncthreads();
+        // phase 2: B_K = inv(L_KK) C  (lower triangular: this wavefront's rows need k < its last row)
+#pragma unroll
+        for (int x = 0; x < RB; ++x)
+#pragma unroll
+            for (int r = 0; r < M::NACC; ++r) acc[x][r] = (T)0;
+        for (int kk = 0; kk < TB; kk += TR_KS) {
+            {
+                const double *src = Dinv + (size_t)(rows0 + tid) * TB + kk;
+                const bool live = rows0 + tid < m_pad;
+#pragma unroll
+                for (int k = 0; k < TR_KS; ++k) sL[k][tid] = live ? (T)src[k] : (T)0;
+            }
+            __syncthreads();
+            if (kk < wv * 64 + 64) {
+#pragma unroll
+                for (int k = 0; k < TR_KS; k += KI) {
+                    const T b = sC[kk + k + klane][idx];
+#pragma unroll
+                    for (int x = 0; x < RB; ++x) acc[x] = M::mma(sL[k + klane][wv * 64 + x * MB + idx], b, acc[x]);
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int x = 0; x < RB; ++x)
+#pragma unroll
+            for (int r = 0; r < M::NACC; ++r) {
+                const int gr = rows0 + wv * 64 + x * MB + M::row(r, lane);
+                if (gr < m_pad) A[(size_t)gr * ld + col0 + M::col(lane)] = acc[x][r];
+            }
+        __syncthreads();
     }
 }
 
@@ -400,19 +537,25 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         k_assemble_S<T><<<grid, 256, 0, s>>>(A, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS);
     }
-    const int n_cchunks = (n_pad + 255) / 256;
     for (int k0 = 0; k0 < m; k0 += NB) {
         const int kb = min(NB, m - k0);
         const int k1 = k0 + kb;
-        k_chol_diag<<<1, 64, 0, s>>>(e->d.S, ldS, k0, kb, e->d.Linv, e->d.counts);
         const int nrb = (m - k1 + NB - 1) / NB; // row blocks below the panel
-        k_chol_panel<T><<<nrb + 1 + n_cchunks, 256, 0, s>>>(e->d.S, ldS, m, k0, kb, e->d.Linv, A, ld, n_pad, e->d.nu,
-                                                           nrb);
+        k_chol_panel<<<nrb + 1, 256, 0, s>>>(e->d.S, ldS, m, k0, kb, e->d.Dinv, e->d.nu, nrb, e->d.counts);
         if (nrb > 0) {
             const int n_stiles = nrb * (nrb + 1) / 2;
-            k_chol_trailing<T><<<n_stiles + nrb * n_cchunks + 1, 256, 0, s>>>(e->d.S, ldS, m, k0, kb, A, ld, n_pad,
-                                                                              e->d.nu, nrb, n_stiles, n_cchunks);
+            k_chol_trailing<<<n_stiles + 1, 256, 0, s>>>(e->d.S, ldS, m, k0, kb, e->d.nu, n_stiles);
         }
+    }
+    for (int sz = NB; sz < TB; sz *= 2) {
+        const int npairs = (m_pad + 2 * sz - 1) / (2 * sz);
+        const int tiles = (sz / NB) * (sz / NB);
+        k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.S, ldS, m, e->d.Dinv, e->d.Tbuf, sz, 0);
+        k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.S, ldS, m, e->d.Dinv, e->d.Tbuf, sz, 1);
+    }
+    {
+        const int CT = sizeof(T) == 4 ? 32 : 16;
+        k_trsm<T><<<n_pad / CT, 256, 0, s>>>(e->d.S, ldS, m, m_pad, e->d.Dinv, A, ld);
     }
     {
         dim3 grid((n + 255) / 256, DX_SPLIT);

@@ -75,6 +75,7 @@ ABI = {
     "ekf_timing_reset": (_i, [_vp]),
     "ekf_timing_get": (_i, [_vp, C.POINTER(EkfStageTimes)]),
     "ekf_synchronize": (_i, [_vp]),
+    "ekf_timing_p_update_launches": (_i, [_vp, _i, _vp, _vp, C.POINTER(_i)]),
     "ekf_shard_rows": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
 }
 
@@ -256,6 +257,15 @@ class EkfEngine:
         t = EkfStageTimes()
         self._chk(self.L.ekf_timing_get(self.h, C.byref(t)))
         return t
+
+    def p_update_launches(self):
+        """(m_rows[int32], ms[float32]) of every P-update launch since the last timing_reset."""
+        k = _i(0)
+        self._chk(self.L.ekf_timing_p_update_launches(self.h, 0, None, None, C.byref(k)))
+        m = np.zeros(max(k.value, 1), dtype=np.int32)
+        ms = np.zeros(max(k.value, 1), dtype=np.float32)
+        self._chk(self.L.ekf_timing_p_update_launches(self.h, k.value, _p(m), _p(ms), C.byref(k)))
+        return m[: k.value], ms[: k.value]
 
     def synchronize(self):
         self._chk(self.L.ekf_synchronize(self.h))
