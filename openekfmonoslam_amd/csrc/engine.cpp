@@ -64,7 +64,7 @@ void ekf_engine_destroy(EkfEngine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     DeviceArrays &d = e->d;
     void *ptrs[] = {d.state,     d.feat_pos,  d.feat_type, d.feat_covpos, d.feat_desc, d.P,        d.pred_vis,
-                    d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,
+                    d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,       d.HPc,      d.Ac,
                     d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
                     d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.Tbuf,
@@ -142,6 +142,8 @@ int ekf_engine_create(const EkfEngineConfig *cfg, EkfEngine **out)
     ALLOC(d.pred_S, 4 * cap);
     ALLOC(d.Hs, 14 * cap);
     ALLOC(d.Hf, 12 * cap);
+    ALLOC(d.HPc, (size_t)mcap * CS);
+    ALLOC(d.Ac, (size_t)round_up((int)mcap, TB) * CS);
     ALLOC(d.work_idx, cap);
     ALLOC(d.work_flag, cap);
     ALLOC(d.plist, cap);

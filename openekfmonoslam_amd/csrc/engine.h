@@ -14,6 +14,7 @@ namespace ekf {
 constexpr int NB = 32;          // Cholesky panel width
 constexpr int TB = 256;         // row block of the triangular solve B = inv(L) A
 constexpr int LD_ALIGN = 128;   // leading dimensions are multiples of this many elements
+constexpr int CS = 16;          // width of the fp64 camera strip kept beside the fp32 work matrices
 constexpr int DX_SPLIT = 16;    // k-splits of the dx = B' z reduction
 
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -53,6 +54,8 @@ struct DeviceArrays {
     double *Hs = nullptr;      // 2x7 per feature
     double *Hf = nullptr;      // 2x6 per feature
     void *HP = nullptr;        // T [2*cap x ldP]: rows 2f, 2f+1 = H_f P
+    double *HPc = nullptr;     // fp64 copy of the first CS = 16 columns of HP (camera block), [2*cap x 16]
+    double *Ac = nullptr;      // fp64 camera strip of A / B, [mcap x 16]
     // work lists
     int *work_idx = nullptr;   // input feature indices of a subset prediction
     int *work_flag = nullptr;  // per work item: predicted?

@@ -22,7 +22,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
          const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
-         double *mHs, double *mHf, int *mpos, int *mdim)
+         double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Ac)
 {
     const int row = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -31,6 +31,7 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
         const int i = row >> 1, r = row & 1;
         const int fi = matches[i].featureIndex;
         if (j < n_pad) A[(size_t)row * ld + j] = HP[(size_t)(2 * fi + r) * ld + j];
+        if (j < CS) Ac[(size_t)row * CS + j] = HPc[(size_t)(2 * fi + r) * CS + j];
         if (blockIdx.x == 0 && r == 0) {
             const int t = threadIdx.x;
             if (t < 14) mHs[14 * i + t] = Hs_tab[14 * fi + t];
@@ -45,6 +46,7 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
         }
     } else if (row < m_pad) {
         if (j < n_pad) A[(size_t)row * ld + j] = (T)0;
+        if (j < CS) Ac[(size_t)row * CS + j] = 0.0;
         if (blockIdx.x == 0 && threadIdx.x == 0) nu[row] = 0.0;
     }
 }
@@ -103,19 +105,29 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane)
     return __hiloint2double(hi, lo);
 }
 
-// Cholesky factor of a 32x32 block held one row per lane (lanes 0..31), in place; returns false on breakdown.
-__device__ __forceinline__ bool wave_chol32(double (&a)[NB], int lane)
+// Cholesky factor AND inverse of a 32x32 block in one sweep, one row per lane (lanes 0..31): forward elimination
+// on the augmented block [A | I] -> [L' | inv(L)].  a[] holds the row of A (lower part meaningful), x[] the row of
+// the identity part; on return a[] = row of L, x[] = row of inv(L).  Column values travel between lanes through
+// SGPRs (v_readlane), never through LDS.  Returns false on a non-positive pivot.
+__device__ __forceinline__ bool wave_chol_inv32(double (&a)[NB], double (&x)[NB], int lane)
 {
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const double djj = bcast_lane(a[j], j);
         ok = ok && (djj > 0.0);
-        const double dj = sqrt(djj > 0.0 ? djj : 1.0);
-        const double l = (lane > j) ? a[j] / dj : (lane == j ? dj : 0.0);
+        const double rs = rsqrt(djj > 0.0 ? djj : 1.0);
+        const double l = (lane > j) ? a[j] * rs : (lane == j ? djj * rs : 0.0);
         a[j] = l;
+        if (lane == j) {
+#pragma unroll
+            for (int c = 0; c <= j; ++c) x[c] *= rs;
+        }
 #pragma unroll
         for (int c = j + 1; c < NB; ++c) a[c] -= l * bcast_lane(l, c);
+        const double lx = (lane > j) ? l : 0.0;
+#pragma unroll
+        for (int c = 0; c <= j; ++c) x[c] -= lx * bcast_lane(x[c], j);
     }
     return ok;
 }
@@ -128,31 +140,18 @@ k_chol_panel(double *S, int ldS, int m, int k0, int kb, double *Dinv, double *nu
     __shared__ double sS[NB][NB + 1];
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < 64) {
-        double a[NB];
+        double a[NB], x[NB];
         const int r = lane < NB ? lane : 0;
 #pragma unroll
-        for (int c = 0; c < NB; ++c)
+        for (int c = 0; c < NB; ++c) {
             a[c] = (lane < kb && c <= r && c < kb) ? S[(size_t)(k0 + r) * ldS + k0 + c] : ((c == r) ? 1.0 : 0.0);
-        const bool ok = wave_chol32(a, lane);
-        if (!ok && lane == 0 && blockIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
-        // L_kk to LDS (sS), then lane c solves column c of the inverse with broadcast LDS reads of L
-        if (lane < NB) {
-#pragma unroll
-            for (int c = 0; c < NB; ++c) sS[lane][c] = (c <= lane) ? a[c] : 0.0;
+            x[c] = (c == lane) ? 1.0 : 0.0;
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): single wavefront, LDS writes above are visible below
-        __builtin_amdgcn_wave_barrier();
+        const bool ok = wave_chol_inv32(a, x, lane);
+        if (!ok && lane == 0 && blockIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
         if (lane < NB) {
-            double x[NB];
 #pragma unroll
-            for (int rr = 0; rr < NB; ++rr) {
-                double sacc = (rr == lane) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < rr; ++k) sacc -= sS[rr][k] * x[k];
-                x[rr] = sacc / sS[rr][rr];
-            }
-#pragma unroll
-            for (int rr = 0; rr < NB; ++rr) sLi[rr][lane] = (rr >= lane) ? x[rr] : 0.0;
+            for (int c = 0; c < NB; ++c) sLi[lane][c] = (c <= lane) ? x[c] : 0.0;
         }
     }
     __syncthreads();
@@ -412,6 +411,25 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
     part[(size_t)ks * ldpart + j] = s;
 }
 
+// fp32 configuration: the 13 camera components of dx from the fp64 strip Bc = inv(L) (H P)[:, 0:16], so the camera
+// state does not inherit the rounding accumulated in the fp32 forward substitution.  Overwrites the partial sums
+// of columns 0..12.
+__global__ void __launch_bounds__(1024) k_dx_cam(const double *Bc, int m, const double *z, double *part, int ldpart)
+{
+    __shared__ double red[64][CS + 1];
+    const int j = threadIdx.x % CS, g = threadIdx.x / CS; // 64 row groups x 16 columns
+    double s = 0.0;
+    for (int k = g; k < m; k += 64) s += Bc[(size_t)k * CS + j] * z[k];
+    red[g][j] = s;
+    __syncthreads();
+    if (threadIdx.x < 13) {
+        double t = 0.0;
+        for (int q = 0; q < 64; ++q) t += red[q][threadIdx.x];
+        part[threadIdx.x] = t;
+        for (int ks = 1; ks < DX_SPLIT; ++ks) part[(size_t)ks * ldpart + threadIdx.x] = 0.0;
+    }
+}
+
 // stateUpdate (Update.cpp:147-204): x += dx with the DELTA dead-band on every component; R(q) recomputed from
 // the un-normalised q (:168).
 __global__ void __launch_bounds__(256)
@@ -530,7 +548,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         dim3 grid((n_pad + 255) / 256, m_pad);
         k_gather<T><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const T *)e->d.HP, A, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
-                                         e->d.mHf, e->d.mpos, e->d.mdim);
+                                         e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Ac);
     }
     {
         dim3 grid((M + 15) / 16, (M + 15) / 16);
@@ -556,10 +574,12 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     {
         const int CT = sizeof(T) == 4 ? 32 : 16;
         k_trsm<T><<<n_pad / CT, 256, 0, s>>>(e->d.S, ldS, m, m_pad, e->d.Dinv, A, ld);
+        if (sizeof(T) == 4) k_trsm<double><<<1, 256, 0, s>>>(e->d.S, ldS, m, m_pad, e->d.Dinv, e->d.Ac, CS);
     }
     {
         dim3 grid((n + 255) / 256, DX_SPLIT);
         k_dx_partial<T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.nu, e->d.dx_part, ld);
+        if (sizeof(T) == 4) k_dx_cam<<<1, 1024, 0, s>>>(e->d.Ac, m, e->d.nu, e->d.dx_part, ld);
         const int nt = max(e->N * 6, 1);
         k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
                                                        e->N, e->d.dx_part, ld);
