@@ -1,0 +1,146 @@
+// compat_check.cpp -- drives the engine through the reference-shaped C++ surface (ekf_compat.h).
+//   compat_check <scenario.bin>
+// Reads a scenario written by tests/test_gpu_compat.py, then
+//   (1) runs every frame through class EKF (device-resident), and
+//   (2) replays frame 0 through the reference's stage functions in the order of EKF::step (EKF.cpp:242-556),
+// printing the camera state, trace(P) and the step counters of both, which the Python test compares with the
+// ctypes path and the oracle.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../openekfmonoslam_amd/compat/ekf_compat.h"
+
+template <typename T>
+static void rd(FILE *f, T *p, size_t n)
+{
+    if (fread(p, sizeof(T), n, f) != n) {
+        std::fprintf(stderr, "short read\n");
+        std::exit(2);
+    }
+}
+
+static void report(const char *tag, const State &s, const Matd &P, const EkfStepInfo *info)
+{
+    double tr = 0, fro = 0;
+    for (int i = 0; i < P.rows; ++i) tr += P[i][i];
+    for (size_t i = 0; i < (size_t)P.rows * P.cols; ++i) fro += P.ptr()[i] * P.ptr()[i];
+    std::printf("%s x13", tag);
+    for (int i = 0; i < 13; ++i) std::printf(" %.17g", s.x13()[i]);
+    std::printf(" trace %.17g fro %.17g", tr, std::sqrt(fro));
+    if (info) std::printf(" counts %d %d %d %d %d", info->n_predicted, info->n_matches, info->n_hypotheses, info->n_inliers, info->n_rescued);
+    std::printf("\n");
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) return 2;
+    FILE *f = std::fopen(argv[1], "rb");
+    if (!f) return 2;
+    EkfCamera cam;
+    EkfParams par;
+    int32_t N, nframes;
+    rd(f, &cam, 1);
+    rd(f, &par, 1);
+    rd(f, &N, 1);
+    rd(f, &nframes, 1);
+    const int n = 13 + 6 * N;
+    State seed;
+    rd(f, seed.x13(), 13);
+    seed.setOrientation(seed.orientation);
+    std::vector<double> pos(6 * (size_t)N);
+    std::vector<uint8_t> desc(EKF_DESC_BYTES * (size_t)N);
+    rd(f, pos.data(), pos.size());
+    rd(f, desc.data(), desc.size());
+    for (int i = 0; i < N; ++i) {
+        Descriptor32 d;
+        std::memcpy(d.bytes, &desc[(size_t)EKF_DESC_BYTES * i], EKF_DESC_BYTES);
+        seed.addFeature(new MapFeature(&pos[6 * (size_t)i], 6, 13 + 6 * i, d, MAPFEATURE_TYPE_INVERSE_DEPTH));
+    }
+    Matd P0(n, n);
+    rd(f, P0.ptr(), (size_t)n * n);
+    std::vector<FrameKeypoints> frames(nframes);
+    for (int t = 0; t < nframes; ++t) {
+        int32_t K;
+        rd(f, &K, 1);
+        frames[t].keypoints.resize(K);
+        frames[t].descriptors.resize((size_t)K * EKF_DESC_BYTES);
+        rd(f, frames[t].keypoints.data(), K);
+        rd(f, frames[t].descriptors.data(), (size_t)K * EKF_DESC_BYTES);
+    }
+    std::fclose(f);
+    try {
+        // (1) class EKF
+        {
+            EKF ekf(cam, par, N + 8);
+            ekf.init(seed, P0);
+            EkfStepInfo info;
+            for (int t = 0; t < nframes; ++t) info = ekf.step(frames[t]);
+            ekf.syncToHost();
+            report("class", ekf.state, ekf.stateCovarianceMatrix, &info);
+        }
+        // (2) the reference's stage functions, frame 0, in EKF::step order
+        ekf_compat::Context::instance().configure(cam, par, N + 8);
+        State state(seed);
+        Matd P = P0;
+        VectorImageFeaturePrediction preds;
+        VectorMatd jac;
+        VectorMapFeature unseen;
+        std::vector<int> all;
+        stateAndCovariancePrediction(state, P);                                               // EKF.cpp:273
+        predictCameraMeasurements(state, P, state.mapFeatures, all, preds, jac, unseen);       // :278
+        VectorFeatureMatch matches;
+        matchPredictedFeatures(frames[0], state, P, preds, matches);                           // :337
+        VectorImageFeaturePrediction mpreds;
+        VectorMatd mjac;
+        for (size_t i = 0; i < matches.size(); ++i)                                            // :368-392
+            for (size_t k = 0; k < preds.size(); ++k)
+                if (preds[k]->featureIndex == matches[i]->featureIndex) {
+                    mpreds.push_back(preds[k]);
+                    mjac.push_back(jac[k]);
+                    break;
+                }
+        VectorFeatureMatch inl, outl;
+        VectorImageFeaturePrediction inlP;
+        VectorMatd inlJ;
+        ransac(state, P, mpreds, mjac, matches, inl, inlP, inlJ, outl);                        // :402
+        update(state, P, inl, inlP, inlJ);                                                     // :430
+        VectorMapFeature outF, unseenOut;
+        std::vector<int> outIdx;
+        for (size_t i = 0; i < outl.size(); ++i) {                                             // :464-470
+            outF.push_back(state.mapFeatures[outl[i]->featureIndex]);
+            outIdx.push_back(outl[i]->featureIndex);
+        }
+        VectorImageFeaturePrediction oP;
+        VectorMatd oJ;
+        if (!outF.empty()) predictCameraMeasurements(state, P, outF, outIdx, oP, oJ, unseenOut); // :473
+        if (!oP.empty() && oP.size() < outl.size()) {                                          // :483-499
+            VectorFeatureMatch kept;
+            size_t j = 0;
+            for (size_t i = 0; i < outl.size() && j < oP.size(); ++i)
+                if (outl[i]->featureIndex == oP[j]->featureIndex) { ++j; kept.push_back(outl[i]); }
+            outl = kept;
+        }
+        VectorFeatureMatch resM;
+        VectorImageFeaturePrediction resP;
+        VectorMatd resJ;
+        if (!outl.empty() && !oP.empty()) rescueOutliers(outl, oP, oJ, resM, resP, resJ);      // :504
+        if (!resM.empty()) update(state, P, resM, resP, resJ);                                 // :531
+        EkfStepInfo info;
+        info.n_predicted = (int)preds.size();
+        info.n_matches = (int)matches.size();
+        info.n_hypotheses = -1;
+        info.n_inliers = (int)inl.size();
+        info.n_rescued = (int)resM.size();
+        report("functions", state, P, &info);
+        // the caller frees the per-frame heap objects (EKF.cpp:637-660)
+        for (size_t i = 0; i < preds.size(); ++i) delete preds[i];
+        for (size_t i = 0; i < jac.size(); ++i) delete jac[i];
+        for (size_t i = 0; i < oP.size(); ++i) delete oP[i];
+        for (size_t i = 0; i < oJ.size(); ++i) delete oJ[i];
+        for (size_t i = 0; i < matches.size(); ++i) delete matches[i];
+    } catch (const ekf_compat::Error &e) {
+        std::fprintf(stderr, "ekf_compat error %d: %s\n", e.code, e.what());
+        return 1;
+    }
+    return 0;
+}

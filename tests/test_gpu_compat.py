@@ -1,0 +1,92 @@
+"""The reference-shaped C++ surface (openekfmonoslam_amd/compat/ekf_compat.h) driven by tests/cpp/compat_check.cpp:
+class EKF and the stage free functions must reproduce the ctypes path and the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from openekfmonoslam_amd.synth import SyntheticSequence
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "openekfmonoslam_amd")
+
+
+def build_compat_check(out_dir):
+    exe = os.path.join(str(out_dir), "compat_check")
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-o", exe, os.path.join(ROOT, "tests", "cpp", "compat_check.cpp"),
+                           "-L", PKG, "-lekf_engine", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def write_scenario(path, seq):
+    with open(path, "wb") as f:
+        f.write(bytes(seq.cam))
+        f.write(bytes(seq.par))
+        f.write(np.array([seq.n_features, len(seq.frames)], dtype=np.int32).tobytes())
+        f.write(np.ascontiguousarray(seq.x13, dtype=np.float64).tobytes())
+        f.write(np.ascontiguousarray(seq.feature_pos, dtype=np.float64).tobytes())
+        f.write(np.ascontiguousarray(seq.feature_desc, dtype=np.uint8).tobytes())
+        f.write(np.ascontiguousarray(seq.P0, dtype=np.float64).tobytes())
+        for kps, desc in seq.frames:
+            f.write(np.array([len(kps)], dtype=np.int32).tobytes())
+            f.write(np.ascontiguousarray(kps).tobytes())
+            f.write(np.ascontiguousarray(desc, dtype=np.uint8).tobytes())
+
+
+def parse(line):
+    tok = line.split()
+    x = np.array([float(v) for v in tok[2:15]])
+    trace, fro = float(tok[16]), float(tok[18])
+    counts = [int(v) for v in tok[20:25]]
+    return x, trace, fro, counts
+
+
+def test_compat_header_compiles_with_plain_gxx(tmp_path):
+    """CPU-only: the compat layer needs nothing but a C++11 compiler and the C ABI library."""
+    from openekfmonoslam_amd import build
+
+    build.build_engine()
+    assert os.path.exists(build_compat_check(tmp_path))
+
+
+@pytest.mark.gpu
+def test_compat_class_and_functions_match_ctypes_and_oracle(tmp_path, oracle_lib):
+    from openekfmonoslam_amd import engine
+
+    seq = SyntheticSequence(24, 3)
+    exe = build_compat_check(tmp_path)
+    scen = os.path.join(str(tmp_path), "scenario.bin")
+    write_scenario(scen, seq)
+    out = subprocess.run([exe, scen], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    res = {ln.split()[0]: parse(ln) for ln in out if ln.startswith(("class", "functions"))}
+    assert set(res) == {"class", "functions"}
+
+    e = engine.EkfEngine(seq.cam, seq.par, 32, max_keypoints=256)
+    o = oracle_lib.Oracle(seq.cam, seq.par, 32)
+    e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    o.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    infos = []
+    for t, (kps, desc) in enumerate(seq.frames):
+        infos.append(e.step(kps, desc))
+        if t == 0:
+            x0, _, P0 = e.get_state()
+            io = o.step(kps, desc, oracle_lib.LITERAL)
+            xo, Po = o.x13(), o.P()
+    x, _, P = e.get_state()
+    # class EKF == ctypes path, all frames, bitwise
+    xc, tr, fro, counts = res["class"]
+    np.testing.assert_array_equal(xc, x)
+    assert tr == float(np.trace(P)) or abs(tr - np.trace(P)) <= 1e-15 * abs(tr)
+    li = infos[-1]
+    assert counts == [li.n_predicted, li.n_matches, li.n_hypotheses, li.n_inliers, li.n_rescued]
+    # stage functions, frame 0: equal to the resident path and within 1e-8 of the oracle
+    xf, trf, frof, cf = res["functions"]
+    np.testing.assert_allclose(xf, x0, rtol=1e-12, atol=1e-15)
+    assert abs(trf - np.trace(P0)) <= 1e-12 * abs(trf)
+    assert cf[0] == infos[0].n_predicted and cf[1] == infos[0].n_matches
+    assert cf[3] == infos[0].n_inliers and cf[4] == infos[0].n_rescued
+    np.testing.assert_allclose(xf, xo, rtol=1e-8, atol=1e-10)
+    assert abs(frof - np.linalg.norm(Po)) <= 1e-8 * frof
+    assert (io.n_matches, io.n_inliers, io.n_rescued) == (cf[1], cf[3], cf[4])
