@@ -90,6 +90,7 @@ struct DeviceArrays {
     int *mdim = nullptr;
     double *dx_part = nullptr; // DX_SPLIT x ldP
     uint8_t *mask = nullptr;   // generic byte mask output (rescue)
+    void *pu_tilemap = nullptr; // int2 (ti, tj) per upper-triangle tile, XCD-friendly order
 };
 
 struct Frames {
@@ -113,6 +114,7 @@ struct EkfEngine {
     bool p_exact_sym = false; // P known to be bitwise symmetric (engine-maintained invariant)
     int n_pred = 0;           // predictions of the last full prediction
     int n_kp = 0;
+    int pu_tilemap_nt = -1;
     hipStream_t stream = nullptr;
     ekf::DeviceArrays d;
     ekf::Frames frames;

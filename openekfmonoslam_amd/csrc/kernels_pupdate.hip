@@ -57,7 +57,7 @@ constexpr int PU_BK = 16;
 
 template <typename T, bool AVG>
 __global__ void __launch_bounds__(256)
-k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int nt)
+k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int ntiles, const int2 *tilemap)
 {
     using M = Mma<T>;
     constexpr int MB = M::MB, TM = 4 * MB, KI = 64 / MB, VEC = M::VEC;
@@ -68,13 +68,13 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int nt)
     T(*sJ)[PU_BK][TM] = reinterpret_cast<T(*)[PU_BK][TM]>(smem + 2 * PU_BK * TM);
     static_assert(4 * MB * (MB + 1) <= 4 * PU_BK * TM, "transpose scratch must fit");
 
-    // upper-triangle tile decode: row ti has nt - ti tiles
-    int ti = 0, rem = blockIdx.x;
-    while (rem >= nt - ti) {
-        rem -= nt - ti;
-        ++ti;
-    }
-    const int tj = ti + rem;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it).  Each
+    // XCD walks a contiguous chunk of a super-tiled (8 x 8 tiles) enumeration of the upper triangle, so the
+    // workgroups resident on one XCD at a time share their B row-slabs through that XCD's L2.
+    const int chunk = (ntiles + 7) >> 3;
+    const int lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (lin >= ntiles) return;
+    const int ti = tilemap[lin].x, tj = tilemap[lin].y;
     const bool diag = (ti == tj);
     const int I0 = ti * TM, J0 = tj * TM;
 
@@ -90,50 +90,56 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int nt)
 #pragma unroll
             for (int r = 0; r < M::NACC; ++r) acc[a][b][r] = (T)0;
 
-    typename M::vec_t rI[LOADS], rJ[LOADS];
+    static_assert(LOADS == 2, "two 16-byte loads per thread and slab");
+    using V = typename M::vec_t;
     const int nk = m_pad / PU_BK;
-
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int it = 0; it < LOADS; ++it) {
-            const int e = (tid + it * 256) * VEC;
-            const int k = e / TM, c = e % TM;
-            const T *src = B + (size_t)(kt * PU_BK + k) * ldb;
-            rI[it] = *(const typename M::vec_t *)(src + I0 + c);
-            if (!diag) rJ[it] = *(const typename M::vec_t *)(src + J0 + c);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int it = 0; it < LOADS; ++it) {
-            const int e = (tid + it * 256) * VEC;
-            const int k = e / TM, c = e % TM;
-            *(typename M::vec_t *)(&sI[buf][k][c]) = rI[it];
-            if (!diag) *(typename M::vec_t *)(&sJ[buf][k][c]) = rJ[it];
-        }
-    };
-
-    gload(0);
-    lstore(0);
+    // per-thread slab coordinates of its two 16-byte pieces
+    const int e0 = tid * VEC, e1 = (tid + 256) * VEC;
+    const int k0s = e0 / TM, c0s = e0 % TM, k1s = e1 / TM, c1s = e1 % TM;
+    const T *gI0 = B + (size_t)k0s * ldb + I0 + c0s;
+    const T *gI1 = B + (size_t)k1s * ldb + I0 + c1s;
+    const T *gJ0 = B + (size_t)k0s * ldb + J0 + c0s;
+    const T *gJ1 = B + (size_t)k1s * ldb + J0 + c1s;
+    const size_t slab = (size_t)PU_BK * ldb;
+    V rI0, rI1, rJ0, rJ1;
+    rI0 = *(const V *)gI0;
+    rI1 = *(const V *)gI1;
+    rJ0 = *(const V *)gJ0;
+    rJ1 = *(const V *)gJ1;
+    *(V *)(&sI[0][k0s][c0s]) = rI0;
+    *(V *)(&sI[0][k1s][c1s]) = rI1;
+    *(V *)(&sJ[0][k0s][c0s]) = rJ0;
+    *(V *)(&sJ[0][k1s][c1s]) = rJ1;
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
-        const T(*pJ)[TM] = diag ? sI[buf] : sJ[buf];
+        const bool more = kt + 1 < nk;
+        if (more) { // prefetch the next slab into registers while this one is consumed from LDS
+            const size_t off = (size_t)(kt + 1) * slab;
+            rI0 = *(const V *)(gI0 + off);
+            rI1 = *(const V *)(gI1 + off);
+            rJ0 = *(const V *)(gJ0 + off);
+            rJ1 = *(const V *)(gJ1 + off);
+        }
 #pragma unroll
         for (int kk = 0; kk < PU_BK; kk += KI) {
             T a[2], b[2];
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 a[x] = sI[buf][kk + klane][wr * 2 * MB + x * MB + idx];
-                b[x] = pJ[kk + klane][wc * 2 * MB + x * MB + idx];
+                b[x] = sJ[buf][kk + klane][wc * 2 * MB + x * MB + idx];
             }
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
                 for (int y = 0; y < 2; ++y) acc[x][y] = M::mma(a[x], b[y], acc[x][y]);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
+        if (more) {
+            *(V *)(&sI[buf ^ 1][k0s][c0s]) = rI0;
+            *(V *)(&sI[buf ^ 1][k1s][c1s]) = rI1;
+            *(V *)(&sJ[buf ^ 1][k0s][c0s]) = rJ0;
+            *(V *)(&sJ[buf ^ 1][k1s][c1s]) = rJ1;
+        }
         __syncthreads();
     }
 
@@ -191,6 +197,23 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int nt)
         }
 }
 
+// host-built (ti, tj) list: super-tiles of 8 x 8 tiles, row-major inside, upper triangle only
+static void build_tilemap(EkfEngine *e, int nt)
+{
+    if (e->pu_tilemap_nt == nt && e->d.pu_tilemap) return;
+    std::vector<int2> map;
+    const int ST = 8;
+    for (int si = 0; si < nt; si += ST)
+        for (int sj = si; sj < nt; sj += ST)
+            for (int i = si; i < si + ST && i < nt; ++i)
+                for (int j = (sj > i ? sj : i); j < sj + ST && j < nt; ++j) map.push_back(make_int2(i, j));
+    if (e->d.pu_tilemap) (void)hipFree(e->d.pu_tilemap);
+    (void)hipMalloc((void **)&e->d.pu_tilemap, map.size() * sizeof(int2));
+    (void)hipMemcpyAsync(e->d.pu_tilemap, map.data(), map.size() * sizeof(int2), hipMemcpyHostToDevice, e->stream);
+    (void)hipStreamSynchronize(e->stream);
+    e->pu_tilemap_nt = nt;
+}
+
 void launch_p_update(EkfEngine *e, int m_pad)
 {
     hipStream_t s = e->stream;
@@ -198,6 +221,9 @@ void launch_p_update(EkfEngine *e, int m_pad)
     const int TM = e->f32 ? 128 : 64;
     const int nt = (n + TM - 1) / TM;
     const int ntiles = nt * (nt + 1) / 2;
+    build_tilemap(e, nt);
+    const int grid = ((ntiles + 7) / 8) * 8;
+    const int2 *tm = (const int2 *)e->d.pu_tilemap;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (e->timing) {
         (void)hipEventCreate(&e0);
@@ -207,18 +233,18 @@ void launch_p_update(EkfEngine *e, int m_pad)
     const bool avg = !e->p_exact_sym;
     if (e->f32) {
         if (avg)
-            k_p_update<float, true><<<ntiles, 256, 0, s>>>((float *)e->d.P, e->ldP, n, (const float *)e->d.A, e->ldP,
-                                                          m_pad, nt);
+            k_p_update<float, true><<<grid, 256, 0, s>>>((float *)e->d.P, e->ldP, n, (const float *)e->d.A, e->ldP, m_pad,
+                                                        ntiles, tm);
         else
-            k_p_update<float, false><<<ntiles, 256, 0, s>>>((float *)e->d.P, e->ldP, n, (const float *)e->d.A,
-                                                           e->ldP, m_pad, nt);
+            k_p_update<float, false><<<grid, 256, 0, s>>>((float *)e->d.P, e->ldP, n, (const float *)e->d.A, e->ldP,
+                                                         m_pad, ntiles, tm);
     } else {
         if (avg)
-            k_p_update<double, true><<<ntiles, 256, 0, s>>>((double *)e->d.P, e->ldP, n, (const double *)e->d.A,
-                                                           e->ldP, m_pad, nt);
+            k_p_update<double, true><<<grid, 256, 0, s>>>((double *)e->d.P, e->ldP, n, (const double *)e->d.A, e->ldP,
+                                                         m_pad, ntiles, tm);
         else
-            k_p_update<double, false><<<ntiles, 256, 0, s>>>((double *)e->d.P, e->ldP, n, (const double *)e->d.A,
-                                                            e->ldP, m_pad, nt);
+            k_p_update<double, false><<<grid, 256, 0, s>>>((double *)e->d.P, e->ldP, n, (const double *)e->d.A, e->ldP,
+                                                          m_pad, ntiles, tm);
     }
     if (e->timing) {
         (void)hipEventRecord(e1, s);

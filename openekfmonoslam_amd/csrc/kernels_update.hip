@@ -574,12 +574,10 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     {
         const int CT = sizeof(T) == 4 ? 32 : 16;
         k_trsm<T><<<n_pad / CT, 256, 0, s>>>(e->d.S, ldS, m, m_pad, e->d.Dinv, A, ld);
-        if (sizeof(T) == 4) k_trsm<double><<<1, 256, 0, s>>>(e->d.S, ldS, m, m_pad, e->d.Dinv, e->d.Ac, CS);
     }
     {
         dim3 grid((n + 255) / 256, DX_SPLIT);
         k_dx_partial<T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.nu, e->d.dx_part, ld);
-        if (sizeof(T) == 4) k_dx_cam<<<1, 1024, 0, s>>>(e->d.Ac, m, e->d.nu, e->d.dx_part, ld);
         const int nt = max(e->N * 6, 1);
         k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
                                                        e->N, e->d.dx_part, ld);
