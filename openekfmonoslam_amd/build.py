@@ -14,6 +14,7 @@ SOURCES = ["engine.cpp", "kernels_predict.hip", "kernels_match.hip", "kernels_ra
 NO_CONTRACT = {"kernels_predict.hip", "kernels_match.hip", "kernels_ransac.hip"}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-x", "hip"]
+FLAGS += os.environ.get("EKF_EXTRA_FLAGS", "").split()  # tuning experiments, e.g. -DPU_BK_VALUE=32
 
 
 def _newer(src, dst):

@@ -53,10 +53,16 @@ struct Mma<double> {
     __device__ static __forceinline__ int col(int lane) { return lane & 15; }
 };
 
-constexpr int PU_BK = 16;
+#ifndef PU_BK_VALUE
+#define PU_BK_VALUE 16
+#endif
+constexpr int PU_BK = PU_BK_VALUE;
 
+#ifndef PU_MIN_WAVES
+#define PU_MIN_WAVES 4
+#endif
 template <typename T, bool AVG>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, PU_MIN_WAVES)
 k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int ntiles, const int2 *tilemap)
 {
     using M = Mma<T>;
@@ -90,36 +96,39 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int ntiles, con
 #pragma unroll
             for (int r = 0; r < M::NACC; ++r) acc[a][b][r] = (T)0;
 
-    static_assert(LOADS == 2, "two 16-byte loads per thread and slab");
     using V = typename M::vec_t;
+    static_assert(LOADS == 2 || LOADS == 4, "2 or 4 16-byte pieces per thread and slab");
     const int nk = m_pad / PU_BK;
-    // per-thread slab coordinates of its two 16-byte pieces
-    const int e0 = tid * VEC, e1 = (tid + 256) * VEC;
-    const int k0s = e0 / TM, c0s = e0 % TM, k1s = e1 / TM, c1s = e1 % TM;
-    const T *gI0 = B + (size_t)k0s * ldb + I0 + c0s;
-    const T *gI1 = B + (size_t)k1s * ldb + I0 + c1s;
-    const T *gJ0 = B + (size_t)k0s * ldb + J0 + c0s;
-    const T *gJ1 = B + (size_t)k1s * ldb + J0 + c1s;
     const size_t slab = (size_t)PU_BK * ldb;
-    V rI0, rI1, rJ0, rJ1;
-    rI0 = *(const V *)gI0;
-    rI1 = *(const V *)gI1;
-    rJ0 = *(const V *)gJ0;
-    rJ1 = *(const V *)gJ1;
-    *(V *)(&sI[0][k0s][c0s]) = rI0;
-    *(V *)(&sI[0][k1s][c1s]) = rI1;
-    *(V *)(&sJ[0][k0s][c0s]) = rJ0;
-    *(V *)(&sJ[0][k1s][c1s]) = rJ1;
+    // Per-thread pieces of a slab, in named registers (arrays here end up in scratch: hipcc cannot promote them).
+#define PU_PIECE(q) const int lk##q = ((tid + q * 256) * VEC) / TM, lc##q = ((tid + q * 256) * VEC) % TM; \
+                    const T *gI##q = B + (size_t)lk##q * ldb + I0 + lc##q; const T *gJ##q = B + (size_t)lk##q * ldb + J0 + lc##q; \
+                    V rI##q = *(const V *)gI##q, rJ##q = *(const V *)gJ##q;
+    PU_PIECE(0)
+    PU_PIECE(1)
+    PU_PIECE(2)
+    PU_PIECE(3)
+#undef PU_PIECE
+#define PU_STORE(q, b) *(V *)(&sI[b][lk##q][lc##q]) = rI##q; *(V *)(&sJ[b][lk##q][lc##q]) = rJ##q;
+#define PU_LOAD(q, off) rI##q = *(const V *)(gI##q + off); rJ##q = *(const V *)(gJ##q + off);
+    PU_STORE(0, 0)
+    PU_STORE(1, 0)
+    if (LOADS == 4) {
+        PU_STORE(2, 0)
+        PU_STORE(3, 0)
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         const bool more = kt + 1 < nk;
         if (more) { // prefetch the next slab into registers while this one is consumed from LDS
             const size_t off = (size_t)(kt + 1) * slab;
-            rI0 = *(const V *)(gI0 + off);
-            rI1 = *(const V *)(gI1 + off);
-            rJ0 = *(const V *)(gJ0 + off);
-            rJ1 = *(const V *)(gJ1 + off);
+            PU_LOAD(0, off)
+            PU_LOAD(1, off)
+            if (LOADS == 4) {
+                PU_LOAD(2, off)
+                PU_LOAD(3, off)
+            }
         }
 #pragma unroll
         for (int kk = 0; kk < PU_BK; kk += KI) {
@@ -135,13 +144,17 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int ntiles, con
                 for (int y = 0; y < 2; ++y) acc[x][y] = M::mma(a[x], b[y], acc[x][y]);
         }
         if (more) {
-            *(V *)(&sI[buf ^ 1][k0s][c0s]) = rI0;
-            *(V *)(&sI[buf ^ 1][k1s][c1s]) = rI1;
-            *(V *)(&sJ[buf ^ 1][k0s][c0s]) = rJ0;
-            *(V *)(&sJ[buf ^ 1][k1s][c1s]) = rJ1;
+            PU_STORE(0, buf ^ 1)
+            PU_STORE(1, buf ^ 1)
+            if (LOADS == 4) {
+                PU_STORE(2, buf ^ 1)
+                PU_STORE(3, buf ^ 1)
+            }
         }
         __syncthreads();
     }
+#undef PU_STORE
+#undef PU_LOAD
 
     // epilogue.  P is bitwise symmetric on entry (engine invariant) unless AVG.
     //  - diagonal tiles: every element (i, j) of the tile is computed (acc is bitwise symmetric), written in place;
