@@ -85,17 +85,12 @@ def main():
     ap.add_argument("--no-roofline-pass", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+    from openekfmonoslam_amd.dist import Ranks
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ranks = Ranks()  # WORLD_SIZE > 1: process group over RCCL ("nccl"), one rank per GPU
+    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
     torch.cuda.set_device(local_rank)
 
@@ -116,23 +111,18 @@ def main():
         for t in range(args.warmup):
             eng.step_frame(t)
         eng.timing_reset()
-        if dist is not None:
-            dist.barrier()
+        ranks.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for t in range(args.warmup, n_frames):
             infos.append(eng.step_frame(t))
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        ranks.barrier()
         torch.cuda.synchronize()
         return time.perf_counter() - t0, infos
 
     elapsed, infos = run(False)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = ranks.max_over_ranks(elapsed)
 
     roof, stages = None, None
     if not args.no_roofline_pass:
@@ -173,8 +163,7 @@ def main():
                                                    "rescue_ms", "update_hi_ms")}
 
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        ranks.close()
         return
     value = world * args.steps / elapsed
     out = {
@@ -209,8 +198,7 @@ def main():
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

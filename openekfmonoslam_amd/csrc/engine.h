@@ -115,6 +115,7 @@ struct EkfEngine {
     int n_pred = 0;           // predictions of the last full prediction
     int n_kp = 0;
     int pu_tilemap_nt = -1;
+    int pu_per_xcd = 0;
     hipStream_t stream = nullptr;
     ekf::DeviceArrays d;
     ekf::Frames frames;

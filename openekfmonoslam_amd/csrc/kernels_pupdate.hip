@@ -58,12 +58,44 @@ struct Mma<double> {
 #endif
 constexpr int PU_BK = PU_BK_VALUE;
 
+// MFMAs of one k-slab held in LDS.  Operands of k-step kk+KI are fetched BEFORE the MFMAs of k-step kk are issued:
+// a wavefront issues in order, so without this its matrix pipe idles for one LDS round trip per k-step.
+template <typename T, bool FULL, int TMc>
+__device__ __forceinline__ void pu_slab(const T (*sIb)[TMc], const T (*sJb)[TMc], int klane, int ra, int cb,
+                                        typename Mma<T>::acc_t &c00, typename Mma<T>::acc_t &c01,
+                                        typename Mma<T>::acc_t &c10, typename Mma<T>::acc_t &c11)
+{
+    using M = Mma<T>;
+    constexpr int MB = M::MB, KI = 64 / MB;
+    T a0 = sIb[klane][ra], a1 = FULL ? sIb[klane][ra + MB] : (T)0;
+    T b0 = sJb[klane][cb], b1 = sJb[klane][cb + MB];
+#pragma unroll
+    for (int kk = 0; kk < PU_BK; kk += KI) {
+        T na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+        if (kk + KI < PU_BK) {
+            na0 = sIb[kk + KI + klane][ra];
+            if (FULL) na1 = sIb[kk + KI + klane][ra + MB];
+            nb0 = sJb[kk + KI + klane][cb];
+            nb1 = sJb[kk + KI + klane][cb + MB];
+        }
+        __builtin_amdgcn_sched_barrier(0); // keep the fetches above the MFMAs they hide behind
+        c00 = M::mma(a0, b0, c00);
+        c01 = M::mma(a0, b1, c01);
+        if (FULL) {
+            c10 = M::mma(a1, b0, c10);
+            c11 = M::mma(a1, b1, c11);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+}
+
 #ifndef PU_MIN_WAVES
-#define PU_MIN_WAVES 4
+#define PU_MIN_WAVES 3
 #endif
 template <typename T, bool AVG>
 __global__ void __launch_bounds__(256, PU_MIN_WAVES)
-k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int ntiles, const int2 *tilemap)
+k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, const int4 *units)
 {
     using M = Mma<T>;
     constexpr int MB = M::MB, TM = 4 * MB, KI = 64 / MB, VEC = M::VEC;
@@ -74,27 +106,27 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int ntiles, con
     T(*sJ)[PU_BK][TM] = reinterpret_cast<T(*)[PU_BK][TM]>(smem + 2 * PU_BK * TM);
     static_assert(4 * MB * (MB + 1) <= 4 * PU_BK * TM, "transpose scratch must fit");
 
-    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it).  Each
-    // XCD walks a contiguous chunk of a super-tiled (8 x 8 tiles) enumeration of the upper triangle, so the
-    // workgroups resident on one XCD at a time share their B row-slabs through that XCD's L2.
-    const int chunk = (ntiles + 7) >> 3;
-    const int lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (lin >= ntiles) return;
-    const int ti = tilemap[lin].x, tj = tilemap[lin].y;
+    // XCD-aware work order: workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it).  Each
+    // XCD walks its own list: a contiguous chunk of a super-tiled (8 x 8 tiles) enumeration of the upper triangle, so
+    // the workgroups resident on one XCD at a time share their B row-slabs through that XCD's L2, followed by the
+    // HALF units (64 of the 128 tile rows) into which the last tiles are split so that the tail of the launch
+    // spreads over all CUs instead of leaving most of them idle for a whole tile time.
+    const int4 unit = units[(size_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)];
+    if (unit.x < 0) return;
+    const int ti = unit.x, tj = unit.y;
+    const bool full = unit.z < 0;
     const bool diag = (ti == tj);
     const int I0 = ti * TM, J0 = tj * TM;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv >> 1, wc = wv & 1;
+    // row offset of this wavefront inside the tile: full unit 64 rows per wavefront row, half unit 32
+    const int rbase = full ? wr * 2 * MB : unit.z * 2 * MB + wr * MB;
     const int klane = lane / MB, idx = lane % MB;
 
-    typename M::acc_t acc[2][2];
+    typename M::acc_t c00, c01, c10, c11;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < M::NACC; ++r) acc[a][b][r] = (T)0;
+    for (int r = 0; r < M::NACC; ++r) c00[r] = c01[r] = c10[r] = c11[r] = (T)0;
 
     using V = typename M::vec_t;
     static_assert(LOADS == 2 || LOADS == 4, "2 or 4 16-byte pieces per thread and slab");
@@ -130,19 +162,8 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int ntiles, con
                 PU_LOAD(3, off)
             }
         }
-#pragma unroll
-        for (int kk = 0; kk < PU_BK; kk += KI) {
-            T a[2], b[2];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                a[x] = sI[buf][kk + klane][wr * 2 * MB + x * MB + idx];
-                b[x] = sJ[buf][kk + klane][wc * 2 * MB + x * MB + idx];
-            }
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) acc[x][y] = M::mma(a[x], b[y], acc[x][y]);
-        }
+        if (full) pu_slab<T, true, TM>(sI[buf], sJ[buf], klane, rbase + idx, wc * 2 * MB + idx, c00, c01, c10, c11);
+        else pu_slab<T, false, TM>(sI[buf], sJ[buf], klane, rbase + idx, wc * 2 * MB + idx, c00, c01, c10, c11);
         if (more) {
             PU_STORE(0, buf ^ 1)
             PU_STORE(1, buf ^ 1)
@@ -167,7 +188,9 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int ntiles, con
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) {
-            const int bi = I0 + wr * 2 * MB + x * MB, bj = J0 + wc * 2 * MB + y * MB;
+            if (x == 1 && !full) continue;
+            const int bi = I0 + rbase + x * MB, bj = J0 + wc * 2 * MB + y * MB;
+            const typename M::acc_t &cc = x == 0 ? (y == 0 ? c00 : c01) : (y == 0 ? c10 : c11);
             if (AVG) {
 #pragma unroll
                 for (int r = 0; r < M::NACC; ++r) {
@@ -175,7 +198,7 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int ntiles, con
                     if (gi < n && gj < n && gi <= gj) {
                         T *pu = P + (size_t)gi * ldp + gj;
                         T *pl = P + (size_t)gj * ldp + gi;
-                        const T v = ((T)0.5 * (*pu) + (T)0.5 * (*pl)) - acc[x][y][r];
+                        const T v = ((T)0.5 * (*pu) + (T)0.5 * (*pl)) - cc[r];
                         *pu = v;
                         *pl = v;
                     }
@@ -189,7 +212,7 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int ntiles, con
                 T v = (T)0;
                 if (gi < n && gj < n) {
                     T *pu = P + (size_t)gi * ldp + gj;
-                    v = *pu - acc[x][y][r];
+                    v = *pu - cc[r];
                     *pu = v;
                 }
                 if (!diag) sT[li * (MB + 1) + lj] = v;
@@ -210,21 +233,38 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int ntiles, con
         }
 }
 
-// host-built (ti, tj) list: super-tiles of 8 x 8 tiles, row-major inside, upper triangle only
-static void build_tilemap(EkfEngine *e, int nt)
+// host-built work list.  Tiles: super-tiles of 8 x 8 tiles, row-major inside, upper triangle only.  The tail
+// (ntiles mod #CUs tiles, i.e. what would occupy only part of the chip for a whole tile time) is split into half units.
+static void build_units(EkfEngine *e, int nt)
 {
     if (e->pu_tilemap_nt == nt && e->d.pu_tilemap) return;
-    std::vector<int2> map;
-    const int ST = 8;
+    std::vector<int4> tiles;
+    const int ST = 8, NCU = 256, NX = 8;
     for (int si = 0; si < nt; si += ST)
         for (int sj = si; sj < nt; sj += ST)
             for (int i = si; i < si + ST && i < nt; ++i)
-                for (int j = (sj > i ? sj : i); j < sj + ST && j < nt; ++j) map.push_back(make_int2(i, j));
+                for (int j = (sj > i ? sj : i); j < sj + ST && j < nt; ++j) tiles.push_back(make_int4(i, j, -1, 0));
+    const int ntiles = (int)tiles.size();
+    const int n_full = ntiles >= NCU ? (ntiles / NCU) * NCU : 0;
+    std::vector<int4> halves;
+    for (int t = n_full; t < ntiles; ++t) {
+        halves.push_back(make_int4(tiles[t].x, tiles[t].y, 0, 0));
+        halves.push_back(make_int4(tiles[t].x, tiles[t].y, 1, 0));
+    }
+    const int fchunk = (n_full + NX - 1) / NX, hchunk = ((int)halves.size() + NX - 1) / NX;
+    const int per = fchunk + hchunk;
+    std::vector<int4> table((size_t)NX * per, make_int4(-1, -1, -1, 0));
+    for (int x = 0; x < NX; ++x) {
+        for (int k = 0; k < fchunk && x * fchunk + k < n_full; ++k) table[(size_t)x * per + k] = tiles[x * fchunk + k];
+        for (int k = 0; k < hchunk && x * hchunk + k < (int)halves.size(); ++k)
+            table[(size_t)x * per + fchunk + k] = halves[x * hchunk + k];
+    }
     if (e->d.pu_tilemap) (void)hipFree(e->d.pu_tilemap);
-    (void)hipMalloc((void **)&e->d.pu_tilemap, map.size() * sizeof(int2));
-    (void)hipMemcpyAsync(e->d.pu_tilemap, map.data(), map.size() * sizeof(int2), hipMemcpyHostToDevice, e->stream);
+    (void)hipMalloc((void **)&e->d.pu_tilemap, table.size() * sizeof(int4));
+    (void)hipMemcpyAsync(e->d.pu_tilemap, table.data(), table.size() * sizeof(int4), hipMemcpyHostToDevice, e->stream);
     (void)hipStreamSynchronize(e->stream);
     e->pu_tilemap_nt = nt;
+    e->pu_per_xcd = per;
 }
 
 void launch_p_update(EkfEngine *e, int m_pad)
@@ -233,10 +273,10 @@ void launch_p_update(EkfEngine *e, int m_pad)
     const int n = e->n;
     const int TM = e->f32 ? 128 : 64;
     const int nt = (n + TM - 1) / TM;
-    const int ntiles = nt * (nt + 1) / 2;
-    build_tilemap(e, nt);
-    const int grid = ((ntiles + 7) / 8) * 8;
-    const int2 *tm = (const int2 *)e->d.pu_tilemap;
+    build_units(e, nt);
+    const int grid = e->pu_per_xcd * 8;
+    const int ntiles = e->pu_per_xcd;
+    const int4 *tm = (const int4 *)e->d.pu_tilemap;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (e->timing) {
         (void)hipEventCreate(&e0);

@@ -1,0 +1,79 @@
+"""N > 1 plumbing on CPU: world_size-2 gloo process group.  Covers what bench.py --gpus N relies on (rendezvous,
+barrier, max-over-ranks timing, aggregate throughput) and the exchange step of the row-sharded update: each rank
+downdates only its own row block of P with the all-gathered B and the assembled result equals the unsharded
+downdate."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent(
+    """
+    import os, sys, time
+    sys.path.insert(0, %r)
+    import numpy as np
+    from openekfmonoslam_amd import dist, engine
+
+    r = dist.Ranks(backend="gloo")
+    assert r.world == 2
+    # timing contract: barrier, K "steps", barrier, max over ranks
+    r.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.05 * (r.rank + 1))
+    el = time.perf_counter() - t0
+    r.barrier()
+    mx = r.max_over_ranks(el)
+    assert mx >= 0.1 - 1e-3 and mx >= el
+    assert r.sum_over_ranks(1.0) == 2.0
+    # row partition: python helper == C ABI
+    N = 7
+    lo, hi = dist.shard_rows(N, r.world, r.rank)
+    assert (lo, hi) == engine.shard_rows(N, r.world, r.rank)
+    # sharded downdate P <- P - B'B: B rows are produced per rank (here: split by rows of B), all-gathered, and each
+    # rank updates only P[lo:hi, :]
+    rng = np.random.default_rng(5)
+    n, m = 13 + 6 * N, 10
+    A = rng.standard_normal((n, n)); P = A @ A.T
+    B = rng.standard_normal((m, n))
+    mlo, mhi = (0, 6) if r.rank == 0 else (6, m)
+    Bfull = r.all_gather_rows(np.ascontiguousarray(B[mlo:mhi]), m)
+    np.testing.assert_array_equal(Bfull, B)
+    mine = P[lo:hi] - Bfull[:, lo:hi].T @ Bfull
+    blocks = r.all_gather_rows(np.ascontiguousarray(mine), n)
+    np.testing.assert_allclose(blocks, P - B.T @ B, rtol=1e-12, atol=1e-12)
+    r.close()
+    print("rank", r.rank, "ok")
+    """
+)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo_plumbing(tmp_path):
+    from openekfmonoslam_amd import build
+
+    build.build_engine()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {rank} ok" in o
