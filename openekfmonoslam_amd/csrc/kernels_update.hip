@@ -123,11 +123,20 @@ __device__ __forceinline__ bool wave_chol_inv32(double (&a)[NB], double (&x)[NB]
 #pragma unroll
             for (int c = 0; c <= j; ++c) x[c] *= rs;
         }
+        // all broadcasts of the step first (SGPR pairs), then all FMAs: interleaving them costs an SGPR-hazard nop
+        // per pair and doubles the step time
+        double lb[NB], xb[NB];
 #pragma unroll
-        for (int c = j + 1; c < NB; ++c) a[c] -= l * bcast_lane(l, c);
+        for (int c = j + 1; c < NB; ++c) lb[c] = bcast_lane(l, c);
+#pragma unroll
+        for (int c = 0; c <= j; ++c) xb[c] = bcast_lane(x[c], j);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) a[c] -= l * lb[c];
         const double lx = (lane > j) ? l : 0.0;
 #pragma unroll
-        for (int c = 0; c <= j; ++c) x[c] -= lx * bcast_lane(x[c], j);
+        for (int c = 0; c <= j; ++c) x[c] -= lx * xb[c];
+        __builtin_amdgcn_sched_barrier(0);
     }
     return ok;
 }
