@@ -91,6 +91,9 @@ int ekf_set_state(EkfEngine *e, const double x13[13], int n_features, const doub
                   const int32_t *feature_type, const uint8_t *desc32, const double *P);
 /* Any output pointer may be NULL.  P is written as n x n doubles. */
 int ekf_get_state(EkfEngine *e, double x13[13], double *feature_pos, double *P);
+/* Per-feature bookkeeping updateMapFeatures maintains every step (EKF/MapManagement.cpp:77-113): the current map
+ * descriptors (32 bytes each) and MapFeature::timesPredicted / timesMatched.  Any pointer may be NULL. */
+int ekf_get_map_features(EkfEngine *e, uint8_t *desc32, uint32_t *times_predicted, uint32_t *times_matched);
 int ekf_state_dim(const EkfEngine *e);
 int ekf_num_features(const EkfEngine *e);
 
@@ -133,7 +136,8 @@ int ekf_update_only_state(EkfEngine *e, const EkfMatch *matches, int M);
  * against the predictions of the last ekf_predict_measurements call that covered those features. */
 int ekf_rescue(EkfEngine *e, const EkfMatch *outliers, int M, uint8_t *rescued_mask);
 
-/* EKF::step(image) with a fixed map                      EKF/EKF.h:57 (.cpp:242-556), fed the frame's keypoints. */
+/* EKF::step(image) with a fixed map                      EKF/EKF.h:57 (.cpp:242-572, including updateMapFeatures),
+ * fed the frame's keypoints. */
 int ekf_step(EkfEngine *e, const EkfKeypoint *kps, const uint8_t *desc32, int n_kp, EkfStepInfo *info);
 
 /* -- pre-staged sequences (inputs resident in HBM before a timed region) ---------------------------------- */

@@ -63,7 +63,7 @@ void ekf_engine_destroy(EkfEngine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     DeviceArrays &d = e->d;
-    void *ptrs[] = {d.state,     d.feat_pos,  d.feat_type, d.feat_covpos, d.feat_desc, d.P,        d.pred_vis,
+    void *ptrs[] = {d.state,     d.feat_pos,  d.feat_type, d.feat_covpos, d.feat_desc, d.feat_times_predicted, d.feat_times_matched, d.P,        d.pred_vis,
                     d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,       d.HPc,      d.Ac,
                     d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
@@ -126,6 +126,8 @@ int ekf_engine_create(const EkfEngineConfig *cfg, EkfEngine **out)
     ALLOC(d.feat_type, cap);
     ALLOC(d.feat_covpos, cap);
     ALLOC(d.feat_desc, EKF_DESC_BYTES * cap);
+    ALLOC(d.feat_times_predicted, cap);
+    ALLOC(d.feat_times_matched, cap);
     {
         uint8_t *raw = nullptr;
         if ((st = dalloc(&raw, (size_t)round_up(e->ncap, LD_ALIGN) * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc P");
@@ -177,6 +179,19 @@ int ekf_engine_create(const EkfEngineConfig *cfg, EkfEngine **out)
         if ((st = hipEventCreate(&ev)) != hipSuccess) return fail(st, "hipEventCreate");
     e->h_counts.assign(CNT_COUNT, 0);
     *out = e;
+    return EKF_OK;
+}
+
+int ekf_get_map_features(EkfEngine *e, uint8_t *desc32, uint32_t *times_predicted, uint32_t *times_matched)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t N = (size_t)e->N;
+    if (N == 0) return EKF_OK;
+    if (desc32) HIPCHK(hipMemcpy(desc32, e->d.feat_desc, N * EKF_DESC_BYTES, hipMemcpyDeviceToHost));
+    if (times_predicted) HIPCHK(hipMemcpy(times_predicted, e->d.feat_times_predicted, N * 4, hipMemcpyDeviceToHost));
+    if (times_matched) HIPCHK(hipMemcpy(times_matched, e->d.feat_times_matched, N * 4, hipMemcpyDeviceToHost));
     return EKF_OK;
 }
 
@@ -242,6 +257,8 @@ int ekf_set_state(EkfEngine *e, const double x13[13], int n_features, const doub
         e->p_exact_sym = false;
     }
     HIPCHK(hipMemset(e->d.pred_vis, 0, (size_t)e->cap * sizeof(int)));
+    HIPCHK(hipMemset(e->d.feat_times_predicted, 0, (size_t)e->cap * sizeof(unsigned)));
+    HIPCHK(hipMemset(e->d.feat_times_matched, 0, (size_t)e->cap * sizeof(unsigned)));
     e->N = n_features;
     e->n = n;
     e->n_pred = 0;
@@ -581,6 +598,7 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
     int np = 0;
     if ((rc = predict_measurements_dev(e, nullptr, e->N, &np))) return rc;
     li.n_predicted = np;
+    launch_count_predicted(e, np); // updateMapFeatures, EKF.cpp:572 / MapManagement.cpp:81-86
     tm.mark();
     // 4. matching (:337)
     int M = 0;
@@ -595,6 +613,7 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
         ni = e->h_counts[CNT_RS_BEST];
         no = M - ni;
         launch_partition(e, e->d.matches, M, e->d.best_flags, e->d.msel, e->d.mout, nullptr);
+        launch_map_update(e, e->d.msel, ni, d_desc); // MapManagement.cpp:88-113 for the low-innovation inliers
     }
     li.n_inliers = ni;
     li.n_outliers = no;
@@ -617,6 +636,7 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
             launch_partition(e, e->d.mout, no, e->d.mask, e->d.msel, nullptr, e->d.counts + CNT_NRESC);
             if ((rc = read_counts(e))) return rc;
             nr = e->h_counts[CNT_NRESC];
+            launch_map_update(e, e->d.msel, nr, d_desc); // rescued matches join the inliers (EKF.cpp:552-556)
         }
     }
     li.n_rescued = nr;

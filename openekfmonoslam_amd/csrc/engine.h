@@ -44,6 +44,8 @@ struct DeviceArrays {
     int *feat_type = nullptr;
     int *feat_covpos = nullptr;
     uint8_t *feat_desc = nullptr;
+    unsigned *feat_times_predicted = nullptr; // MapFeature::timesPredicted / timesMatched (EKF/MapFeature.h:72-73)
+    unsigned *feat_times_matched = nullptr;
     void *P = nullptr; // T [ncap x ldP]
     // prediction tables, keyed by feature index
     int *pred_vis = nullptr;
@@ -146,5 +148,7 @@ void launch_ransac_init(EkfEngine *e, int M);
 void launch_update(EkfEngine *e, int M, bool update_cov);
 void launch_rescue(EkfEngine *e, int M);
 void launch_state_only_predict(EkfEngine *e, EkfPrediction *d_out); // predictMeasurementState on current state
+void launch_count_predicted(EkfEngine *e, int n_pred);
+void launch_map_update(EkfEngine *e, const EkfMatch *d_sel, int count, const uint8_t *d_kdesc);
 
 } // namespace ekf

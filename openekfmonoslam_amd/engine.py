@@ -58,6 +58,7 @@ ABI = {
     "ekf_device_count": (_i, []),
     "ekf_set_state": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "ekf_get_state": (_i, [_vp, _vp, _vp, _vp]),
+    "ekf_get_map_features": (_i, [_vp, _vp, _vp, _vp]),
     "ekf_state_dim": (_i, [_vp]),
     "ekf_num_features": (_i, [_vp]),
     "ekf_predict": (_i, [_vp]),
@@ -176,6 +177,15 @@ class EkfEngine:
         P = np.zeros((self.n, self.n)) if want_P else None
         self._chk(self.L.ekf_get_state(self.h, _p(x), _p(fp), _p(P)))
         return x, fp[: self.N], P
+
+    def get_map_features(self):
+        """(descriptors [N,32] u8, timesPredicted [N] u32, timesMatched [N] u32)."""
+        N = max(self.N, 1)
+        d = np.zeros((N, DESC_BYTES), dtype=np.uint8)
+        tp = np.zeros(N, dtype=np.uint32)
+        tm = np.zeros(N, dtype=np.uint32)
+        self._chk(self.L.ekf_get_map_features(self.h, _p(d), _p(tp), _p(tm)))
+        return d[: self.N], tp[: self.N], tm[: self.N]
 
     # ---- stages
     def predict(self):

@@ -34,6 +34,8 @@ struct OrcFilter {
     int32_t *ftype;
     int32_t *fcovpos;
     uint8_t *fdesc;
+    uint32_t *ftimes_predicted;
+    uint32_t *ftimes_matched;
     double *P;     /* n x n, leading dimension n */
     size_t Pcap;   /* allocated doubles */
 };
@@ -214,6 +216,8 @@ OrcFilter *orc_create(const EkfCamera *cam, const EkfParams *par, int max_featur
     f->ftype = (int32_t *)calloc((size_t)max_features + 1, sizeof(int32_t));
     f->fcovpos = (int32_t *)calloc((size_t)max_features + 1, sizeof(int32_t));
     f->fdesc = (uint8_t *)calloc((size_t)max_features * EKF_DESC_BYTES + EKF_DESC_BYTES, 1);
+    f->ftimes_predicted = (uint32_t *)calloc((size_t)max_features + 1, sizeof(uint32_t));
+    f->ftimes_matched = (uint32_t *)calloc((size_t)max_features + 1, sizeof(uint32_t));
     size_t nmax = 13 + (size_t)6 * max_features;
     f->Pcap = nmax * nmax;
     f->P = (double *)calloc(f->Pcap, sizeof(double));
@@ -226,6 +230,7 @@ void orc_destroy(OrcFilter *f)
 {
     if (!f) return;
     free(f->fpos); free(f->ftype); free(f->fcovpos); free(f->fdesc); free(f->P);
+    free(f->ftimes_predicted); free(f->ftimes_matched);
     free(f);
 }
 
@@ -256,6 +261,8 @@ double *orc_feature_pos(OrcFilter *f) { return f->fpos; }
 int32_t *orc_feature_type(OrcFilter *f) { return f->ftype; }
 int32_t *orc_feature_covpos(OrcFilter *f) { return f->fcovpos; }
 uint8_t *orc_feature_desc(OrcFilter *f) { return f->fdesc; }
+uint32_t *orc_feature_times_predicted(OrcFilter *f) { return f->ftimes_predicted; }
+uint32_t *orc_feature_times_matched(OrcFilter *f) { return f->ftimes_matched; }
 double *orc_P(OrcFilter *f) { return f->P; }
 
 int orc_set_state(OrcFilter *f, const double x13[13], int n_features, const double *feature_pos,
@@ -275,6 +282,8 @@ int orc_set_state(OrcFilter *f, const double x13[13], int n_features, const doub
     }
     if (desc32) memcpy(f->fdesc, desc32, (size_t)n_features * EKF_DESC_BYTES);
     else memset(f->fdesc, 0, (size_t)n_features * EKF_DESC_BYTES);
+    memset(f->ftimes_predicted, 0, (size_t)n_features * sizeof(uint32_t));
+    memset(f->ftimes_matched, 0, (size_t)n_features * sizeof(uint32_t));
     f->N = n_features;
     f->n = pos;
     if (P) memcpy(f->P, P, (size_t)pos * pos * sizeof(double));
@@ -1357,6 +1366,8 @@ int orc_step(OrcFilter *f, const EkfKeypoint *kps, const uint8_t *desc32, int n_
     orc_predict(f, NULL, NULL);                                              /* :273 */
     int np = orc_predict_measurements(f, NULL, 0, preds, Hs, Hf, NULL);      /* :278 */
     li.n_predicted = np;
+    /* updateMapFeatures, first loop (EKF/MapManagement.cpp:81-86): every predicted feature counts */
+    for (int k = 0; k < np; ++k) f->ftimes_predicted[preds[k].featureIndex]++;
     int M = orc_match(f, preds, np, kps, desc32, n_kp, matches);             /* :337 */
     li.n_matches = M;
     /* predictions/Jacobians re-ordered to match order :368-392 */
@@ -1388,6 +1399,14 @@ int orc_step(OrcFilter *f, const EkfKeypoint *kps, const uint8_t *desc32, int n_
     }
     li.n_inliers = ni;
     li.n_outliers = no;
+    /* updateMapFeatures for the low-innovation inliers (EKF.cpp:572, MapManagement.cpp:88-113): matched counter and
+     * the map descriptor replaced by the matched keypoint's; it runs after both updates in the reference, which is
+     * equivalent because nothing in between reads descriptors or counters */
+    for (int i = 0; i < ni; ++i) {
+        int fi = sel[i].featureIndex;
+        f->ftimes_matched[fi]++;
+        memcpy(&f->fdesc[(size_t)fi * EKF_DESC_BYTES], &desc32[(size_t)sel[i].keypointIndex * EKF_DESC_BYTES], EKF_DESC_BYTES);
+    }
     int st = orc_update(f, sel, preds, Hs, Hf, ni, variant);                 /* :430 */
     if (st != EKF_OK) status = st;
     /* re-predict the outliers with the updated state and covariance :473 */
@@ -1415,6 +1434,11 @@ int orc_step(OrcFilter *f, const EkfKeypoint *kps, const uint8_t *desc32, int n_
             }
     }
     li.n_rescued = nr;
+    for (int i = 0; i < nr; ++i) { /* rescued matches join the inliers (EKF.cpp:552-556) */
+        int fi = sel[i].featureIndex;
+        f->ftimes_matched[fi]++;
+        memcpy(&f->fdesc[(size_t)fi * EKF_DESC_BYTES], &desc32[(size_t)sel[i].keypointIndex * EKF_DESC_BYTES], EKF_DESC_BYTES);
+    }
     if (nr > 0) {                                                            /* :529-532 */
         st = orc_update(f, sel, preds, Hs, Hf, nr, variant);
         if (st != EKF_OK) status = st;

@@ -65,6 +65,8 @@ double *orc_feature_pos(OrcFilter *f);    /* 6 per feature */
 int32_t *orc_feature_type(OrcFilter *f);
 int32_t *orc_feature_covpos(OrcFilter *f);
 uint8_t *orc_feature_desc(OrcFilter *f);
+uint32_t *orc_feature_times_predicted(OrcFilter *f); /* MapFeature::timesPredicted */
+uint32_t *orc_feature_times_matched(OrcFilter *f);   /* MapFeature::timesMatched   */
 double *orc_P(OrcFilter *f); /* n x n row-major, leading dimension n */
 
 /* stateAndCovariancePrediction: EKF/StateAndCovariancePrediction.cpp:244-253.  If F13/GQG13 are non-NULL
@@ -108,7 +110,9 @@ int orc_update(OrcFilter *f, const EkfMatch *matches, const EkfPrediction *preds
 int orc_rescue(const OrcFilter *f, const EkfMatch *matches, const EkfPrediction *preds, int M,
                uint8_t *rescued_mask);
 
-/* One EKF::step (EKF/EKF.cpp:242-556) with a fixed map, fed the keypoints/descriptors of the frame. */
+/* One EKF::step (EKF/EKF.cpp:242-572) with a fixed map, fed the keypoints/descriptors of the frame; includes
+ * updateMapFeatures (EKF/MapManagement.cpp:77-113: prediction/match counters, descriptor refresh of matched
+ * features), which the reference runs every step. */
 int orc_step(OrcFilter *f, const EkfKeypoint *kps, const uint8_t *desc32, int n_kp, int variant,
              OrcStepInfo *info);
 

@@ -37,7 +37,9 @@ def lib():
         L.orc_num_features.argtypes = [vp]
         for name, rt in [("orc_x13", dp), ("orc_rotation", dp), ("orc_feature_pos", dp), ("orc_P", dp),
                          ("orc_feature_type", C.POINTER(C.c_int32)), ("orc_feature_covpos", C.POINTER(C.c_int32)),
-                         ("orc_feature_desc", C.POINTER(C.c_uint8))]:
+                         ("orc_feature_desc", C.POINTER(C.c_uint8)),
+                         ("orc_feature_times_predicted", C.POINTER(C.c_uint32)),
+                         ("orc_feature_times_matched", C.POINTER(C.c_uint32))]:
             getattr(L, name).restype = rt
             getattr(L, name).argtypes = [vp]
         L.orc_predict.argtypes = [vp, vp, vp]
@@ -96,6 +98,13 @@ class Oracle:
 
     def feature_pos(self):
         return np.ctypeslib.as_array(self.L.orc_feature_pos(self.h), (self.N * 6,)).copy().reshape(-1, 6)
+
+    def map_features(self):
+        N = self.N
+        d = np.ctypeslib.as_array(self.L.orc_feature_desc(self.h), (N * DESC_BYTES,)).copy().reshape(N, DESC_BYTES)
+        tp = np.ctypeslib.as_array(self.L.orc_feature_times_predicted(self.h), (N,)).copy()
+        tm = np.ctypeslib.as_array(self.L.orc_feature_times_matched(self.h), (N,)).copy()
+        return d, tp, tm
 
     def feature_covpos(self):
         return np.ctypeslib.as_array(self.L.orc_feature_covpos(self.h), (self.N,)).copy()

@@ -301,6 +301,13 @@ def test_full_step_sequence_fp64(eng_mod, oracle_lib, nfeat, frames):
         for f in ("n_predicted", "n_matches", "n_hypotheses", "n_inliers", "n_outliers", "n_rescued", "status"):
             assert getattr(ie, f) == getattr(io, f), (t, f, getattr(ie, f), getattr(io, f))
         assert_state_close(e, o, 1e-8, f"step {t}")
+    # updateMapFeatures (EKF.cpp:572): refreshed descriptors and counters identical
+    de, tpe, tme = e.get_map_features()
+    do, tpo, tmo = o.map_features()
+    np.testing.assert_array_equal(de, do)
+    np.testing.assert_array_equal(tpe, tpo)
+    np.testing.assert_array_equal(tme, tmo)
+    assert tmo.sum() > 0 and (do != seq.feature_desc).any()
 
 
 def test_staged_frames_equal_host_frames(eng_mod, seq12):
