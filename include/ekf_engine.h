@@ -97,6 +97,23 @@ int ekf_get_map_features(EkfEngine *e, uint8_t *desc32, uint32_t *times_predicte
 int ekf_state_dim(const EkfEngine *e);
 int ekf_num_features(const EkfEngine *e);
 
+/* -- map management: the state dimension changes, P is edited in place on the device ------ */
+/* initState + initCovariance                              EKF/CommonFunctions.cpp:39-80 (empties the map) */
+int ekf_reset(EkfEngine *e);
+/* addFeaturesToStateAndCovariance(measurements, state, P) EKF/AddMapFeature.h (.cpp:354; per feature :293-344,
+ * covariance :221-289): uv = distorted pixel of each new feature (2 doubles each), desc32 = its descriptor. */
+int ekf_add_features(EkfEngine *e, const double *uv, const uint8_t *desc32, int count);
+/* removeFeaturesFromStateAndCovariance(featuresToRemove, state, P)  EKF/MapManagement.cpp:212-259;
+ * ascending feature indices (map order, as the reference requires sorted ranges). */
+int ekf_remove_features(EkfEngine *e, const int32_t *feat_idx, int count);
+/* removeBadMapFeatures(state, P)                          EKF/MapManagement.cpp:279-308 */
+int ekf_remove_bad_features(EkfEngine *e, int *n_removed);
+/* convertMapFeaturesInverseDepthToDepth(state, P)         EKF/MapManagement.cpp:494-521 (at most one per call;
+ * converted_index receives the feature index or -1) */
+int ekf_convert_inverse_depth_to_depth(EkfEngine *e, int *converted_index);
+/* MapFeature::featureType / covarianceMatrixPos of every feature (EKF/MapFeature.h:60-68) */
+int ekf_get_feature_layout(EkfEngine *e, int32_t *type, int32_t *covpos);
+
 /* -- stages ---------------------------------------------------------------------------------------------- */
 /* stateAndCovariancePrediction(State&, Matd&)            EKF/StateAndCovariancePrediction.h:41 (.cpp:244-253) */
 int ekf_predict(EkfEngine *e);

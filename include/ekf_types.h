@@ -31,8 +31,8 @@ typedef struct EkfCamera {
 /* Filter parameters consumed on the hot path.
  * Mirrors class ExtendedKalmanFilterParameters,
  * Cfg/ExtendedKalmanFilterConfiguration/ExtendedKalmanFilterParameters.h:37-76
- * (only the fields read by stages A1..A9 of SURVEY.md section 8(a), plus the three used when a
- * feature is appended to the map). */
+ * (only the fields read by stages A1..A9 of SURVEY.md section 8(a), plus those the map-management row
+ * 8(f)-1 reads: new-feature initialisation, bad-feature removal, inverse-depth -> depth conversion). */
 typedef struct EkfParams {
     double initInvDepthRho;
     double initLinearAccelSD;
@@ -44,6 +44,8 @@ typedef struct EkfParams {
     double ransacThresholdPredictDistance;
     double ransacAllInliersProbability;
     double ransacChi2Threshold;
+    double goodFeatureMatchingPercent;          /* removeBadMapFeatures, EKF/MapManagement.cpp:279-308        */
+    double inverseDepthLinearityIndexThreshold; /* convertMapFeaturesInverseDepthToDepth, MapManagement.cpp:494 */
 } EkfParams;
 
 /* Map feature parametrisation, enum MapFeatureType EKF/MapFeature.h:39-44 (same numeric values). */

@@ -63,7 +63,7 @@ void ekf_engine_destroy(EkfEngine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     DeviceArrays &d = e->d;
-    void *ptrs[] = {d.state,     d.feat_pos,  d.feat_type, d.feat_covpos, d.feat_desc, d.feat_times_predicted, d.feat_times_matched, d.P,        d.pred_vis,
+    void *ptrs[] = {d.state,     d.feat_pos,  d.feat_type, d.feat_covpos, d.feat_desc, d.feat_times_predicted, d.feat_times_matched, d.P, d.P2, d.mm_scratch, d.mm_index,        d.pred_vis,
                     d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,       d.HPc,      d.Ac,
                     d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
@@ -137,6 +137,8 @@ int ekf_engine_create(const EkfEngineConfig *cfg, EkfEngine **out)
         if ((st = dalloc(&raw, (size_t)mcap * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc A");
         d.A = raw;
     }
+    ALLOC(d.mm_scratch, (size_t)60 * cap + 4 * (size_t)e->ldP + 64);
+    ALLOC(d.mm_index, (size_t)e->ncap + 8);
     ALLOC(d.pred_vis, cap);
     ALLOC(d.pred_uv, 2 * cap);
     ALLOC(d.pred_vis2, cap);
@@ -262,6 +264,8 @@ int ekf_set_state(EkfEngine *e, const double x13[13], int n_features, const doub
     e->N = n_features;
     e->n = n;
     e->n_pred = 0;
+    e->h_type = type;
+    e->h_covpos = covpos;
     return EKF_OK;
 }
 
@@ -285,6 +289,181 @@ int ekf_get_state(EkfEngine *e, double x13[13], double *feature_pos, double *P)
         }
     }
     return EKF_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------ map management
+static int check_async(EkfEngine *e);
+static int dims_of(int type) { return type == EKF_FEATURE_INVERSE_DEPTH ? 6 : 3; }
+
+int ekf_reset(EkfEngine *e)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    // initState + initCovariance, EKF/CommonFunctions.cpp:39-80
+    double x[13] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, EKF_EPSILON, EKF_EPSILON, EKF_EPSILON};
+    double P[169];
+    std::memset(P, 0, sizeof(P));
+    for (int i = 0; i < 7; ++i) P[i * 13 + i] = EKF_EPSILON;
+    for (int i = 0; i < 3; ++i) {
+        P[(i + 7) * 13 + i + 7] = e->cfg.par.initLinearAccelSD * e->cfg.par.initLinearAccelSD;
+        P[(i + 10) * 13 + i + 10] = e->cfg.par.initAngularAccelSD * e->cfg.par.initAngularAccelSD;
+    }
+    return ekf_set_state(e, x, 0, nullptr, nullptr, nullptr, P);
+}
+
+int ekf_get_feature_layout(EkfEngine *e, int32_t *type, int32_t *covpos)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    for (int i = 0; i < e->N; ++i) {
+        if (type) type[i] = e->h_type[i];
+        if (covpos) covpos[i] = e->h_covpos[i];
+    }
+    return EKF_OK;
+}
+
+int ekf_add_features(EkfEngine *e, const double *uv, const uint8_t *desc32, int count)
+{
+    if (!e || count < 0 || (count > 0 && !uv)) return EKF_ERR_INVALID_ARG;
+    if (count == 0) return EKF_OK;
+    if (e->N + count > e->cap) return EKF_ERR_CAPACITY;
+    HIPCHK(hipSetDevice(e->device));
+    double *d_uv = e->d.mm_scratch, *d_Jpo = d_uv + 2 * (size_t)e->cap, *d_Jhr = d_Jpo + 42 * (size_t)count;
+    HIPCHK(hipMemcpyAsync(d_uv, uv, (size_t)2 * count * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    uint8_t *dd = e->d.feat_desc + (size_t)e->N * EKF_DESC_BYTES;
+    if (desc32) HIPCHK(hipMemcpyAsync(dd, desc32, (size_t)count * EKF_DESC_BYTES, hipMemcpyHostToDevice, e->stream));
+    else HIPCHK(hipMemsetAsync(dd, 0, (size_t)count * EKF_DESC_BYTES, e->stream));
+    HIPCHK(hipMemsetAsync(e->d.feat_times_predicted + e->N, 0, (size_t)count * 4, e->stream));
+    HIPCHK(hipMemsetAsync(e->d.feat_times_matched + e->N, 0, (size_t)count * 4, e->stream));
+    launch_add_features(e, d_uv, count, d_Jpo, d_Jhr);
+    for (int j = 0; j < count; ++j) {
+        e->h_type.push_back(EKF_FEATURE_INVERSE_DEPTH);
+        e->h_covpos.push_back(e->n + 6 * j);
+    }
+    e->N += count;
+    e->n += 6 * count;
+    e->n_pred = 0;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return check_async(e);
+}
+
+// drop the listed rows (sorted row flags) from P and the listed features from the SoA arrays
+static int compact_map(EkfEngine *e, const std::vector<uint8_t> &drop_feature, const std::vector<uint8_t> &drop_row)
+{
+    const int N = e->N, n = e->n;
+    std::vector<int> new2old;
+    for (int i = 0; i < n; ++i)
+        if (!drop_row[i]) new2old.push_back(i);
+    const int n_new = (int)new2old.size();
+    if (!e->d.P2) {
+        const size_t bytes = (size_t)round_up(e->ncap, LD_ALIGN) * e->ldP * (e->f32 ? 4 : 8);
+        HIPCHK(hipMalloc(&e->d.P2, bytes));
+        HIPCHK(hipMemset(e->d.P2, 0, bytes));
+    }
+    HIPCHK(hipMemcpyAsync(e->d.mm_index, new2old.data(), (size_t)n_new * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    launch_compact_P(e, n_new, e->d.mm_index);
+    // SoA arrays: small, compacted through the host
+    std::vector<double> pos(6 * (size_t)N);
+    std::vector<uint8_t> desc((size_t)N * EKF_DESC_BYTES);
+    std::vector<unsigned> tp(N), tm(N);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(pos.data(), e->d.feat_pos, pos.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(desc.data(), e->d.feat_desc, desc.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tp.data(), e->d.feat_times_predicted, (size_t)N * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tm.data(), e->d.feat_times_matched, (size_t)N * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(e->h_type.data(), e->d.feat_type, (size_t)N * 4, hipMemcpyDeviceToHost)); // conversions change types
+    int w = 0, p = 13;
+    for (int i = 0; i < N; ++i) {
+        if (drop_feature[i]) continue;
+        std::memmove(&pos[6 * (size_t)w], &pos[6 * (size_t)i], 6 * sizeof(double));
+        std::memmove(&desc[(size_t)w * EKF_DESC_BYTES], &desc[(size_t)i * EKF_DESC_BYTES], EKF_DESC_BYTES);
+        tp[w] = tp[i];
+        tm[w] = tm[i];
+        e->h_type[w] = e->h_type[i];
+        e->h_covpos[w] = p;
+        p += dims_of(e->h_type[w]);
+        ++w;
+    }
+    e->h_type.resize(w);
+    e->h_covpos.resize(w);
+    if (p != n_new) {
+        e->err = "map compaction: layout mismatch";
+        return EKF_ERR_INVALID_ARG;
+    }
+    if (w > 0) {
+        HIPCHK(hipMemcpy(e->d.feat_pos, pos.data(), (size_t)6 * w * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d.feat_desc, desc.data(), (size_t)w * EKF_DESC_BYTES, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d.feat_times_predicted, tp.data(), (size_t)w * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d.feat_times_matched, tm.data(), (size_t)w * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d.feat_type, e->h_type.data(), (size_t)w * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d.feat_covpos, e->h_covpos.data(), (size_t)w * 4, hipMemcpyHostToDevice));
+    }
+    e->N = w;
+    e->n = n_new;
+    e->n_pred = 0;
+    return check_async(e);
+}
+
+int ekf_remove_features(EkfEngine *e, const int32_t *feat_idx, int count)
+{
+    if (!e || count < 0 || (count > 0 && !feat_idx)) return EKF_ERR_INVALID_ARG;
+    if (count == 0) return EKF_OK;
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<uint8_t> df(e->N, 0), dr(e->n, 0);
+    for (int i = 0; i < count; ++i) {
+        const int f = feat_idx[i];
+        if (f < 0 || f >= e->N || (i > 0 && feat_idx[i] <= feat_idx[i - 1])) return EKF_ERR_INVALID_ARG;
+        df[f] = 1;
+        for (int k = 0; k < dims_of(e->h_type[f]); ++k) dr[e->h_covpos[f] + k] = 1;
+    }
+    return compact_map(e, df, dr);
+}
+
+int ekf_remove_bad_features(EkfEngine *e, int *n_removed)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const int N = e->N;
+    std::vector<unsigned> tp(N), tm(N);
+    if (N > 0) {
+        HIPCHK(hipMemcpy(tp.data(), e->d.feat_times_predicted, (size_t)N * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tm.data(), e->d.feat_times_matched, (size_t)N * 4, hipMemcpyDeviceToHost));
+    }
+    std::vector<int32_t> idx;
+    for (int i = 0; i < N; ++i) { // EKF/MapManagement.cpp:291-302 (float ratio, 0/0 = NaN keeps the feature)
+        const float pct = static_cast<float>(tm[i]) / static_cast<float>(tp[i]);
+        if (pct < e->cfg.par.goodFeatureMatchingPercent) idx.push_back(i);
+    }
+    if (n_removed) *n_removed = (int)idx.size();
+    return ekf_remove_features(e, idx.data(), (int)idx.size());
+}
+
+int ekf_convert_inverse_depth_to_depth(EkfEngine *e, int *converted_index)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    if (converted_index) *converted_index = -1;
+    if (e->N == 0) return EKF_OK;
+    HIPCHK(hipSetDevice(e->device));
+    double *d_li = e->d.mm_scratch;
+    launch_linearity(e, d_li);
+    std::vector<double> li(e->N);
+    HIPCHK(hipMemcpyAsync(li.data(), d_li, (size_t)e->N * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int fi = -1;
+    for (int i = 0; i < e->N; ++i) // first inverse-depth feature in map order below the threshold, one per call (:494-521)
+        if (e->h_type[i] == EKF_FEATURE_INVERSE_DEPTH && li[i] < e->cfg.par.inverseDepthLinearityIndexThreshold) {
+            fi = i;
+            break;
+        }
+    if (fi < 0) return EKF_OK;
+    const int pos = e->h_covpos[fi];
+    double *d_J = e->d.mm_scratch + e->cap, *d_T3 = d_J + 32;
+    launch_convert(e, fi, pos, d_J, d_T3);
+    e->h_type[fi] = EKF_FEATURE_DEPTH;
+    std::vector<uint8_t> df(e->N, 0), dr(e->n, 0);
+    dr[pos + 3] = dr[pos + 4] = dr[pos + 5] = 1;
+    if (converted_index) *converted_index = fi;
+    return compact_map(e, df, dr);
 }
 
 // ----------------------------------------------------------------------------------------------- utilities

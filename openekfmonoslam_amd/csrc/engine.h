@@ -47,6 +47,9 @@ struct DeviceArrays {
     unsigned *feat_times_predicted = nullptr; // MapFeature::timesPredicted / timesMatched (EKF/MapFeature.h:72-73)
     unsigned *feat_times_matched = nullptr;
     void *P = nullptr; // T [ncap x ldP]
+    void *P2 = nullptr; // second buffer of the same size, allocated on the first removal (compaction target)
+    double *mm_scratch = nullptr; // map management scratch: Jpo/Jhr of a batch, 3 x ldP conversion rows, N linearity values
+    int *mm_index = nullptr;      // new2old row map (ncap ints)
     // prediction tables, keyed by feature index
     int *pred_vis = nullptr;
     double *pred_uv = nullptr; // 2 per feature
@@ -132,6 +135,7 @@ struct EkfEngine {
     std::vector<std::pair<int, float>> pu_log;                 // harvested (m, ms) per launch
     // host scratch
     std::vector<int> h_counts;
+    std::vector<int> h_type, h_covpos; // host mirror of the map layout (type, covariance position per feature)
 };
 
 namespace ekf {
@@ -149,6 +153,10 @@ void launch_update(EkfEngine *e, int M, bool update_cov);
 void launch_rescue(EkfEngine *e, int M);
 void launch_state_only_predict(EkfEngine *e, EkfPrediction *d_out); // predictMeasurementState on current state
 void launch_count_predicted(EkfEngine *e, int n_pred);
+void launch_add_features(EkfEngine *e, const double *d_uv, int count, double *d_Jpo, double *d_Jhr);
+void launch_compact_P(EkfEngine *e, int n_new, const int *d_new2old);
+void launch_linearity(EkfEngine *e, double *d_out);
+void launch_convert(EkfEngine *e, int fi, int pos, double *d_J, double *d_T3);
 void launch_map_update(EkfEngine *e, const EkfMatch *d_sel, int count, const uint8_t *d_kdesc);
 
 } // namespace ekf

@@ -39,6 +39,8 @@ class EkfParams(C.Structure):
         ("ransacThresholdPredictDistance", C.c_double),
         ("ransacAllInliersProbability", C.c_double),
         ("ransacChi2Threshold", C.c_double),
+        ("goodFeatureMatchingPercent", C.c_double),
+        ("inverseDepthLinearityIndexThreshold", C.c_double),
     ]
 
 
@@ -118,4 +120,6 @@ def s3_params():
     p.ransacThresholdPredictDistance = 1.0
     p.ransacAllInliersProbability = 0.99
     p.ransacChi2Threshold = 5.9915
+    p.goodFeatureMatchingPercent = 0.5
+    p.inverseDepthLinearityIndexThreshold = 0.1
     return p

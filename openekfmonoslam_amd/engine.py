@@ -59,6 +59,12 @@ ABI = {
     "ekf_set_state": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "ekf_get_state": (_i, [_vp, _vp, _vp, _vp]),
     "ekf_get_map_features": (_i, [_vp, _vp, _vp, _vp]),
+    "ekf_reset": (_i, [_vp]),
+    "ekf_add_features": (_i, [_vp, _vp, _vp, _i]),
+    "ekf_remove_features": (_i, [_vp, _vp, _i]),
+    "ekf_remove_bad_features": (_i, [_vp, C.POINTER(_i)]),
+    "ekf_convert_inverse_depth_to_depth": (_i, [_vp, C.POINTER(_i)]),
+    "ekf_get_feature_layout": (_i, [_vp, _vp, _vp]),
     "ekf_state_dim": (_i, [_vp]),
     "ekf_num_features": (_i, [_vp]),
     "ekf_predict": (_i, [_vp]),
@@ -177,6 +183,35 @@ class EkfEngine:
         P = np.zeros((self.n, self.n)) if want_P else None
         self._chk(self.L.ekf_get_state(self.h, _p(x), _p(fp), _p(P)))
         return x, fp[: self.N], P
+
+    # ---- map management
+    def reset(self):
+        self._chk(self.L.ekf_reset(self.h))
+
+    def add_features(self, uv, desc=None):
+        uv = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
+        d = None if desc is None else np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, DESC_BYTES)
+        self._chk(self.L.ekf_add_features(self.h, _p(uv), _p(d), len(uv)))
+
+    def remove_features(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        self._chk(self.L.ekf_remove_features(self.h, _p(idx), len(idx)))
+
+    def remove_bad_features(self):
+        k = _i(0)
+        self._chk(self.L.ekf_remove_bad_features(self.h, C.byref(k)))
+        return k.value
+
+    def convert_inverse_depth_to_depth(self):
+        k = _i(-1)
+        self._chk(self.L.ekf_convert_inverse_depth_to_depth(self.h, C.byref(k)))
+        return k.value
+
+    def feature_layout(self):
+        t = np.zeros(max(self.N, 1), dtype=np.int32)
+        c = np.zeros(max(self.N, 1), dtype=np.int32)
+        self._chk(self.L.ekf_get_feature_layout(self.h, _p(t), _p(c)))
+        return t[: self.N], c[: self.N]
 
     def get_map_features(self):
         """(descriptors [N,32] u8, timesPredicted [N] u32, timesMatched [N] u32)."""

@@ -455,6 +455,156 @@ int orc_add_feature(OrcFilter *f, const double uv[2], const uint8_t *desc32)
     return idx;
 }
 
+
+/* --------------------------------------------------------------------------------------- map management */
+
+/* removeFeaturesFromStateAndCovariance: EKF/MapManagement.cpp:212-259 (+ removeRowsAndColumnsFromMat :168-208).
+ * idx: ascending feature indices.  P is compacted in place (row-major, moving up/left only). */
+int orc_remove_features(OrcFilter *f, const int32_t *idx, int count)
+{
+    if (count <= 0) return EKF_OK;
+    int n = f->n, N = f->N;
+    uint8_t *drop = (uint8_t *)calloc((size_t)n, 1);
+    uint8_t *dropf = (uint8_t *)calloc((size_t)N, 1);
+    for (int i = 0; i < count; ++i) {
+        int fi = idx[i];
+        if (fi < 0 || fi >= N || (i > 0 && idx[i] <= idx[i - 1])) { free(drop); free(dropf); return EKF_ERR_INVALID_ARG; }
+        dropf[fi] = 1;
+        for (int k = 0; k < feat_dim(f->ftype[fi]); ++k) drop[f->fcovpos[fi] + k] = 1;
+    }
+    int *keep = (int *)malloc((size_t)n * sizeof(int));
+    int nn = 0;
+    for (int i = 0; i < n; ++i)
+        if (!drop[i]) keep[nn++] = i;
+    for (int i = 0; i < nn; ++i)
+        for (int j = 0; j < nn; ++j) f->P[(size_t)i * nn + j] = f->P[(size_t)keep[i] * n + keep[j]];
+    int w = 0, pos = 13;
+    for (int i = 0; i < N; ++i) {
+        if (dropf[i]) continue;
+        if (w != i) {
+            memcpy(&f->fpos[6 * w], &f->fpos[6 * i], 6 * sizeof(double));
+            f->ftype[w] = f->ftype[i];
+            memcpy(&f->fdesc[(size_t)w * EKF_DESC_BYTES], &f->fdesc[(size_t)i * EKF_DESC_BYTES], EKF_DESC_BYTES);
+            f->ftimes_predicted[w] = f->ftimes_predicted[i];
+            f->ftimes_matched[w] = f->ftimes_matched[i];
+        }
+        f->fcovpos[w] = pos;
+        pos += feat_dim(f->ftype[w]);
+        ++w;
+    }
+    f->N = w;
+    f->n = nn;
+    free(drop); free(dropf); free(keep);
+    return EKF_OK;
+}
+
+/* removeBadMapFeatures: EKF/MapManagement.cpp:279-308.  Returns how many were removed. */
+int orc_remove_bad_features(OrcFilter *f)
+{
+    int32_t *idx = (int32_t *)malloc((size_t)(f->N + 1) * sizeof(int32_t));
+    int c = 0;
+    for (int i = 0; i < f->N; ++i) {
+        float pct = (float)f->ftimes_matched[i] / (float)f->ftimes_predicted[i]; /* 0/0 = NaN compares false */
+        if (pct < f->par.goodFeatureMatchingPercent) idx[c++] = i;
+    }
+    orc_remove_features(f, idx, c);
+    free(idx);
+    return c;
+}
+
+/* computeLinearityIndex: EKF/MapManagement.cpp:312-341 */
+double orc_linearity_index(const OrcFilter *f, int fi)
+{
+    int d = feat_dim(f->ftype[fi]);
+    int ii = f->fcovpos[fi] + d - 1;
+    const double *p = &f->fpos[6 * fi];
+    double inv_err = sqrt(f->P[(size_t)ii * f->n + ii]);
+    double inv_val = p[d - 1];
+    double sigma = inv_err / (inv_val * inv_val);
+    double m[3], xyz[3];
+    dir_vector(p[3], p[4], m); /* changeInverseDepthToDepth, EKF/CommonFunctions.cpp:149-159 */
+    xyz[0] = p[0] + m[0] / p[5];
+    xyz[1] = p[1] + m[1] / p[5];
+    xyz[2] = p[2] + m[2] / p[5];
+    double to_cam[3] = {xyz[0] - f->x[0], xyz[1] - f->x[1], xyz[2] - f->x[2]};
+    double to_first[3] = {xyz[0] - p[0], xyz[1] - p[1], xyz[2] - p[2]};
+    double dot = 0.0;
+    for (int k = 0; k < 3; ++k) dot += to_cam[k] * to_first[k];
+    double d_first = norm3(to_first), d_cam = norm3(to_cam);
+    double cos_div = dot / (d_first * d_cam);
+    return 4.0 * sigma * cos_div / d_cam;
+}
+
+/* convertToDepth: EKF/MapManagement.cpp:343-490 */
+int orc_convert_to_depth(OrcFilter *f, int fi)
+{
+    if (fi < 0 || fi >= f->N || f->ftype[fi] != EKF_FEATURE_INVERSE_DEPTH) return EKF_ERR_INVALID_ARG;
+    int n = f->n, pos = f->fcovpos[fi];
+    double *p = &f->fpos[6 * fi];
+    double theta = p[3], phi = p[4], rho = p[5], mi[3];
+    dir_vector(theta, phi, mi);
+    double xyz[3] = {p[0] + mi[0] / rho, p[1] + mi[1] / rho, p[2] + mi[2] / rho};
+    double J[18];
+    memset(J, 0, sizeof(J));
+    J[0 * 6 + 0] = 1.0; J[1 * 6 + 1] = 1.0; J[2 * 6 + 2] = 1.0;
+    J[0 * 6 + 3] = cos(phi) * cos(theta) / rho;  J[1 * 6 + 3] = 0.0;             J[2 * 6 + 3] = -cos(phi) * sin(theta) / rho;
+    J[0 * 6 + 4] = -sin(phi) * sin(theta) / rho; J[1 * 6 + 4] = -cos(phi) / rho; J[2 * 6 + 4] = -sin(phi) * cos(theta) / rho;
+    J[0 * 6 + 5] = -mi[0] / (rho * rho);         J[1 * 6 + 5] = -mi[1] / (rho * rho); J[2 * 6 + 5] = -mi[2] / (rho * rho);
+    /* subResult_3xn = J * P[pos:pos+6, :] ; new columns = P[:, pos:pos+6] * J' ; block = subResult[:, pos:pos+6] * J' */
+    double *T = (double *)malloc((size_t)3 * n * sizeof(double));
+    gemm_ikj(3, 6, n, J, 6, f->P + (size_t)pos * n, n, T, n);
+    double *C = (double *)malloc((size_t)n * 3 * sizeof(double));
+    for (int i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            double s2 = 0.0;
+            for (int k = 0; k < 6; ++k) s2 += f->P[(size_t)i * n + pos + k] * J[a * 6 + k];
+            C[(size_t)i * 3 + a] = s2;
+        }
+    double B[9];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            double s2 = 0.0;
+            for (int k = 0; k < 6; ++k) s2 += T[(size_t)a * n + pos + k] * J[b * 6 + k];
+            B[a * 3 + b] = s2;
+        }
+    int nn = n - 3;
+    double *Pn = (double *)malloc((size_t)nn * nn * sizeof(double));
+    for (int i = 0; i < nn; ++i) {
+        int oi = i < pos ? i : (i < pos + 3 ? -1 - (i - pos) : i + 3); /* <0: new feature row a = -1-oi */
+        for (int j = 0; j < nn; ++j) {
+            int oj = j < pos ? j : (j < pos + 3 ? -1 - (j - pos) : j + 3);
+            double v;
+            if (oi >= 0 && oj >= 0) v = f->P[(size_t)oi * n + oj];
+            else if (oi < 0 && oj < 0) v = B[(-1 - oi) * 3 + (-1 - oj)];
+            else if (oi < 0) v = T[(size_t)(-1 - oi) * n + oj];
+            else v = C[(size_t)oi * 3 + (-1 - oj)];
+            Pn[(size_t)i * nn + j] = v;
+        }
+    }
+    memcpy(f->P, Pn, (size_t)nn * nn * sizeof(double));
+    free(T); free(C); free(Pn);
+    p[0] = xyz[0]; p[1] = xyz[1]; p[2] = xyz[2]; p[3] = p[4] = p[5] = 0.0;
+    f->ftype[fi] = EKF_FEATURE_DEPTH;
+    for (int i = 0; i < f->N; ++i)
+        if (f->fcovpos[i] > pos) f->fcovpos[i] -= 3;
+    f->n = nn;
+    return EKF_OK;
+}
+
+/* convertMapFeaturesInverseDepthToDepth: EKF/MapManagement.cpp:494-521 -- at most one conversion per call, the
+ * first inverse-depth feature (map order) whose linearity index is below the threshold.  Returns its index or -1. */
+int orc_convert_inverse_depth_to_depth(OrcFilter *f)
+{
+    for (int i = 0; i < f->N; ++i) {
+        if (f->ftype[i] != EKF_FEATURE_INVERSE_DEPTH) continue;
+        if (orc_linearity_index(f, i) < f->par.inverseDepthLinearityIndexThreshold) {
+            orc_convert_to_depth(f, i);
+            return i;
+        }
+    }
+    return -1;
+}
+
 /* -------------------------------------------------------------------------------------------- prediction */
 
 /* derivQuat*: EKF/StateAndCovariancePrediction.cpp:100-119 */

@@ -52,6 +52,15 @@ void orc_reset(OrcFilter *f);
 /* addFeatureToStateAndCovariance: EKF/AddMapFeature.cpp:293-344 (+ :109-289).  Returns new feature index or <0. */
 int orc_add_feature(OrcFilter *f, const double uv[2], const uint8_t *desc32);
 
+/* Map management, EKF/MapManagement.cpp: removeFeaturesFromStateAndCovariance :212 (ascending
+ * feature indices), removeBadMapFeatures :279, computeLinearityIndex :312, convertToDepth :343,
+ * convertMapFeaturesInverseDepthToDepth :494 (returns the converted feature index or -1). */
+int orc_remove_features(OrcFilter *f, const int32_t *idx, int count);
+int orc_remove_bad_features(OrcFilter *f);
+double orc_linearity_index(const OrcFilter *f, int fi);
+int orc_convert_to_depth(OrcFilter *f, int fi);
+int orc_convert_inverse_depth_to_depth(OrcFilter *f);
+
 /* Bulk load.  feature_pos holds 6 doubles per feature (depth features use the first 3); covariance positions
  * are assigned sequentially in map order (13, 13+d0, ...) as State/MapFeature do.  P is n x n row-major. */
 int orc_set_state(OrcFilter *f, const double x13[13], int n_features, const double *feature_pos,

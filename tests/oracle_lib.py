@@ -42,6 +42,12 @@ def lib():
                          ("orc_feature_times_matched", C.POINTER(C.c_uint32))]:
             getattr(L, name).restype = rt
             getattr(L, name).argtypes = [vp]
+        L.orc_remove_features.argtypes = [vp, vp, i32]
+        L.orc_remove_bad_features.argtypes = [vp]
+        L.orc_linearity_index.restype = C.c_double
+        L.orc_linearity_index.argtypes = [vp, i32]
+        L.orc_convert_to_depth.argtypes = [vp, i32]
+        L.orc_convert_inverse_depth_to_depth.argtypes = [vp]
         L.orc_predict.argtypes = [vp, vp, vp]
         L.orc_predict_measurement_state.argtypes = [vp, vp, vp, vp, vp, i32, vp]
         L.orc_predict_measurements.argtypes = [vp, vp, i32, vp, vp, vp, vp]
@@ -105,6 +111,25 @@ class Oracle:
         tp = np.ctypeslib.as_array(self.L.orc_feature_times_predicted(self.h), (N,)).copy()
         tm = np.ctypeslib.as_array(self.L.orc_feature_times_matched(self.h), (N,)).copy()
         return d, tp, tm
+
+    def feature_type(self):
+        return np.ctypeslib.as_array(self.L.orc_feature_type(self.h), (self.N,)).copy()
+
+    def remove_features(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        assert self.L.orc_remove_features(self.h, _p(idx), len(idx)) == 0
+
+    def remove_bad_features(self):
+        return self.L.orc_remove_bad_features(self.h)
+
+    def linearity_index(self, fi):
+        return self.L.orc_linearity_index(self.h, int(fi))
+
+    def convert_to_depth(self, fi):
+        assert self.L.orc_convert_to_depth(self.h, int(fi)) == 0
+
+    def convert_inverse_depth_to_depth(self):
+        return self.L.orc_convert_inverse_depth_to_depth(self.h)
 
     def feature_covpos(self):
         return np.ctypeslib.as_array(self.L.orc_feature_covpos(self.h), (self.N,)).copy()

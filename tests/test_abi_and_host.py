@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_struct_layouts_match_header():
     # sizes implied by include/ekf_types.h (no implicit padding surprises)
     assert C.sizeof(EkfCamera) == 8 + 12 * 8
-    assert C.sizeof(EkfParams) == 10 * 8
+    assert C.sizeof(EkfParams) == 12 * 8
     assert C.sizeof(engine.EkfEngineConfig) == C.sizeof(EkfCamera) + C.sizeof(EkfParams) + 6 * 4
     assert C.sizeof(engine.EkfStageTimes) == 11 * 8
 

@@ -271,3 +271,67 @@ def test_step_runs_and_tracks(oracle_lib, seq50):
     P = o.P()
     assert np.abs(P - P.T).max() <= 1e-15 * np.abs(P).max() and np.isfinite(P).all()
     assert abs(np.linalg.norm(o.x13()[3:7]) - 1.0) < 1e-12
+
+
+# ----------------------------------------------------------------------------------------- map management (8(f)-1)
+def test_remove_features_matches_numpy_delete(oracle_lib, seq12):
+    o = _load(oracle_lib, seq12)
+    P0, f0 = o.P(), o.feature_pos()
+    o.remove_features([2, 5, 6])
+    rows = np.concatenate([np.arange(13 + 6 * f, 19 + 6 * f) for f in (2, 5, 6)])
+    np.testing.assert_array_equal(o.P(), np.delete(np.delete(P0, rows, 0), rows, 1))
+    np.testing.assert_array_equal(o.feature_pos(), np.delete(f0, [2, 5, 6], 0))
+    assert o.N == 9 and o.n == 13 + 54 and list(o.feature_covpos()) == [13 + 6 * i for i in range(9)]
+
+
+def test_convert_to_depth_matches_numpy_and_keeps_the_projection(oracle_lib, seq12):
+    o = _load(oracle_lib, seq12)
+    fi = 4
+    P0, f0, x = o.P(), o.feature_pos(), o.x13()
+    uv_before = _measure(o, x, f0)[fi]
+    p = f0[fi]
+    th, ph, rho = p[3], p[4], p[5]
+    m = np.array([np.cos(ph) * np.sin(th), -np.sin(ph), np.cos(ph) * np.cos(th)])
+    J = np.zeros((3, 6))
+    J[:, :3] = np.eye(3)
+    J[:, 3] = [np.cos(ph) * np.cos(th) / rho, 0, -np.cos(ph) * np.sin(th) / rho]
+    J[:, 4] = [-np.sin(ph) * np.sin(th) / rho, -np.cos(ph) / rho, -np.sin(ph) * np.cos(th) / rho]
+    J[:, 5] = -m / rho**2
+    n = o.n
+    pos = 13 + 6 * fi
+    T = np.zeros((n - 3, n))
+    T[:pos, :pos] = np.eye(pos)
+    T[pos:pos + 3, pos:pos + 6] = J
+    T[pos + 3:, pos + 6:] = np.eye(n - pos - 6)
+    li = o.linearity_index(fi)
+    o.convert_to_depth(fi)
+    np.testing.assert_allclose(o.P(), T @ P0 @ T.T, rtol=1e-12, atol=1e-18)
+    np.testing.assert_allclose(o.feature_pos()[fi][:3], p[:3] + m / rho, rtol=1e-15)
+    assert o.feature_type()[fi] == 1 and o.n == n - 3
+    assert list(o.feature_covpos()) == [13 + 6 * i for i in range(fi + 1)] + [13 + 6 * i - 3 for i in range(fi + 1, 12)]
+    # same 3-D point => same predicted pixel (depth features go through inv(R), inverse-depth through R')
+    np.testing.assert_allclose(_measure(o, x, o.feature_pos())[fi], uv_before, rtol=1e-10)
+    # linearity index: 4 sigma_d cos(alpha) / d  (EKF/MapManagement.cpp:312-341)
+    sig = np.sqrt(P0[pos + 5, pos + 5]) / rho**2
+    xyz = p[:3] + m / rho
+    tc, tf = xyz - x[:3], xyz - p[:3]
+    ref = 4 * sig * (tc @ tf) / (np.linalg.norm(tc) * np.linalg.norm(tf)) / np.linalg.norm(tc)
+    np.testing.assert_allclose(li, ref, rtol=1e-12)
+
+
+def test_step_with_depth_features_and_bad_feature_removal(oracle_lib, seq50):
+    """A map holding both parametrisations keeps tracking; removeBadMapFeatures drops never-matched features."""
+    ol = oracle_lib
+    o = _load(ol, seq50)
+    for kps, desc in seq50.frames[:3]:
+        o.step(kps, desc, ol.LITERAL)
+    for fi in (3, 17, 30):
+        o.convert_to_depth(fi)
+    assert o.n == 313 - 9
+    for kps, desc in seq50.frames[3:]:
+        info = o.step(kps, desc, ol.LITERAL)
+        assert info.status == 0 and info.n_predicted >= 47 and info.n_inliers + info.n_rescued >= 0.5 * info.n_matches
+    d, tp, tm = o.map_features()
+    assert tp.max() == len(seq50.frames)
+    bad = int(((tm.astype(np.float32) / tp.astype(np.float32)) < 0.5).sum())
+    assert o.remove_bad_features() == bad and o.N == 50 - bad
