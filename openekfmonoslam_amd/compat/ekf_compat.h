@@ -499,7 +499,35 @@ public:
         if (rc != EKF_OK) throw ekf_compat::Error(rc, ekf_last_error(e_));
         return info;
     }
-    void syncToHost() { ekf_compat::download(e_, state, &stateCovarianceMatrix); }
+    void syncToHost()
+    {
+        refreshLayout();
+        ekf_compat::download(e_, state, &stateCovarianceMatrix);
+    }
+    // ---- map management on the device (EKF.cpp:574-612).  Detection of new features stays on the
+    // host: the caller passes the distorted pixel + descriptor of each new ImageFeatureMeasurement.
+    void addFeaturesToStateAndCovariance(const std::vector<double> &uv, const std::vector<uint8_t> &descriptors)
+    { // AddMapFeature.cpp:354
+        ekf_compat::chk(e_, ekf_add_features(e_, uv.data(), descriptors.empty() ? 0 : descriptors.data(), (int)(uv.size() / 2)),
+                        "ekf_add_features");
+    }
+    int removeBadMapFeatures()
+    { // MapManagement.cpp:279
+        int k = 0;
+        ekf_compat::chk(e_, ekf_remove_bad_features(e_, &k), "ekf_remove_bad_features");
+        return k;
+    }
+    void removeFeaturesFromStateAndCovariance(const std::vector<int32_t> &ascendingFeatureIndexes)
+    { // MapManagement.cpp:212
+        ekf_compat::chk(e_, ekf_remove_features(e_, ascendingFeatureIndexes.data(), (int)ascendingFeatureIndexes.size()),
+                        "ekf_remove_features");
+    }
+    int convertMapFeaturesInverseDepthToDepth()
+    { // MapManagement.cpp:494
+        int k = -1;
+        ekf_compat::chk(e_, ekf_convert_inverse_depth_to_depth(e_, &k), "ekf_convert_inverse_depth_to_depth");
+        return k;
+    }
     EkfEngine *engine() { return e_; }
     Matd stateCovarianceMatrix;
     State state;
@@ -507,6 +535,27 @@ public:
 private:
     EKF(const EKF &);
     EKF &operator=(const EKF &);
+    // rebuild the host-side MapFeature list when the device map changed size or parametrisation
+    void refreshLayout()
+    {
+        const int N = ekf_num_features(e_);
+        std::vector<int32_t> type(N + 1), covpos(N + 1);
+        std::vector<uint8_t> desc((size_t)(N + 1) * EKF_DESC_BYTES);
+        std::vector<uint32_t> tp(N + 1), tm(N + 1);
+        ekf_compat::chk(e_, ekf_get_feature_layout(e_, type.data(), covpos.data()), "ekf_get_feature_layout");
+        ekf_compat::chk(e_, ekf_get_map_features(e_, desc.data(), tp.data(), tm.data()), "ekf_get_map_features");
+        state.removeAllFeatures();
+        const double zero[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < N; ++i) {
+            Descriptor32 d;
+            std::memcpy(d.bytes, &desc[(size_t)i * EKF_DESC_BYTES], EKF_DESC_BYTES);
+            const bool inv = type[i] == EKF_FEATURE_INVERSE_DEPTH;
+            MapFeature *f = new MapFeature(zero, inv ? 6 : 3, covpos[i], d, inv ? MAPFEATURE_TYPE_INVERSE_DEPTH : MAPFEATURE_TYPE_DEPTH);
+            f->timesPredicted = tp[i];
+            f->timesMatched = tm[i];
+            state.addFeature(f);
+        }
+    }
     EkfEngine *e_;
     int steps_;
 };

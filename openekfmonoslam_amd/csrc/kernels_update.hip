@@ -88,82 +88,112 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 }
 
 // -------------------------------------------------------------------------------------- blocked Cholesky sweep
-// Right-looking sweep over [ S | nu ], panel width NB = 32, rows k0..k0+kb-1.  Two launches per panel:
-//   panel : every workgroup first factorises the 32x32 diagonal block S_kk = L_kk L_kk' and inverts L_kk, entirely
-//           in the registers of its first wavefront (lane = row, cross-lane broadcasts; no LDS round trips), then
-//           forms its own 32-row block  L_ik = S_ik inv(L_kk)'  (i > k).  The extra workgroup stores inv(L_kk)
-//           into the block-diagonal inverse Dinv and solves z_k = inv(L_kk) nu_k.
-//   trail : S_ij -= L_ik L_jk' (i >= j > k),  nu_i -= L_ik z_k.
+// Right-looking sweep over [ S | nu ], panel width NB = 32.  The only serial piece is the 32x32 diagonal block:
+// its Cholesky factor and the inverse of that factor.  It is computed by ONE workgroup with all 256 threads working
+// in LDS (block_chol_inv32, one barrier per column) and -- look-ahead -- inside the trailing-update launch of the
+// PREVIOUS panel, by the workgroup that owns tile (k+1, k+1): while the other workgroups of that launch update
+// their tiles, this one finishes tile (k+1, k+1), factorises it and stores inv(L_{k+1,k+1}) into Dinv.  Per panel:
+//   panel : L_ik = S_ik inv(L_kk)' for the row blocks below (inverse read from Dinv), z_k = inv(L_kk) nu_k
+//   trail : S_ij -= L_ik L_jk' (i >= j > k), nu_i -= L_ik z_k, + the look-ahead factorisation of block k+1
 // B = inv(L) A is NOT part of the sweep: it is independent per column of A and runs afterwards as one launch
 // (k_trsm) on the MFMA pipe.
 
-// broadcast of a double from a compile-time lane through SGPRs (v_readlane_b32 x2): no LDS round trip
-__device__ __forceinline__ double bcast_lane(double v, int src_lane)
+// Forward elimination on the augmented block [A | I], all 256 threads of a workgroup: thread (r, g) keeps columns
+// 4g..4g+3 of row r of both halves in REGISTERS for the whole sweep; only what a step broadcasts travels through LDS
+// (the pivot column and the pivot row of the identity half, double-buffered, one barrier per column).
+//   a : 32x33 doubles in LDS, lower triangle of the SPD block (identity-padded rows beyond the live size)
+//   x : 32x33 doubles in LDS, receives inv(L) (zeros above the diagonal)
+// Scalings are deferred: updates use 1 / a[j][j]; inv(L)[r][:] = x[r][:] sqrt(1 / pivot_r) is applied at the end.
+// Returns false (uniformly) on a non-positive pivot.
+__device__ __forceinline__ bool block_chol_inv32(double (*a)[NB + 1], double (*x)[NB + 1], double *rs)
 {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
-}
-
-// Cholesky factor AND inverse of a 32x32 block in one sweep, one row per lane (lanes 0..31): forward elimination
-// on the augmented block [A | I] -> [L' | inv(L)].  a[] holds the row of A (lower part meaningful), x[] the row of
-// the identity part; on return a[] = row of L, x[] = row of inv(L).  Column values travel between lanes through
-// SGPRs (v_readlane), never through LDS.  Returns false on a non-positive pivot.
-__device__ __forceinline__ bool wave_chol_inv32(double (&a)[NB], double (&x)[NB], int lane)
-{
-    bool ok = true;
+    __shared__ double colbuf[2][NB], rowbuf[2][NB];
+    const int t = threadIdx.x;
+    const int r = t >> 3, c0 = (t & 7) * 4;
+    double av[4], xv[4];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const double djj = bcast_lane(a[j], j);
-        ok = ok && (djj > 0.0);
-        const double rs = rsqrt(djj > 0.0 ? djj : 1.0);
-        const double l = (lane > j) ? a[j] * rs : (lane == j ? djj * rs : 0.0);
-        a[j] = l;
-        if (lane == j) {
-#pragma unroll
-            for (int c = 0; c <= j; ++c) x[c] *= rs;
-        }
-        // all broadcasts of the step first (SGPR pairs), then all FMAs: interleaving them costs an SGPR-hazard nop
-        // per pair and doubles the step time
-        double lb[NB], xb[NB];
-#pragma unroll
-        for (int c = j + 1; c < NB; ++c) lb[c] = bcast_lane(l, c);
-#pragma unroll
-        for (int c = 0; c <= j; ++c) xb[c] = bcast_lane(x[c], j);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = j + 1; c < NB; ++c) a[c] -= l * lb[c];
-        const double lx = (lane > j) ? l : 0.0;
-#pragma unroll
-        for (int c = 0; c <= j; ++c) x[c] -= lx * xb[c];
-        __builtin_amdgcn_sched_barrier(0);
+    for (int e = 0; e < 4; ++e) {
+        av[e] = (c0 + e <= r) ? a[r][c0 + e] : 0.0;
+        xv[e] = (r == c0 + e) ? 1.0 : 0.0;
     }
+    if (c0 == 0) colbuf[0][r] = av[0];
+    if (r == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rowbuf[0][c0 + e] = xv[e];
+    }
+    __syncthreads();
+    bool ok = true;
+    for (int j = 0; j < NB; ++j) {
+        const int p = j & 1;
+        const double djj = colbuf[p][j];
+        ok = ok && (djj > 0.0);
+        const double inv = 1.0 / (djj > 0.0 ? djj : 1.0);
+        if (t == 0) rs[j] = inv;
+        if (r > j) {
+            const double arj = colbuf[p][r] * inv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = c0 + e;
+                if (c > j && c <= r) av[e] -= arj * colbuf[p][c];
+                if (c <= j) xv[e] -= arj * rowbuf[p][c];
+            }
+        }
+        const int jn = j + 1;
+        if (jn < NB) { // publish column j+1 of the A half and row j+1 of the identity half for the next step
+            const int e = jn - c0;
+            if (e >= 0 && e < 4 && r >= jn) colbuf[p ^ 1][r] = e == 0 ? av[0] : (e == 1 ? av[1] : (e == 2 ? av[2] : av[3]));
+            if (r == jn) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rowbuf[p ^ 1][c0 + q] = xv[q];
+            }
+        }
+        __syncthreads();
+    }
+    const double sr = sqrt(rs[r]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[r][c0 + e] = (c0 + e <= r) ? xv[e] * sr : 0.0;
+    __syncthreads();
     return ok;
 }
 
-// grid.x = nrb row blocks below the panel + 1 (diagonal bookkeeping, nu)
+// store inv(L_kk) (32x32, in LDS) into the block-diagonal inverse: Dinv is [m_pad256 x 256], row (k0 + r) holds
+// its 256-block's row
+__device__ __forceinline__ void store_linv(double *Dinv, int k0, const double (*x)[NB + 1])
+{
+    const int cb = k0 % TB;
+    for (int i = threadIdx.x; i < NB * NB; i += 256) {
+        const int r = i / NB, c = i % NB;
+        Dinv[(size_t)(k0 + r) * TB + cb + c] = x[r][c];
+    }
+}
+
+// first panel only: factorise block 0
+__global__ void __launch_bounds__(256) k_chol_diag0(const double *S, int ldS, int kb, double *Dinv, int *counts)
+{
+    __shared__ double sa[NB][NB + 1], sx[NB][NB + 1], srs[NB];
+    for (int i = threadIdx.x; i < NB * NB; i += 256) {
+        const int r = i / NB, c = i % NB;
+        sa[r][c] = (r < kb && c <= r) ? S[(size_t)r * ldS + c] : ((r == c) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (!block_chol_inv32(sa, sx, srs) && threadIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
+    store_linv(Dinv, 0, sx);
+}
+
+// grid.x = nrb row blocks below the panel + 1 (z_k)
 __global__ void __launch_bounds__(256)
-k_chol_panel(double *S, int ldS, int m, int k0, int kb, double *Dinv, double *nu, int nrb, int *counts)
+k_chol_panel(double *S, int ldS, int m, int k0, int kb, const double *Dinv, double *nu, int nrb)
 {
     __shared__ double sLi[NB][NB + 1]; // inv(L_kk)
     __shared__ double sS[NB][NB + 1];
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < 64) {
-        double a[NB], x[NB];
-        const int r = lane < NB ? lane : 0;
-#pragma unroll
-        for (int c = 0; c < NB; ++c) {
-            a[c] = (lane < kb && c <= r && c < kb) ? S[(size_t)(k0 + r) * ldS + k0 + c] : ((c == r) ? 1.0 : 0.0);
-            x[c] = (c == lane) ? 1.0 : 0.0;
-        }
-        const bool ok = wave_chol_inv32(a, x, lane);
-        if (!ok && lane == 0 && blockIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
-        if (lane < NB) {
-#pragma unroll
-            for (int c = 0; c < NB; ++c) sLi[lane][c] = (c <= lane) ? x[c] : 0.0;
+    const int tid = threadIdx.x;
+    {
+        const int cb = k0 % TB;
+        for (int i = tid; i < NB * NB; i += 256) {
+            const int r = i / NB, c = i % NB;
+            sLi[r][c] = Dinv[(size_t)(k0 + r) * TB + cb + c];
         }
     }
-    __syncthreads();
     const int k1 = k0 + kb;
     if ((int)blockIdx.x < nrb) {
         const int i0 = k1 + blockIdx.x * NB;
@@ -181,12 +211,6 @@ k_chol_panel(double *S, int ldS, int m, int k0, int kb, double *Dinv, double *nu
             }
         }
     } else {
-        // block-diagonal inverse storage: Dinv is [m_pad256 x 256], row (k0 + r) holds its 256-block's row
-        const int cb = k0 % TB;
-        for (int i = tid; i < NB * NB; i += 256) {
-            const int r = i / NB, c = i % NB;
-            Dinv[(size_t)(k0 + r) * TB + cb + c] = sLi[r][c];
-        }
         __shared__ double sn[NB];
         if (tid < NB) sn[tid] = tid < kb ? nu[k0 + tid] : 0.0;
         __syncthreads();
@@ -198,12 +222,14 @@ k_chol_panel(double *S, int ldS, int m, int k0, int kb, double *Dinv, double *nu
     }
 }
 
-// grid.x : [0, n_stiles) lower-triangular 32x32 tiles of the trailing S, then one block for nu.
+// grid.x : [0, n_stiles) lower-triangular 32x32 tiles of the trailing S (tile 0 = block (k+1, k+1): look-ahead
+// factorisation), then one block for nu.
 __global__ void __launch_bounds__(256)
-k_chol_trailing(double *S, int ldS, int m, int k0, int kb, double *nu, int n_stiles)
+k_chol_trailing(double *S, int ldS, int m, int k0, int kb, double *nu, int n_stiles, double *Dinv, int *counts)
 {
     __shared__ double sA[NB][NB + 1];
     __shared__ double sB[NB][NB + 1];
+    __shared__ double srs[NB];
     const int tid = threadIdx.x;
     const int k1 = k0 + kb;
     const int b = blockIdx.x;
@@ -219,15 +245,33 @@ k_chol_trailing(double *S, int ldS, int m, int k0, int kb, double *nu, int n_sti
             sB[r][c] = (j0 + r < m && c < kb) ? S[(size_t)(j0 + r) * ldS + k0 + c] : 0.0;
         }
         __syncthreads();
-        for (int i = tid; i < NB * NB; i += 256) {
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * 256;
             const int r = i / NB, c = i % NB;
+            v[q] = 0.0;
             if (i0 + r < m && j0 + c < m && j0 + c <= i0 + r) {
                 double s = 0.0;
 #pragma unroll
                 for (int k2 = 0; k2 < NB; ++k2) s += sA[r][k2] * sB[c][k2];
-                S[(size_t)(i0 + r) * ldS + j0 + c] -= s;
+                v[q] = S[(size_t)(i0 + r) * ldS + j0 + c] - s;
+                if (b != 0) S[(size_t)(i0 + r) * ldS + j0 + c] = v[q];
             }
         }
+        if (b != 0) return;
+        // look-ahead: this workgroup owns block (k+1, k+1); finish it in LDS, factorise, publish its inverse
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * 256;
+            const int r = i / NB, c = i % NB;
+            const bool live = (k1 + r < m) && (c <= r);
+            sA[r][c] = live ? v[q] : ((r == c) ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (!block_chol_inv32(sA, sB, srs) && tid == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
+        store_linv(Dinv, k1, sB);
         return;
     }
     for (int i = k1 + tid; i < m; i += 256) {
@@ -564,14 +608,16 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         k_assemble_S<T><<<grid, 256, 0, s>>>(A, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS);
     }
+    k_chol_diag0<<<1, 256, 0, s>>>(e->d.S, ldS, min(NB, m), e->d.Dinv, e->d.counts);
     for (int k0 = 0; k0 < m; k0 += NB) {
         const int kb = min(NB, m - k0);
         const int k1 = k0 + kb;
         const int nrb = (m - k1 + NB - 1) / NB; // row blocks below the panel
-        k_chol_panel<<<nrb + 1, 256, 0, s>>>(e->d.S, ldS, m, k0, kb, e->d.Dinv, e->d.nu, nrb, e->d.counts);
+        k_chol_panel<<<nrb + 1, 256, 0, s>>>(e->d.S, ldS, m, k0, kb, e->d.Dinv, e->d.nu, nrb);
         if (nrb > 0) {
             const int n_stiles = nrb * (nrb + 1) / 2;
-            k_chol_trailing<<<n_stiles + 1, 256, 0, s>>>(e->d.S, ldS, m, k0, kb, e->d.nu, n_stiles);
+            k_chol_trailing<<<n_stiles + 1, 256, 0, s>>>(e->d.S, ldS, m, k0, kb, e->d.nu, n_stiles, e->d.Dinv,
+                                                         e->d.counts);
         }
     }
     for (int sz = NB; sz < TB; sz *= 2) {
