@@ -162,6 +162,29 @@ int ekf_frames_upload(EkfEngine *e, int n_frames, const int32_t *kp_counts, cons
                       const uint8_t *desc_concat);
 int ekf_step_frame(EkfEngine *e, int frame, EkfStepInfo *info);
 
+/* -- matcher mode B: image in, no detector ----------------------------------------------------------------
+ * matchPredictedFeatures(const cv::Mat &image, ...)  EKF/Matching.h:66 and EKF::step(const cv::Mat &image)
+ * EKF/EKF.h:57 take the frame itself.  Mode B keeps that signature: the frame is uploaded (1, 3 = BGR or
+ * 4 = RGBA bytes per pixel, as Img/FileSequenceImageGenerator.cpp:82 and android jni/EKFNative.cpp:163 deliver
+ * it), reduced to a 3-level gray pyramid on the device, and each predicted feature is matched by zero-mean NCC
+ * of its 11x11 template inside the predicted ellipse (gate of Matching.cpp:217-241), coarse to fine.  The
+ * reference has no such matcher (it runs an OpenCV detector + descriptor on the host, Matching.cpp:188-210);
+ * the definition is this build's and is restated on the CPU in oracle/ekf_oracle.c for the parity tests.
+ * Matches carry keypointIndex = -1 and integer pixel positions; templates are captured once and kept. */
+int ekf_image_upload(EkfEngine *e, const uint8_t *image, int width, int height, int stride, int channels);
+int ekf_get_image_level(EkfEngine *e, int level, uint8_t *out, int *width, int *height); /* readback for tests */
+/* templates of the listed map features, cut from the CURRENT image around uv (the pixel a feature was
+ * initialised at: addFeaturesToStateAndCovariance keeps the descriptor there, EKF/AddMapFeature.cpp:317-337) */
+int ekf_capture_templates(EkfEngine *e, const int32_t *feat_idx, const double *uv, int count);
+int ekf_match_ncc(EkfEngine *e, EkfMatch *matches, int *n_matches);
+int ekf_step_image(EkfEngine *e, const uint8_t *image, int width, int height, int stride, int channels,
+                   EkfStepInfo *info);
+/* pre-staged image sequence (n_frames images of identical geometry, concatenated) */
+int ekf_images_upload(EkfEngine *e, int n_frames, const uint8_t *images, int width, int height, int stride,
+                      int channels);
+int ekf_select_staged_image(EkfEngine *e, int frame); /* build the pyramid of a staged frame */
+int ekf_step_staged_image(EkfEngine *e, int frame, EkfStepInfo *info);
+
 /* -- instrumentation ------------------------------------------------------------------------------------- */
 int ekf_timing_enable(EkfEngine *e, int on); /* HIP-event timing of stages and of the P-update kernel */
 int ekf_timing_reset(EkfEngine *e);

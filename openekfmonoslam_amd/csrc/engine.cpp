@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <new>
 
@@ -69,7 +70,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
                     d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.Tbuf,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.pu_tilemap,
-                    e->frames.kps, e->frames.desc};
+                    e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.raw, e->img.seq};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &ev : e->ev)
@@ -158,6 +159,8 @@ int ekf_engine_create(const EkfEngineConfig *cfg, EkfEngine **out)
     ALLOC(d.mt_valid, cap);
     ALLOC(d.mt_kp, cap);
     ALLOC(d.mt_dist, cap);
+    ALLOC(d.mt_xy, cap);
+    ALLOC(d.tmpl, (size_t)3 * 121 * cap);
     ALLOC(d.matches, cap);
     ALLOC(d.msel, cap);
     ALLOC(d.mout, cap);
@@ -365,7 +368,9 @@ static int compact_map(EkfEngine *e, const std::vector<uint8_t> &drop_feature, c
     std::vector<double> pos(6 * (size_t)N);
     std::vector<uint8_t> desc((size_t)N * EKF_DESC_BYTES);
     std::vector<unsigned> tp(N), tm(N);
+    std::vector<uint8_t> tmpl((size_t)N * 363);
     HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(tmpl.data(), e->d.tmpl, tmpl.size(), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(pos.data(), e->d.feat_pos, pos.size() * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(desc.data(), e->d.feat_desc, desc.size(), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(tp.data(), e->d.feat_times_predicted, (size_t)N * 4, hipMemcpyDeviceToHost));
@@ -376,6 +381,7 @@ static int compact_map(EkfEngine *e, const std::vector<uint8_t> &drop_feature, c
         if (drop_feature[i]) continue;
         std::memmove(&pos[6 * (size_t)w], &pos[6 * (size_t)i], 6 * sizeof(double));
         std::memmove(&desc[(size_t)w * EKF_DESC_BYTES], &desc[(size_t)i * EKF_DESC_BYTES], EKF_DESC_BYTES);
+        std::memmove(&tmpl[(size_t)w * 363], &tmpl[(size_t)i * 363], 363);
         tp[w] = tp[i];
         tm[w] = tm[i];
         e->h_type[w] = e->h_type[i];
@@ -392,6 +398,7 @@ static int compact_map(EkfEngine *e, const std::vector<uint8_t> &drop_feature, c
     if (w > 0) {
         HIPCHK(hipMemcpy(e->d.feat_pos, pos.data(), (size_t)6 * w * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d.feat_desc, desc.data(), (size_t)w * EKF_DESC_BYTES, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d.tmpl, tmpl.data(), (size_t)w * 363, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d.feat_times_predicted, tp.data(), (size_t)w * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d.feat_times_matched, tm.data(), (size_t)w * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d.feat_type, e->h_type.data(), (size_t)w * 4, hipMemcpyHostToDevice));
@@ -765,7 +772,10 @@ struct StageTimer {
 };
 
 // EKF::step (EKF.cpp:242-556) with keypoints already on the device
-static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_desc, int n_kp, EkfStepInfo *info)
+static int match_ncc_dev(EkfEngine *e, int *n_matches);
+
+static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_desc, int n_kp, EkfStepInfo *info,
+                    bool use_ncc = false)
 {
     EkfStepInfo li;
     std::memset(&li, 0, sizeof(li));
@@ -781,7 +791,7 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
     tm.mark();
     // 4. matching (:337)
     int M = 0;
-    if ((rc = match_dev(e, d_kps, d_desc, n_kp, &M))) return rc;
+    if ((rc = use_ncc ? match_ncc_dev(e, &M) : match_dev(e, d_kps, d_desc, n_kp, &M))) return rc;
     li.n_matches = M;
     tm.mark();
     // 6. 1-point RANSAC (:402); predictions/Jacobians are looked up by featureIndex (:368-392)
@@ -875,6 +885,155 @@ int ekf_step_frame(EkfEngine *e, int frame, EkfStepInfo *info)
     HIPCHK(hipSetDevice(e->device));
     const size_t off = (size_t)e->frames.offset[frame];
     return step_dev(e, e->frames.kps + off, e->frames.desc + off * EKF_DESC_BYTES, e->frames.count[frame], info);
+}
+
+// ------------------------------------------------------------------------------------- NCC matcher (mode B)
+static int ensure_pyramid(EkfEngine *e, int w, int h)
+{
+    if (e->img.w[0] == w && e->img.h[0] == h && e->img.px[0]) return EKF_OK;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int lw = w, lh = h;
+    for (int l = 0; l < 3; ++l) {
+        if (e->img.px[l]) (void)hipFree(e->img.px[l]);
+        e->img.px[l] = nullptr;
+        e->img.w[l] = lw;
+        e->img.h[l] = lh;
+        HIPCHK(hipMalloc((void **)&e->img.px[l], (size_t)std::max(lw, 1) * std::max(lh, 1)));
+        lw /= 2;
+        lh /= 2;
+    }
+    return EKF_OK;
+}
+
+static int valid_image_args(const uint8_t *image, int w, int h, int stride, int channels)
+{
+    return image && w >= 4 && h >= 4 && (channels == 1 || channels == 3 || channels == 4) && stride >= w * channels;
+}
+
+int ekf_image_upload(EkfEngine *e, const uint8_t *image, int width, int height, int stride, int channels)
+{
+    if (!e || !valid_image_args(image, width, height, stride, channels)) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    int rc = ensure_pyramid(e, width, height);
+    if (rc) return rc;
+    const size_t bytes = (size_t)stride * height;
+    if (e->img.raw_cap < bytes) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->img.raw) (void)hipFree(e->img.raw);
+        e->img.raw = nullptr;
+        HIPCHK(hipMalloc((void **)&e->img.raw, bytes));
+        e->img.raw_cap = bytes;
+    }
+    HIPCHK(hipMemcpyAsync(e->img.raw, image, bytes, hipMemcpyHostToDevice, e->stream));
+    launch_ncc_pyramid(e, e->img.raw, stride, channels);
+    e->img.valid = true;
+    return check_async(e);
+}
+
+int ekf_get_image_level(EkfEngine *e, int level, uint8_t *out, int *width, int *height)
+{
+    if (!e || level < 0 || level > 2 || !e->img.valid) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (width) *width = e->img.w[level];
+    if (height) *height = e->img.h[level];
+    if (out) HIPCHK(hipMemcpy(out, e->img.px[level], (size_t)e->img.w[level] * e->img.h[level], hipMemcpyDeviceToHost));
+    return EKF_OK;
+}
+
+int ekf_capture_templates(EkfEngine *e, const int32_t *feat_idx, const double *uv, int count)
+{
+    if (!e || count < 0 || (count > 0 && (!feat_idx || !uv)) || !e->img.valid) return EKF_ERR_INVALID_ARG;
+    if (count > e->cap) return EKF_ERR_CAPACITY;
+    for (int i = 0; i < count; ++i)
+        if (feat_idx[i] < 0 || feat_idx[i] >= e->N) return EKF_ERR_INVALID_ARG;
+    if (count == 0) return EKF_OK;
+    HIPCHK(hipSetDevice(e->device));
+    // work_idx / pred_uv2 are free between stages
+    HIPCHK(hipMemcpyAsync(e->d.work_idx, feat_idx, (size_t)count * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d.pred_uv2, uv, (size_t)count * 2 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    launch_ncc_capture(e, e->d.work_idx, e->d.pred_uv2, count);
+    HIPCHK(hipStreamSynchronize(e->stream)); // the host arrays may be reused by the caller
+    return check_async(e);
+}
+
+static int match_ncc_dev(EkfEngine *e, int *n_matches)
+{
+    if (!e->img.valid) {
+        e->err = "NCC matcher: no image uploaded";
+        return EKF_ERR_INVALID_ARG;
+    }
+    launch_match_ncc(e, e->n_pred);
+    int rc = read_counts(e);
+    if (rc) return rc;
+    *n_matches = e->h_counts[CNT_NMATCH];
+    return check_async(e);
+}
+
+int ekf_match_ncc(EkfEngine *e, EkfMatch *matches, int *n_matches)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    int M = 0;
+    int rc = match_ncc_dev(e, &M);
+    if (rc) return rc;
+    if (n_matches) *n_matches = M;
+    if (matches && M > 0) HIPCHK(hipMemcpy(matches, e->d.matches, (size_t)M * sizeof(EkfMatch), hipMemcpyDeviceToHost));
+    return EKF_OK;
+}
+
+int ekf_step_image(EkfEngine *e, const uint8_t *image, int width, int height, int stride, int channels, EkfStepInfo *info)
+{
+    int rc = ekf_image_upload(e, image, width, height, stride, channels);
+    if (rc) return rc;
+    return step_dev(e, nullptr, nullptr, 0, info, true);
+}
+
+int ekf_images_upload(EkfEngine *e, int n_frames, const uint8_t *images, int width, int height, int stride, int channels)
+{
+    if (!e || n_frames < 0 || (n_frames > 0 && !valid_image_args(images, width, height, stride, channels))) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->img.seq) (void)hipFree(e->img.seq);
+    e->img.seq = nullptr;
+    e->img.seq_n = 0;
+    if (n_frames == 0) return EKF_OK;
+    const size_t bytes = (size_t)stride * height * n_frames;
+    HIPCHK(hipMalloc((void **)&e->img.seq, bytes));
+    HIPCHK(hipMemcpy(e->img.seq, images, bytes, hipMemcpyHostToDevice));
+    e->img.seq_n = n_frames;
+    e->img.seq_w = width;
+    e->img.seq_h = height;
+    e->img.seq_stride = stride;
+    e->img.seq_channels = channels;
+    return EKF_OK;
+}
+
+static int staged_pyramid(EkfEngine *e, int frame)
+{
+    if (frame < 0 || frame >= e->img.seq_n) return EKF_ERR_INVALID_ARG;
+    int rc = ensure_pyramid(e, e->img.seq_w, e->img.seq_h);
+    if (rc) return rc;
+    launch_ncc_pyramid(e, e->img.seq + (size_t)frame * e->img.seq_stride * e->img.seq_h, e->img.seq_stride, e->img.seq_channels);
+    e->img.valid = true;
+    return EKF_OK;
+}
+
+int ekf_select_staged_image(EkfEngine *e, int frame)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    int rc = staged_pyramid(e, frame);
+    return rc ? rc : check_async(e);
+}
+
+int ekf_step_staged_image(EkfEngine *e, int frame, EkfStepInfo *info)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    int rc = staged_pyramid(e, frame);
+    if (rc) return rc;
+    return step_dev(e, nullptr, nullptr, 0, info, true);
 }
 
 // -------------------------------------------------------------------------------------------------- timing

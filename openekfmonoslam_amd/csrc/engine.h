@@ -74,6 +74,8 @@ struct DeviceArrays {
     int *mt_valid = nullptr;  // per prediction slot
     int *mt_kp = nullptr;
     float *mt_dist = nullptr;
+    EkfKeypoint *mt_xy = nullptr; // NCC matcher: matched pixel per prediction slot
+    uint8_t *tmpl = nullptr;      // NCC matcher: 3 levels x 121 bytes per feature
     EkfMatch *matches = nullptr; // compacted matches (prediction order) / uploaded matches
     EkfMatch *msel = nullptr;    // matches selected for an update (inliers / rescued), update order
     EkfMatch *mout = nullptr;    // outlier matches
@@ -96,6 +98,18 @@ struct DeviceArrays {
     double *dx_part = nullptr; // DX_SPLIT x ldP
     uint8_t *mask = nullptr;   // generic byte mask output (rescue)
     void *pu_tilemap = nullptr; // int2 (ti, tj) per upper-triangle tile, XCD-friendly order
+};
+
+// current frame of the NCC matcher: gray pyramid (level 0 = full resolution) + the raw upload staging buffer
+struct Image {
+    uint8_t *px[3] = {nullptr, nullptr, nullptr};
+    int w[3] = {0, 0, 0}, h[3] = {0, 0, 0};
+    uint8_t *raw = nullptr;
+    size_t raw_cap = 0;
+    bool valid = false;
+    // staged sequence (ekf_images_upload)
+    uint8_t *seq = nullptr;
+    int seq_n = 0, seq_w = 0, seq_h = 0, seq_stride = 0, seq_channels = 0;
 };
 
 struct Frames {
@@ -124,6 +138,7 @@ struct EkfEngine {
     hipStream_t stream = nullptr;
     ekf::DeviceArrays d;
     ekf::Frames frames;
+    ekf::Image img;
     std::string err;
     // timing
     bool timing = false;
@@ -157,6 +172,9 @@ void launch_add_features(EkfEngine *e, const double *d_uv, int count, double *d_
 void launch_compact_P(EkfEngine *e, int n_new, const int *d_new2old);
 void launch_linearity(EkfEngine *e, double *d_out);
 void launch_convert(EkfEngine *e, int fi, int pos, double *d_J, double *d_T3);
+void launch_ncc_pyramid(EkfEngine *e, const uint8_t *d_raw, int stride, int channels);
+void launch_ncc_capture(EkfEngine *e, const int *d_idx, const double *d_uv, int count);
+void launch_match_ncc(EkfEngine *e, int n_pred);
 void launch_map_update(EkfEngine *e, const EkfMatch *d_sel, int count, const uint8_t *d_kdesc);
 
 } // namespace ekf

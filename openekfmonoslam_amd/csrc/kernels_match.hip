@@ -5,62 +5,9 @@
 // one workgroup per prediction, keypoints strided over the lanes, candidates replayed in keypoint order so the
 // order-dependent list logic gives the reference's answer.
 #include "engine.h"
+#include "gate.h"
 
 namespace ekf {
-
-// cv::eigen of a symmetric 2x2 (Jacobi, eigenvalues descending, eigenvectors as rows) + the ellipse of
-// matrix2x2ToUncertaintyEllipse2D: float semi-axes, angle = atan(V[1][0] / V[0][0]).
-__device__ void ellipse_from_cov(const double *S, float *axes, double *angle)
-{
-    double A01 = S[1], W0 = S[0], W1 = S[3];
-    double V[4] = {1, 0, 0, 1};
-    for (int it = 0; it < 120; ++it) {
-        const double p = A01;
-        if (fabs(p) <= 2.220446049250313e-16) break;
-        const double y = (W1 - W0) * 0.5;
-        double t = fabs(y) + hypot(p, y);
-        double s = hypot(p, t);
-        const double c = t / s;
-        s = p / s;
-        t = (p / t) * p;
-        if (y < 0) { s = -s; t = -t; }
-        A01 = 0;
-        W0 -= t;
-        W1 += t;
-        for (int i = 0; i < 2; ++i) {
-            const double a0 = V[i], b0 = V[2 + i];
-            V[i] = a0 * c - b0 * s;
-            V[2 + i] = a0 * s + b0 * c;
-        }
-    }
-    if (W0 < W1) {
-        double t = W0; W0 = W1; W1 = t;
-        for (int i = 0; i < 2; ++i) { t = V[i]; V[i] = V[2 + i]; V[2 + i] = t; }
-    }
-    axes[0] = (float)(2.0 * sqrt(W0 * EKF_CHISQ_95_2));
-    axes[1] = (float)(2.0 * sqrt(W1 * EKF_CHISQ_95_2));
-    *angle = atan(V[2] / V[0]);
-}
-
-struct Gate {
-    double f1x, f1y, f2x, f2y, two_major;
-};
-
-// foci of the integer-axes ellipse (pointIsInsideEllipse, Core/EKFMath.cpp:302-334)
-__device__ void gate_from_ellipse(float cx, float cy, int aw, int ah, double angle, Gate *g)
-{
-    const double major = aw > ah ? aw : ah;
-    const double minor = aw < ah ? aw : ah;
-    const double fo = sqrt(major * major - minor * minor);
-    if (ah < aw) {
-        g->f1x = fo * cos(angle) + cx;  g->f1y = fo * sin(angle) + cy;
-        g->f2x = -fo * cos(angle) + cx; g->f2y = -fo * sin(angle) + cy;
-    } else {
-        g->f1x = fo * (-sin(angle)) + cx;  g->f1y = fo * cos(angle) + cy;
-        g->f2x = -fo * (-sin(angle)) + cx; g->f2y = -fo * cos(angle) + cy;
-    }
-    g->two_major = 2 * major;
-}
 
 __global__ void __launch_bounds__(256)
 k_match(const int *plist, const double *uv_tab, const double *S_tab, const uint8_t *feat_desc,
@@ -144,7 +91,7 @@ k_match(const int *plist, const double *uv_tab, const double *S_tab, const uint8
 // compacted match list in prediction order (matches.push_back order, Matching.cpp:247-262)
 __global__ void __launch_bounds__(1024)
 k_match_compact(const int *plist, int n_pred, const int *mt_valid, const int *mt_kp, const float *mt_dist,
-                const EkfKeypoint *kps, EkfMatch *out, int *out_count)
+                const EkfKeypoint *kps, int by_slot, EkfMatch *out, int *out_count)
 {
     __shared__ int part[1024];
     const int tid = threadIdx.x;
@@ -165,9 +112,11 @@ k_match_compact(const int *plist, int n_pred, const int *mt_valid, const int *mt
         if (mt_valid[i]) {
             EkfMatch m;
             m.featureIndex = plist[i];
-            m.keypointIndex = mt_kp[i];
-            m.imagePos[0] = (double)kps[mt_kp[i]].x;
-            m.imagePos[1] = (double)kps[mt_kp[i]].y;
+            // by_slot (NCC matcher): the matched pixel sits in kps[prediction slot]; there is no keypoint index
+            const int kp = by_slot ? i : mt_kp[i];
+            m.keypointIndex = by_slot ? -1 : kp;
+            m.imagePos[0] = (double)kps[kp].x;
+            m.imagePos[1] = (double)kps[kp].y;
             m.distance = mt_dist[i];
             m._pad = 0.f;
             out[pos++] = m;
@@ -185,7 +134,13 @@ void launch_match(EkfEngine *e, int n_pred, int n_kp)
                                            e->d.kdesc, n_kp, e->cfg.par.matchingCompCoefSecondBestVSFirst,
                                            e->d.mt_valid, e->d.mt_kp, e->d.mt_dist);
     k_match_compact<<<1, 1024, 0, e->stream>>>(e->d.plist, n_pred, e->d.mt_valid, e->d.mt_kp, e->d.mt_dist,
-                                               e->d.kps, e->d.matches, e->d.counts + CNT_NMATCH);
+                                               e->d.kps, 0, e->d.matches, e->d.counts + CNT_NMATCH);
+}
+
+void launch_match_compact_slots(EkfEngine *e, int n_pred, const EkfKeypoint *d_slot_xy)
+{
+    k_match_compact<<<1, 1024, 0, e->stream>>>(e->d.plist, n_pred, e->d.mt_valid, e->d.mt_kp, e->d.mt_dist, d_slot_xy,
+                                               1, e->d.matches, e->d.counts + CNT_NMATCH);
 }
 
 // match_of_feat[f] = smallest match index whose featureIndex is f, or -1 (the linear searches of

@@ -78,6 +78,14 @@ ABI = {
     "ekf_step": (_i, [_vp, _vp, _vp, _i, C.POINTER(EkfStepInfo)]),
     "ekf_frames_upload": (_i, [_vp, _i, _vp, _vp, _vp]),
     "ekf_step_frame": (_i, [_vp, _i, C.POINTER(EkfStepInfo)]),
+    "ekf_image_upload": (_i, [_vp, _vp, _i, _i, _i, _i]),
+    "ekf_get_image_level": (_i, [_vp, _i, _vp, C.POINTER(_i), C.POINTER(_i)]),
+    "ekf_capture_templates": (_i, [_vp, _vp, _vp, _i]),
+    "ekf_match_ncc": (_i, [_vp, _vp, C.POINTER(_i)]),
+    "ekf_step_image": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(EkfStepInfo)]),
+    "ekf_images_upload": (_i, [_vp, _i, _vp, _i, _i, _i, _i]),
+    "ekf_select_staged_image": (_i, [_vp, _i]),
+    "ekf_step_staged_image": (_i, [_vp, _i, C.POINTER(EkfStepInfo)]),
     "ekf_timing_enable": (_i, [_vp, _i]),
     "ekf_timing_reset": (_i, [_vp]),
     "ekf_timing_get": (_i, [_vp, C.POINTER(EkfStageTimes)]),
@@ -289,6 +297,60 @@ class EkfEngine:
     def step_frame(self, i):
         info = EkfStepInfo()
         self._chk(self.L.ekf_step_frame(self.h, int(i), C.byref(info)))
+        return info
+
+    # ---- matcher mode B (image in)
+    @staticmethod
+    def _image_args(image):
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        if img.ndim == 2:
+            h, w = img.shape
+            ch = 1
+        else:
+            h, w, ch = img.shape
+        return img, w, h, w * ch, ch
+
+    def upload_image(self, image):
+        img, w, h, stride, ch = self._image_args(image)
+        self._chk(self.L.ekf_image_upload(self.h, _p(img), w, h, stride, ch))
+
+    def image_level(self, level):
+        w, h = C.c_int(0), C.c_int(0)
+        self._chk(self.L.ekf_get_image_level(self.h, int(level), None, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), dtype=np.uint8)
+        self._chk(self.L.ekf_get_image_level(self.h, int(level), _p(out), C.byref(w), C.byref(h)))
+        return out
+
+    def capture_templates(self, feat_idx, uv):
+        idx = np.ascontiguousarray(feat_idx, dtype=np.int32)
+        uv = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
+        assert len(idx) == len(uv)
+        self._chk(self.L.ekf_capture_templates(self.h, _p(idx), _p(uv), len(idx)))
+
+    def match_ncc(self):
+        out = np.zeros(max(self.N, 1), dtype=MATCH_DTYPE)
+        n = C.c_int(0)
+        self._chk(self.L.ekf_match_ncc(self.h, _p(out), C.byref(n)))
+        return out[: n.value]
+
+    def step_image(self, image):
+        img, w, h, stride, ch = self._image_args(image)
+        info = EkfStepInfo()
+        self._chk(self.L.ekf_step_image(self.h, _p(img), w, h, stride, ch, C.byref(info)))
+        return info
+
+    def upload_images(self, images):
+        arr = np.ascontiguousarray(np.stack(images), dtype=np.uint8)
+        n = arr.shape[0]
+        _, w, h, stride, ch = self._image_args(arr[0])
+        self._chk(self.L.ekf_images_upload(self.h, n, _p(arr), w, h, stride, ch))
+
+    def select_staged_image(self, i):
+        self._chk(self.L.ekf_select_staged_image(self.h, int(i)))
+
+    def step_staged_image(self, i):
+        info = EkfStepInfo()
+        self._chk(self.L.ekf_step_staged_image(self.h, int(i), C.byref(info)))
         return info
 
     # ---- instrumentation

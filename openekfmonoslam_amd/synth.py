@@ -273,3 +273,61 @@ class SyntheticSequence:
     @property
     def state_dim(self):
         return 13 + 6 * self.n_features
+
+    # ---- images for matcher mode B (NCC): every point carries a fixed smooth texture patch, pasted at its rounded
+    # projection over a noisy background; frame 0 is the map-seeding frame the templates are cut from
+    def _textures(self, patch):
+        if getattr(self, "_tex", None) is not None and self._tex.shape[1] == patch:
+            return self._tex
+        rng = np.random.Generator(np.random.PCG64(0x7E87 + self.n_features))
+        N = self.n_features
+        g = rng.uniform(30.0, 225.0, (N, 5, 5))
+        xs = np.linspace(0.0, 4.0, patch)
+        i0 = np.minimum(xs.astype(int), 3)
+        fr = xs - i0
+        rows = g[:, i0, :] * (1 - fr)[None, :, None] + g[:, i0 + 1, :] * fr[None, :, None]
+        tex = rows[:, :, i0] * (1 - fr)[None, None, :] + rows[:, :, i0 + 1] * fr[None, None, :]
+        tex = tex + rng.normal(0.0, 8.0, tex.shape)
+        self._tex = np.clip(np.rint(tex), 0, 255).astype(np.uint8)
+        return self._tex
+
+    def pixel_positions(self, t):
+        """Integer pixel (x, y) each point's patch is centred on in frame t (t = 0: seeding frame)."""
+        R = quat_to_rot(self.truth_q[t])
+        uv, _ = project(self.cam, self.truth_r[t], R, self.points)
+        return np.rint(uv).astype(np.int64)
+
+    def render_image(self, t, patch=17, noise_sigma=2.0, outlier_fraction=0.05, channels=1):
+        """uint8 frame t: [H, W] (channels=1), [H, W, 3] BGR or [H, W, 4] RGBA."""
+        W, H = self.cam.pixelsX, self.cam.pixelsY
+        rng = np.random.Generator(np.random.PCG64(0x1A6E0000 + 977 * self.n_features + t))
+        img = rng.normal(118.0, 6.0, (H, W))
+        tex = self._textures(patch)
+        px = self.pixel_positions(t)
+        if t > 0 and outlier_fraction > 0:
+            gross = rng.random(self.n_features) < outlier_fraction
+            ang = rng.uniform(0, 2 * np.pi, self.n_features)
+            mag = rng.uniform(5.0, 12.0, self.n_features)
+            off = np.rint(np.stack([mag * np.cos(ang), mag * np.sin(ang)], -1)).astype(np.int64)
+            px = px + off * gross[:, None]
+        hp = patch // 2
+        for i in range(self.n_features):
+            x, y = int(px[i, 0]), int(px[i, 1])
+            x0, x1, y0, y1 = max(x - hp, 0), min(x + hp + 1, W), max(y - hp, 0), min(y + hp + 1, H)
+            if x0 >= x1 or y0 >= y1:
+                continue
+            img[y0:y1, x0:x1] = tex[i, y0 - (y - hp):y1 - (y - hp), x0 - (x - hp):x1 - (x - hp)]
+        img = img + rng.normal(0.0, noise_sigma, img.shape)
+        gray = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        if channels == 1:
+            return gray
+        out = np.zeros((H, W, channels), dtype=np.uint8)
+        # a colour cast per channel so the gray conversion is exercised (weights 77/150/29)
+        r = np.clip(gray.astype(np.int32) + 9, 0, 255)
+        g = gray.astype(np.int32)
+        b = np.clip(gray.astype(np.int32) - 14, 0, 255)
+        if channels == 3:
+            out[..., 0], out[..., 1], out[..., 2] = b, g, r
+        else:
+            out[..., 0], out[..., 1], out[..., 2], out[..., 3] = r, g, b, 255
+        return out

@@ -1096,6 +1096,172 @@ int orc_match(const OrcFilter *f, const EkfPrediction *preds, int n_pred, const 
     return nm;
 }
 
+
+/* ------------------------------------------------------------------------------------ NCC matcher (mode B) */
+/* The north star's patch matcher (ZNCC of an 11x11 template inside the predicted ellipse, coarse-to-fine over a
+ * 3-level pyramid) has NO counterpart in the reference (its matcher is detector + descriptor + gate,
+ * EKF/Matching.cpp:181-264).  This is the build's own definition, restated on the CPU so the HIP kernels can be
+ * checked bit-exactly: all image arithmetic is integer, the score is one fp64 multiply and one fp64 divide of
+ * exactly representable or identically rounded operands. */
+
+#define NCC_LEVELS 3
+#define NCC_R 5              /* template half size: 11 x 11 */
+#define NCC_T (2 * NCC_R + 1)
+#define NCC_MAXRAD 16        /* coarse search radius, pixels at the coarse level */
+
+typedef struct OrcImage {
+    int w[NCC_LEVELS], h[NCC_LEVELS];
+    uint8_t *px[NCC_LEVELS];
+} OrcImage;
+
+static OrcImage g_img; /* one current frame per process is enough for a test oracle */
+static uint8_t *g_tmpl; /* cap x levels x 121 */
+static int g_tmpl_cap;
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* gray = (77 R + 150 G + 29 B + 128) >> 8 for 3/4-channel input (BGR / RGBA byte order as the reference's two
+ * front ends deliver it: Img/FileSequenceImageGenerator.cpp:82, android jni/EKFNative.cpp:163-166), copy for 1 */
+int orc_image_set(const uint8_t *image, int w, int h, int stride, int channels)
+{
+    for (int l = 0; l < NCC_LEVELS; ++l) { free(g_img.px[l]); g_img.px[l] = NULL; }
+    g_img.w[0] = w; g_img.h[0] = h;
+    g_img.px[0] = (uint8_t *)malloc((size_t)w * h);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const uint8_t *p = image + (size_t)y * stride + (size_t)x * channels;
+            int g;
+            if (channels == 1) g = p[0];
+            else if (channels == 3) g = (77 * p[2] + 150 * p[1] + 29 * p[0] + 128) >> 8;      /* B G R */
+            else g = (77 * p[0] + 150 * p[1] + 29 * p[2] + 128) >> 8;                          /* R G B A */
+            g_img.px[0][(size_t)y * w + x] = (uint8_t)g;
+        }
+    for (int l = 1; l < NCC_LEVELS; ++l) {
+        int pw = g_img.w[l - 1], ww = pw / 2, hh = g_img.h[l - 1] / 2;
+        g_img.w[l] = ww; g_img.h[l] = hh;
+        g_img.px[l] = (uint8_t *)malloc((size_t)ww * hh + 1);
+        const uint8_t *s2 = g_img.px[l - 1];
+        for (int y = 0; y < hh; ++y)
+            for (int x = 0; x < ww; ++x)
+                g_img.px[l][(size_t)y * ww + x] = (uint8_t)((s2[(size_t)(2 * y) * pw + 2 * x] + s2[(size_t)(2 * y) * pw + 2 * x + 1] +
+                                                             s2[(size_t)(2 * y + 1) * pw + 2 * x] + s2[(size_t)(2 * y + 1) * pw + 2 * x + 1] + 2) >> 2);
+    }
+    return EKF_OK;
+}
+
+const uint8_t *orc_image_level(int level, int *w, int *h)
+{
+    *w = g_img.w[level]; *h = g_img.h[level];
+    return g_img.px[level];
+}
+
+static int img_at(int l, int x, int y)
+{
+    x = clampi(x, 0, g_img.w[l] - 1);
+    y = clampi(y, 0, g_img.h[l] - 1);
+    return g_img.px[l][(size_t)y * g_img.w[l] + x];
+}
+
+/* level-l pixel that contains level-0 coordinate u: floor((u + 0.5) / 2^l) */
+static int to_level(double u, int l) { return (int)floor((u + 0.5) / (double)(1 << l)); }
+
+/* templates of the listed features from the CURRENT image, centred on the pixel containing uv at each level */
+int orc_capture_templates(OrcFilter *f, const int32_t *feat_idx, const double *uv, int count)
+{
+    if (g_tmpl_cap < f->cap) {
+        free(g_tmpl);
+        g_tmpl = (uint8_t *)calloc((size_t)f->cap * NCC_LEVELS * NCC_T * NCC_T, 1);
+        g_tmpl_cap = f->cap;
+    }
+    for (int i = 0; i < count; ++i)
+        for (int l = 0; l < NCC_LEVELS; ++l) {
+            int cx = to_level(uv[2 * i], l), cy = to_level(uv[2 * i + 1], l);
+            uint8_t *t = g_tmpl + ((size_t)feat_idx[i] * NCC_LEVELS + l) * NCC_T * NCC_T;
+            for (int dy = -NCC_R; dy <= NCC_R; ++dy)
+                for (int dx = -NCC_R; dx <= NCC_R; ++dx) t[(dy + NCC_R) * NCC_T + dx + NCC_R] = (uint8_t)img_at(l, cx + dx, cy + dy);
+        }
+    return EKF_OK;
+}
+
+const uint8_t *orc_templates(void) { return g_tmpl; }
+
+/* key of a candidate: num^2 / den if the correlation numerator is positive, -1 otherwise (den == 0: flat window) */
+static double ncc_key(int l, const uint8_t *t, int cx, int cy)
+{
+    long long sw = 0, sww = 0, swt = 0, st = 0, stt = 0;
+    for (int dy = -NCC_R; dy <= NCC_R; ++dy)
+        for (int dx = -NCC_R; dx <= NCC_R; ++dx) {
+            int w = img_at(l, cx + dx, cy + dy), tv = t[(dy + NCC_R) * NCC_T + dx + NCC_R];
+            sw += w; sww += w * w; swt += w * tv; st += tv; stt += tv * tv;
+        }
+    const long long n = NCC_T * NCC_T;
+    long long num = n * swt - sw * st;
+    long long den = (n * sww - sw * sw) * (n * stt - st * st);
+    if (num <= 0 || den <= 0) return -1.0;
+    double dn = (double)num;
+    return dn * dn / (double)den;
+}
+
+/* One prediction.  Returns 1 and the level-0 pixel + key when matched. */
+static int ncc_match_one(const OrcFilter *f, const EkfPrediction *p, int *mx, int *my, double *mkey)
+{
+    float axes[2];
+    double angle;
+    orc_ellipse(p->covarianceMatrix, axes, &angle);
+    int aw = (int)lrintf(axes[0]), ah = (int)lrintf(axes[1]);
+    float cxf = (float)p->imagePos[0], cyf = (float)p->imagePos[1];
+    const uint8_t *tb = g_tmpl + (size_t)p->featureIndex * NCC_LEVELS * NCC_T * NCC_T;
+    /* coarse level: every pixel of the (clamped) window whose centre, mapped to level 0, lies inside the ellipse */
+    int L = NCC_LEVELS - 1;
+    int c2x = to_level(p->imagePos[0], L), c2y = to_level(p->imagePos[1], L);
+    int major = aw > ah ? aw : ah;
+    int rad = (major >> L) + 1;
+    if (rad > NCC_MAXRAD) rad = NCC_MAXRAD;
+    int bx = c2x, by = c2y;
+    double bkey = -3.0;
+    for (int y = c2y - rad; y <= c2y + rad; ++y)
+        for (int x = c2x - rad; x <= c2x + rad; ++x) {
+            if (x < 0 || y < 0 || x >= g_img.w[L] || y >= g_img.h[L]) continue;
+            float x0 = (float)((x + 0.5) * (1 << L) - 0.5), y0 = (float)((y + 0.5) * (1 << L) - 0.5);
+            if (!(x == c2x && y == c2y) && !orc_point_in_ellipse(x0, y0, cxf, cyf, aw, ah, angle)) continue;
+            double k = ncc_key(L, tb + (size_t)L * NCC_T * NCC_T, x, y);
+            if (k > bkey) { bkey = k; bx = x; by = y; }
+        }
+    /* refinement: the 4 x 4 block of children around the best parent, no gate */
+    for (int l = L - 1; l >= 0; --l) {
+        int px = bx, py = by;
+        bkey = -3.0;
+        for (int y = 2 * py - 1; y <= 2 * py + 2; ++y)
+            for (int x = 2 * px - 1; x <= 2 * px + 2; ++x) {
+                if (x < 0 || y < 0 || x >= g_img.w[l] || y >= g_img.h[l]) continue;
+                double k = ncc_key(l, tb + (size_t)l * NCC_T * NCC_T, x, y);
+                if (k > bkey) { bkey = k; bx = x; by = y; }
+            }
+    }
+    *mx = bx; *my = by; *mkey = bkey;
+    /* accept: ZNCC >= 0.8 (key = zncc^2 >= 0.64) and the pixel inside the gate ellipse */
+    return bkey >= 0.64 && orc_point_in_ellipse((float)bx, (float)by, cxf, cyf, aw, ah, angle);
+}
+
+int orc_match_ncc(const OrcFilter *f, const EkfPrediction *preds, int n_pred, EkfMatch *out)
+{
+    int nm = 0;
+    for (int i = 0; i < n_pred; ++i) {
+        int x, y;
+        double key;
+        if (ncc_match_one(f, &preds[i], &x, &y, &key)) {
+            out[nm].featureIndex = preds[i].featureIndex;
+            out[nm].keypointIndex = -1;
+            out[nm].imagePos[0] = (double)x;
+            out[nm].imagePos[1] = (double)y;
+            out[nm].distance = (float)(1.0 - sqrt(key));
+            out[nm]._pad = 0.f;
+            ++nm;
+        }
+    }
+    return nm;
+}
+
 /* ------------------------------------------------------------------------------------------ state update */
 
 /* stateUpdate: EKF/Update.cpp:147-204 -- apply K*nu with the DELTA dead-band on every component */
@@ -1496,8 +1662,8 @@ int orc_rescue(const OrcFilter *f, const EkfMatch *matches, const EkfPrediction 
 /* -------------------------------------------------------------------------------------------------- step */
 
 /* EKF::step: EKF/EKF.cpp:242-556 with a fixed map (map management :572-612 and logging are out of scope) */
-int orc_step(OrcFilter *f, const EkfKeypoint *kps, const uint8_t *desc32, int n_kp, int variant,
-             OrcStepInfo *info)
+static int orc_step_impl(OrcFilter *f, const EkfKeypoint *kps, const uint8_t *desc32, int n_kp, int variant,
+                         OrcStepInfo *info, int use_ncc)
 {
     int N = f->N, status = EKF_OK;
     OrcStepInfo li;
@@ -1518,7 +1684,7 @@ int orc_step(OrcFilter *f, const EkfKeypoint *kps, const uint8_t *desc32, int n_
     li.n_predicted = np;
     /* updateMapFeatures, first loop (EKF/MapManagement.cpp:81-86): every predicted feature counts */
     for (int k = 0; k < np; ++k) f->ftimes_predicted[preds[k].featureIndex]++;
-    int M = orc_match(f, preds, np, kps, desc32, n_kp, matches);             /* :337 */
+    int M = use_ncc ? orc_match_ncc(f, preds, np, matches) : orc_match(f, preds, np, kps, desc32, n_kp, matches); /* :337 */
     li.n_matches = M;
     /* predictions/Jacobians re-ordered to match order :368-392 */
     for (int i = 0; i < M; ++i) {
@@ -1555,7 +1721,7 @@ int orc_step(OrcFilter *f, const EkfKeypoint *kps, const uint8_t *desc32, int n_
     for (int i = 0; i < ni; ++i) {
         int fi = sel[i].featureIndex;
         f->ftimes_matched[fi]++;
-        memcpy(&f->fdesc[(size_t)fi * EKF_DESC_BYTES], &desc32[(size_t)sel[i].keypointIndex * EKF_DESC_BYTES], EKF_DESC_BYTES);
+        if (!use_ncc) memcpy(&f->fdesc[(size_t)fi * EKF_DESC_BYTES], &desc32[(size_t)sel[i].keypointIndex * EKF_DESC_BYTES], EKF_DESC_BYTES);
     }
     int st = orc_update(f, sel, preds, Hs, Hf, ni, variant);                 /* :430 */
     if (st != EKF_OK) status = st;
@@ -1587,7 +1753,7 @@ int orc_step(OrcFilter *f, const EkfKeypoint *kps, const uint8_t *desc32, int n_
     for (int i = 0; i < nr; ++i) { /* rescued matches join the inliers (EKF.cpp:552-556) */
         int fi = sel[i].featureIndex;
         f->ftimes_matched[fi]++;
-        memcpy(&f->fdesc[(size_t)fi * EKF_DESC_BYTES], &desc32[(size_t)sel[i].keypointIndex * EKF_DESC_BYTES], EKF_DESC_BYTES);
+        if (!use_ncc) memcpy(&f->fdesc[(size_t)fi * EKF_DESC_BYTES], &desc32[(size_t)sel[i].keypointIndex * EKF_DESC_BYTES], EKF_DESC_BYTES);
     }
     if (nr > 0) {                                                            /* :529-532 */
         st = orc_update(f, sel, preds, Hs, Hf, nr, variant);
@@ -1598,6 +1764,17 @@ int orc_step(OrcFilter *f, const EkfKeypoint *kps, const uint8_t *desc32, int n_
     free(preds); free(Hs); free(Hf); free(matches); free(mp); free(mHs); free(mHf); free(sel); free(mask);
     free(oidx); free(outl);
     return status;
+}
+
+int orc_step(OrcFilter *f, const EkfKeypoint *kps, const uint8_t *desc32, int n_kp, int variant, OrcStepInfo *info)
+{
+    return orc_step_impl(f, kps, desc32, n_kp, variant, info, 0);
+}
+
+/* EKF::step with the NCC matcher on the current image (orc_image_set); templates stay fixed */
+int orc_step_image(OrcFilter *f, int variant, OrcStepInfo *info)
+{
+    return orc_step_impl(f, NULL, NULL, 0, variant, info, 1);
 }
 
 /* --------------------------------------------------------------------------------------- timing helper */

@@ -125,6 +125,15 @@ int orc_rescue(const OrcFilter *f, const EkfMatch *matches, const EkfPrediction 
 int orc_step(OrcFilter *f, const EkfKeypoint *kps, const uint8_t *desc32, int n_kp, int variant,
              OrcStepInfo *info);
 
+/* NCC matcher (mode B: 11x11 ZNCC inside the predicted ellipse, 3-level pyramid, coarse-to-fine).  No reference
+ * counterpart -- the build's own definition (see ekf_oracle.c); one current image per process. */
+int orc_image_set(const uint8_t *image, int w, int h, int stride, int channels);
+const uint8_t *orc_image_level(int level, int *w, int *h);
+int orc_capture_templates(OrcFilter *f, const int32_t *feat_idx, const double *uv, int count);
+const uint8_t *orc_templates(void);
+int orc_match_ncc(const OrcFilter *f, const EkfPrediction *preds, int n_pred, EkfMatch *out);
+int orc_step_image(OrcFilter *f, int variant, OrcStepInfo *info);
+
 /* Timing helper for bench.py's cpu_baseline: runs the three dense products of the LITERAL covariance update
  * (K H, I - K H, (I - K H) P ; EKF/Update.cpp:214-218) restricted to the first `rows` rows of the result and
  * returns the wall seconds spent.  K is n x m, H is m x n, P is n x n, all random-filled by the caller. */

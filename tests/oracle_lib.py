@@ -58,6 +58,13 @@ def lib():
         L.orc_update.argtypes = [vp, vp, vp, vp, vp, i32, i32]
         L.orc_rescue.argtypes = [vp, vp, vp, i32, vp]
         L.orc_step.argtypes = [vp, vp, vp, i32, i32, vp]
+        L.orc_image_set.argtypes = [vp, i32, i32, i32, i32]
+        L.orc_image_level.restype = C.POINTER(C.c_uint8)
+        L.orc_image_level.argtypes = [i32, C.POINTER(i32), C.POINTER(i32)]
+        L.orc_capture_templates.argtypes = [vp, vp, vp, i32]
+        L.orc_templates.restype = C.POINTER(C.c_uint8)
+        L.orc_match_ncc.argtypes = [vp, vp, i32, vp]
+        L.orc_step_image.argtypes = [vp, i32, vp]
         L.orc_time_literal_rows.restype = C.c_double
         L.orc_time_literal_rows.argtypes = [i32, i32, i32, vp, vp, vp, vp]
         _lib = L
@@ -230,6 +237,42 @@ class Oracle:
         desc = np.ascontiguousarray(desc, dtype=np.uint8)
         info = EkfStepInfo()
         self.L.orc_step(self.h, _p(kps), _p(desc), len(kps), variant, C.byref(info))
+        return info
+
+
+    # -- matcher mode B (one current image per process)
+    def set_image(self, image):
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        if img.ndim == 2:
+            h, w = img.shape
+            ch = 1
+        else:
+            h, w, ch = img.shape
+        assert self.L.orc_image_set(_p(img), w, h, w * ch, ch) == 0
+
+    def image_level(self, level):
+        w, h = C.c_int(0), C.c_int(0)
+        ptr = self.L.orc_image_level(int(level), C.byref(w), C.byref(h))
+        return np.ctypeslib.as_array(ptr, (h.value * w.value,)).copy().reshape(h.value, w.value)
+
+    def capture_templates(self, feat_idx, uv):
+        idx = np.ascontiguousarray(feat_idx, dtype=np.int32)
+        uv = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
+        assert self.L.orc_capture_templates(self.h, _p(idx), _p(uv), len(idx)) == 0
+
+    def templates(self):
+        return np.ctypeslib.as_array(self.L.orc_templates(), (self.N * 363,)).copy().reshape(self.N, 3, 11, 11)
+
+    def match_ncc(self, preds):
+        preds = np.ascontiguousarray(preds, dtype=PREDICTION_DTYPE)
+        out = np.zeros(max(len(preds), 1), dtype=MATCH_DTYPE)
+        k = self.L.orc_match_ncc(self.h, _p(preds), len(preds), _p(out))
+        return out[:k].copy()
+
+    def step_image(self, image, variant=LITERAL):
+        self.set_image(image)
+        info = EkfStepInfo()
+        self.L.orc_step_image(self.h, variant, C.byref(info))
         return info
 
 

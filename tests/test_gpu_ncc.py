@@ -1,0 +1,139 @@
+"""GPU parity of matcher mode B (image in, NCC over a pyramid): pyramid bytes, templates (through their effect on
+the matches), the match list and the full image step, HIP engine through the C ABI vs the CPU oracle.  Integer and
+index outputs (pyramid, matched pixels, match order, counts) must be identical; the fp64 state after image steps
+within F64_TOL."""
+import numpy as np
+import pytest
+
+from openekfmonoslam_amd.synth import SyntheticSequence
+from tests.oracle_lib import ALGORITHMIC
+from tests.test_gpu_parity import F32_TOL, F64_TOL, assert_state_close, eng_mod, make_pair  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("channels,w,h", [(1, 640, 480), (3, 322, 242), (4, 321, 243)])
+def test_pyramid_identical(eng_mod, oracle_lib, channels, w, h):
+    seq = SyntheticSequence(16, 1, width=w, height=h)
+    img = seq.render_image(0, channels=channels)
+    e, o = make_pair(eng_mod, oracle_lib, seq)
+    e.upload_image(img)
+    o.set_image(img)
+    for lvl in range(3):
+        np.testing.assert_array_equal(e.image_level(lvl), o.image_level(lvl))
+
+
+def _with_templates(eng_mod, oracle_lib, seq, precision=0):
+    e, o = make_pair(eng_mod, oracle_lib, seq, precision)
+    img0 = seq.render_image(0)
+    uv0 = seq.pixel_positions(0).astype(np.float64)
+    idx = np.arange(seq.n_features)
+    e.upload_image(img0)
+    e.capture_templates(idx, uv0)
+    o.set_image(img0)
+    o.capture_templates(idx, uv0)
+    return e, o
+
+
+@pytest.mark.parametrize("nfeat", [12, 50, 200])
+def test_match_ncc_identical(eng_mod, oracle_lib, nfeat):
+    seq = SyntheticSequence(nfeat, 3)
+    e, o = _with_templates(eng_mod, oracle_lib, seq)
+    for t in (1, 2):
+        e.predict()
+        o.predict()
+        e.predict_measurements()
+        preds, _, _ = o.predict_measurements()
+        img = seq.render_image(t)
+        e.upload_image(img)
+        o.set_image(img)
+        mg = e.match_ncc()
+        mo = o.match_ncc(preds)
+        assert len(mg) == len(mo) and len(mo) > 0.6 * nfeat
+        np.testing.assert_array_equal(mg["featureIndex"], mo["featureIndex"])
+        np.testing.assert_array_equal(mg["keypointIndex"], mo["keypointIndex"])
+        np.testing.assert_array_equal(mg["imagePos"], mo["imagePos"])
+        np.testing.assert_array_equal(mg["distance"], mo["distance"])
+
+
+def test_match_ncc_edge_images(eng_mod, oracle_lib):
+    """flat frame (zero variance), pure noise, and predictions whose windows hang over the border"""
+    seq = SyntheticSequence(40, 2, margin=2.0)
+    e, o = _with_templates(eng_mod, oracle_lib, seq)
+    e.predict()
+    o.predict()
+    e.predict_measurements()
+    preds, _, _ = o.predict_measurements()
+    rng = np.random.default_rng(11)
+    for img in (np.full((480, 640), 200, dtype=np.uint8), rng.integers(0, 256, (480, 640), dtype=np.uint8),
+                seq.render_image(1)):
+        e.upload_image(img)
+        o.set_image(img)
+        mg, mo = e.match_ncc(), o.match_ncc(preds)
+        assert len(mg) == len(mo)
+        np.testing.assert_array_equal(mg["featureIndex"], mo["featureIndex"])
+        np.testing.assert_array_equal(mg["imagePos"], mo["imagePos"])
+
+
+@pytest.mark.parametrize("nfeat,frames", [(50, 4), (200, 2)])
+def test_step_image_parity_f64(eng_mod, oracle_lib, nfeat, frames):
+    seq = SyntheticSequence(nfeat, frames)
+    e, o = _with_templates(eng_mod, oracle_lib, seq)
+    for t in range(1, frames + 1):
+        img = seq.render_image(t, channels=3 if t % 2 else 1)
+        gi = e.step_image(img)
+        oi = o.step_image(img, ALGORITHMIC)
+        for f in ("n_predicted", "n_matches", "n_hypotheses", "n_inliers", "n_outliers", "n_rescued", "status"):
+            assert getattr(gi, f) == getattr(oi, f), (t, f, getattr(gi, f), getattr(oi, f))
+        assert_state_close(e, o, F64_TOL, f"image step {t}")
+    _, tp, tm = e.get_map_features()
+    _, tpo, tmo = o.map_features()
+    np.testing.assert_array_equal(tp, tpo)
+    np.testing.assert_array_equal(tm, tmo)
+
+
+def test_staged_images_equal_direct_steps(eng_mod, oracle_lib):
+    seq = SyntheticSequence(50, 3)
+    e1, _ = _with_templates(eng_mod, oracle_lib, seq)
+    e2, _ = _with_templates(eng_mod, oracle_lib, seq)
+    imgs = [seq.render_image(t) for t in range(1, 4)]
+    e2.upload_images(imgs)
+    for t in range(3):
+        a = e1.step_image(imgs[t])
+        b = e2.step_staged_image(t)
+        assert (a.n_matches, a.n_inliers, a.n_rescued) == (b.n_matches, b.n_inliers, b.n_rescued)
+    x1, f1, P1 = e1.get_state()
+    x2, f2, P2 = e2.get_state()
+    np.testing.assert_array_equal(x1, x2)
+    np.testing.assert_array_equal(P1, P2)
+
+
+def test_templates_follow_map_compaction(eng_mod, oracle_lib):
+    seq = SyntheticSequence(30, 2)
+    e, o = _with_templates(eng_mod, oracle_lib, seq)
+    drop = np.array([3, 4, 17], dtype=np.int32)
+    e.remove_features(drop)
+    o.remove_features(drop)
+    # the oracle keeps templates per feature slot: re-capture the survivors from frame 0 at their new indices
+    keep = np.setdiff1d(np.arange(30), drop)
+    o.set_image(seq.render_image(0))
+    o.capture_templates(np.arange(len(keep)), seq.pixel_positions(0)[keep].astype(np.float64))
+    e.predict()
+    o.predict()
+    e.predict_measurements()
+    preds, _, _ = o.predict_measurements()
+    img = seq.render_image(1)
+    e.upload_image(img)
+    o.set_image(img)
+    mg, mo = e.match_ncc(), o.match_ncc(preds)
+    np.testing.assert_array_equal(mg["featureIndex"], mo["featureIndex"])
+    np.testing.assert_array_equal(mg["imagePos"], mo["imagePos"])
+
+
+def test_ncc_requires_an_image(eng_mod, oracle_lib):
+    seq = SyntheticSequence(12, 1)
+    e, _ = make_pair(eng_mod, oracle_lib, seq)
+    e.predict()
+    e.predict_measurements()
+    with pytest.raises(eng_mod.EkfError):
+        e.match_ncc()
