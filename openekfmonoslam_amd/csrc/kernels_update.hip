@@ -12,6 +12,7 @@
 // The reference forms K = P H' inv(S) with an LU inverse and multiplies the dense (I - K H) by P (2 n^3 flops);
 // both give the same x and P up to rounding (S is symmetric positive definite: R = pixelErrorX * I).
 #include "engine.h"
+#include "chol32.h"
 
 namespace ekf {
 
@@ -90,7 +91,7 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 // -------------------------------------------------------------------------------------- blocked Cholesky sweep
 // Right-looking sweep over [ S | nu ], panel width NB = 32.  The only serial piece is the 32x32 diagonal block:
 // its Cholesky factor and the inverse of that factor.  It is computed by ONE workgroup with all 256 threads working
-// in LDS (block_chol_inv32, one barrier per column) and -- look-ahead -- inside the trailing-update launch of the
+// in LDS (block_chol_inv32_bp in chol32.h: 4x4 block pivots, one barrier per block column) and -- look-ahead -- inside the trailing-update launch of the
 // PREVIOUS panel, by the workgroup that owns tile (k+1, k+1): while the other workgroups of that launch update
 // their tiles, this one finishes tile (k+1, k+1), factorises it and stores inv(L_{k+1,k+1}) into Dinv.  Per panel:
 //   panel : L_ik = S_ik inv(L_kk)' for the row blocks below (inverse read from Dinv), z_k = inv(L_kk) nu_k
@@ -98,65 +99,6 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 // B = inv(L) A is NOT part of the sweep: it is independent per column of A and runs afterwards as one launch
 // (k_trsm) on the MFMA pipe.
 
-// Forward elimination on the augmented block [A | I], all 256 threads of a workgroup: thread (r, g) keeps columns
-// 4g..4g+3 of row r of both halves in REGISTERS for the whole sweep; only what a step broadcasts travels through LDS
-// (the pivot column and the pivot row of the identity half, double-buffered, one barrier per column).
-//   a : 32x33 doubles in LDS, lower triangle of the SPD block (identity-padded rows beyond the live size)
-//   x : 32x33 doubles in LDS, receives inv(L) (zeros above the diagonal)
-// Scalings are deferred: updates use 1 / a[j][j]; inv(L)[r][:] = x[r][:] sqrt(1 / pivot_r) is applied at the end.
-// Returns false (uniformly) on a non-positive pivot.
-__device__ __forceinline__ bool block_chol_inv32(double (*a)[NB + 1], double (*x)[NB + 1], double *rs)
-{
-    __shared__ double colbuf[2][NB], rowbuf[2][NB];
-    const int t = threadIdx.x;
-    const int r = t >> 3, c0 = (t & 7) * 4;
-    double av[4], xv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        av[e] = (c0 + e <= r) ? a[r][c0 + e] : 0.0;
-        xv[e] = (r == c0 + e) ? 1.0 : 0.0;
-    }
-    if (c0 == 0) colbuf[0][r] = av[0];
-    if (r == 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rowbuf[0][c0 + e] = xv[e];
-    }
-    __syncthreads();
-    bool ok = true;
-    for (int j = 0; j < NB; ++j) {
-        const int p = j & 1;
-        const double djj = colbuf[p][j];
-        ok = ok && (djj > 0.0);
-        const double inv = 1.0 / (djj > 0.0 ? djj : 1.0);
-        if (t == 0) rs[j] = inv;
-        if (r > j) {
-            const double arj = colbuf[p][r] * inv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = c0 + e;
-                if (c > j && c <= r) av[e] -= arj * colbuf[p][c];
-                if (c <= j) xv[e] -= arj * rowbuf[p][c];
-            }
-        }
-        const int jn = j + 1;
-        if (jn < NB) { // publish column j+1 of the A half and row j+1 of the identity half for the next step
-            const int e = jn - c0;
-            if (e >= 0 && e < 4 && r >= jn) colbuf[p ^ 1][r] = e == 0 ? av[0] : (e == 1 ? av[1] : (e == 2 ? av[2] : av[3]));
-            if (r == jn) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rowbuf[p ^ 1][c0 + q] = xv[q];
-            }
-        }
-        __syncthreads();
-    }
-    const double sr = sqrt(rs[r]);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) x[r][c0 + e] = (c0 + e <= r) ? xv[e] * sr : 0.0;
-    __syncthreads();
-    return ok;
-}
-
-// store inv(L_kk) (32x32, in LDS) into the block-diagonal inverse: Dinv is [m_pad256 x 256], row (k0 + r) holds
 // its 256-block's row
 __device__ __forceinline__ void store_linv(double *Dinv, int k0, const double (*x)[NB + 1])
 {
@@ -170,13 +112,13 @@ __device__ __forceinline__ void store_linv(double *Dinv, int k0, const double (*
 // first panel only: factorise block 0
 __global__ void __launch_bounds__(256) k_chol_diag0(const double *S, int ldS, int kb, double *Dinv, int *counts)
 {
-    __shared__ double sa[NB][NB + 1], sx[NB][NB + 1], srs[NB];
+    __shared__ double sa[NB][NB + 1], sx[NB][NB + 1];
     for (int i = threadIdx.x; i < NB * NB; i += 256) {
         const int r = i / NB, c = i % NB;
         sa[r][c] = (r < kb && c <= r) ? S[(size_t)r * ldS + c] : ((r == c) ? 1.0 : 0.0);
     }
     __syncthreads();
-    if (!block_chol_inv32(sa, sx, srs) && threadIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
+    if (!block_chol_inv32_bp(sa, sx) && threadIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
     store_linv(Dinv, 0, sx);
 }
 
@@ -229,7 +171,6 @@ k_chol_trailing(double *S, int ldS, int m, int k0, int kb, double *nu, int n_sti
 {
     __shared__ double sA[NB][NB + 1];
     __shared__ double sB[NB][NB + 1];
-    __shared__ double srs[NB];
     const int tid = threadIdx.x;
     const int k1 = k0 + kb;
     const int b = blockIdx.x;
@@ -270,7 +211,7 @@ k_chol_trailing(double *S, int ldS, int m, int k0, int kb, double *nu, int n_sti
             sA[r][c] = live ? v[q] : ((r == c) ? 1.0 : 0.0);
         }
         __syncthreads();
-        if (!block_chol_inv32(sA, sB, srs) && tid == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
+        if (!block_chol_inv32_bp(sA, sB) && tid == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
         store_linv(Dinv, k1, sB);
         return;
     }
