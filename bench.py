@@ -75,6 +75,21 @@ def cpu_baseline(seq, workload):
     }
 
 
+def committed_pmc_traffic(workload):
+    """HBM bytes per k_p_update launch from the committed rocprofv3 PMC summary of this workload (FETCH_SIZE and
+    WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950 -- scripts/profile_summary.py); counters cannot be read
+    from inside an un-profiled run, so the figure is the profile's, named in traffic_source; null without one."""
+    import glob
+    import re
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "profiles", f"r*_pmc_hbm_p_update_{workload}.csv")), reverse=True):
+        with open(path) as f:
+            m = re.search(r"# mean per launch: .* total ([0-9.]+) MB", f.read())
+        if m:
+            return float(m.group(1)) * 1e6, os.path.relpath(path, here)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,6 +140,7 @@ def main():
     elapsed = ranks.max_over_ranks(elapsed)
 
     roof, stages = None, None
+    pmc_traffic = committed_pmc_traffic(args.workload)
     if not args.no_roofline_pass:
         _, _ = run(True)
         tm = eng.timing_get()
@@ -139,7 +155,8 @@ def main():
                 "peak": PEAK_TFLOPS[dtype],
                 "unit": "TFLOP/s",
                 "frac": ach / PEAK_TFLOPS[dtype],
-                "traffic": None,
+                "traffic": pmc_traffic[0],
+                "traffic_source": pmc_traffic[1],
                 "avg_launch_ms": avg_ms,
                 "launches": int(tm.p_update_launches),
                 "algorithmic_flops_per_launch": flops,

@@ -7,9 +7,9 @@ def kernel_stats(db_path, out_path, limit=40):
     cur = sqlite3.connect(db_path).cursor()
     rows = list(cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
     with open(out_path, "w") as f:
-        f.write("kernel,calls,total_us,avg_us,percent\n")
+        f.write("kernel,calls,total_ms,avg_us,percent\n")
         for name, calls, total, avg, pct in rows[:limit]:
-            f.write(f"\"{name}\",{calls},{total / 1e3:.1f},{avg / 1e3:.2f},{pct:.2f}\n")
+            f.write(f"\"{name}\",{calls},{total / 1e3:.2f},{avg:.2f},{pct:.2f}\n")
 
 
 def pmc(db_path, counter, like="%k_p_update%"):
