@@ -96,6 +96,12 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="n1000_f32", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
+                    help="N > 1: independent replicas (default; the path does not shard at N <= 1000) or ONE filter "
+                         "row-sharded over the ranks (SURVEY 8(e), meant for N >= 2000)")
+    ap.add_argument("--emulate-shards", type=int, default=0,
+                    help="functional check on ONE GPU: run the sharded filter with this many ranks in one process "
+                         "(device-to-device exchange); not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-pass", action="store_true")
     args = ap.parse_args()
@@ -115,22 +121,47 @@ def main():
     N, W, H, precision, dtype = WORKLOADS[args.workload]
     n_frames = args.warmup + args.steps
     seq = SyntheticSequence(N, n_frames, width=W, height=H)
-    eng = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=precision,
-                           device=local_rank)
-    eng.upload_frames(seq.frames)
+    sharded = args.mode == "sharded" and world > 1
+    emulate = args.emulate_shards if world == 1 else 0
+    kw = dict(max_keypoints=len(seq.frames[0][0]) + 64, precision=precision, device=local_rank)
+    group = None
+    if emulate > 1:
+        from openekfmonoslam_amd.shard import LocalShardGroup
+
+        group = LocalShardGroup(seq.cam, seq.par, N, emulate, **kw)
+        eng = group.engines[0]
+        for e in group.engines:
+            e.upload_frames(seq.frames)
+    else:
+        eng = engine.EkfEngine(seq.cam, seq.par, N, shard=(rank, world) if sharded else None, **kw)
+        if sharded:
+            from openekfmonoslam_amd.shard import DistributedExchange
+
+            eng.set_exchange(DistributedExchange(ranks.dist, ranks.device))
+        eng.upload_frames(seq.frames)
+    P0 = 0.5 * (seq.P0 + seq.P0.T) if (sharded or group) else seq.P0
 
     def run(timing):
-        eng.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
-        eng.timing(timing)
-        infos = []
-        for t in range(args.warmup):
-            eng.step_frame(t)
-        eng.timing_reset()
+        for e in (group.engines if group else [eng]):
+            e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, P0)
+            e.timing(timing)
+
+        def frames(e, lo, hi):
+            return [e.step_frame(t) for t in range(lo, hi)]
+
+        if group:
+            group.run(lambda r, e: frames(e, 0, args.warmup))
+        else:
+            frames(eng, 0, args.warmup)
+        for e in (group.engines if group else [eng]):
+            e.timing_reset()
         ranks.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for t in range(args.warmup, n_frames):
-            infos.append(eng.step_frame(t))
+        if group:
+            infos = group.run(lambda r, e: frames(e, args.warmup, n_frames))[0]
+        else:
+            infos = frames(eng, args.warmup, n_frames)
         torch.cuda.synchronize()
         ranks.barrier()
         torch.cuda.synchronize()
@@ -149,7 +180,8 @@ def main():
             flops = tm.p_update_flops / tm.p_update_launches
             ach = flops / (avg_ms * 1e-3) / 1e12
             roof = {
-                "kernel": "k_p_update (P <- sym(P) - B'B, upper-triangle tiles)",
+                "kernel": ("k_p_update (P <- sym(P) - B'B, upper-triangle tiles)" if not (sharded or group) else
+                           "k_p_update RECT (owned row tiles of P <- P - B'B), rank 0"),
                 "bound": "mfma",
                 "achieved": ach,
                 "peak": PEAK_TFLOPS[dtype],
@@ -161,7 +193,7 @@ def main():
                 "launches": int(tm.p_update_launches),
                 "algorithmic_flops_per_launch": flops,
             }
-        if roof is not None:
+        if roof is not None and not (sharded or group):
             mm, mss = eng.p_update_launches()
             n_state = 13 + 6 * N
             big = mm >= 512
@@ -182,7 +214,17 @@ def main():
     if rank != 0:
         ranks.close()
         return
-    value = world * args.steps / elapsed
+    # replicas: every rank ran its own filter (weak scaling); sharded: all ranks advanced ONE filter (strong scaling)
+    value = (1 if sharded else world) * args.steps / elapsed
+    if world == 1 and not group:
+        par_desc = "single GPU"
+    elif group:
+        par_desc = (f"{emulate} row shards of ONE filter emulated on ONE GPU (device-to-device exchange; functional "
+                    "check, not a scaling number)")
+    elif sharded:
+        par_desc = f"ONE filter row-sharded over {world} GPUs (camera rows replicated, H.P row blocks all-gathered over RCCL)"
+    else:
+        par_desc = f"{world} independent replicas (path does not shard at this N)"
     out = {
         "metric": "EKF updates/s (frames/s) at N features",
         "value": value,
@@ -192,7 +234,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if sharded else "weak",
         "vs_baseline": None,
         "dtype": dtype,
         "data": "synthetic",
@@ -201,7 +243,7 @@ def main():
                         f"{'fp32' if precision else 'fp64'} covariance, {len(seq.frames[0][0])} keypoints/frame, "
                         "fixed map",
             "name": args.workload,
-            "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (path does not shard at this N)",
+            "parallelism": par_desc,
             "mean_matches": float(np.mean([i.n_matches for i in infos])),
             "mean_li_inliers": float(np.mean([i.n_inliers for i in infos])),
             "mean_rescued": float(np.mean([i.n_rescued for i in infos])),
@@ -210,7 +252,7 @@ def main():
         "roofline": roof,
         "stage_ms_per_step": stages,
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not group and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(seq, args.workload)
     else:
         out["cpu_baseline"] = None

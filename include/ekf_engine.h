@@ -194,7 +194,29 @@ int ekf_synchronize(EkfEngine *e);
  * HIP-event duration in ms.  Writes at most `capacity` entries; *count receives the number available. */
 int ekf_timing_p_update_launches(EkfEngine *e, int capacity, int32_t *m_rows, float *ms, int *count);
 
-/* -- partition of the covariance rows across ranks (multi-GPU); pure host arithmetic -------- */
+/* -- row-sharded filter (multi-GPU) ----------------------------------------------------------
+ * One engine per GPU / rank.  Rank g stores the 13 camera rows of P (replicated, updated identically everywhere)
+ * and the rows of the features [f0_g, f1_g) it owns, each with all n columns; everything else (state, map, H.P rows,
+ * S, its factor, B) is replicated.  Owned rows are predicted, multiplied (H_f P) and downdated locally; the one
+ * exchange per prediction is an all-gather of the H.P row blocks (and of the 2x2 S_i of the owned features), done by
+ * the callback the host installs: RCCL broadcasts/all-gather between processes, device-to-device copies when
+ * several ranks share a GPU (tests).  Map management is not available on a sharded engine. */
+typedef int (*EkfExchangeFn)(void *user, int what, void *device_base, size_t row_bytes, const int32_t *row_begin,
+                             int world, int rank);
+enum { EKF_XCHG_HP = 0, EKF_XCHG_PRED_S = 1 };
+/* what: which replicated table is being completed; device_base: its first row on this rank's GPU; rank r owns rows
+ * [row_begin[r], row_begin[r+1]) of row_bytes each and has just written them.  The callback returns when this
+ * rank's table holds every rank's rows (0 = ok).  It is called with the engine's stream idle. */
+int ekf_engine_create_sharded(const EkfEngineConfig *cfg, int rank, int world, EkfEngine **out);
+int ekf_set_exchange(EkfEngine *e, EkfExchangeFn fn, void *user);
+/* P rows held by this rank: [*row_begin, *row_end) of the state (rank 0's range starts at 0: the camera rows,
+ * which every rank also keeps).  On a sharded engine ekf_set_state takes the full n x n matrix and keeps its rows;
+ * ekf_get_state fills only those rows of the caller's n x n buffer (camera rows + owned rows). */
+int ekf_shard_info(const EkfEngine *e, int *rank, int *world, int *row_begin, int *row_end);
+/* device-to-device copy on the engine's device, synchronous: the exchange primitive when ranks share a GPU */
+int ekf_device_copy(EkfEngine *e, void *dst, const void *src, size_t bytes);
+
+/* -- partition of the covariance rows across ranks; pure host arithmetic ------------------------------------- */
 /* Row block [row_begin, row_end) of P owned by `rank` of `world` for a map of n_features inverse-depth features:
  * the 13 camera rows go to rank 0, features are split contiguously. */
 int ekf_shard_rows(int n_features, int world, int rank, int *row_begin, int *row_end);

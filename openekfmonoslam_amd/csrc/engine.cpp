@@ -65,7 +65,7 @@ void ekf_engine_destroy(EkfEngine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     DeviceArrays &d = e->d;
     void *ptrs[] = {d.state,     d.feat_pos,  d.feat_type, d.feat_covpos, d.feat_desc, d.feat_times_predicted, d.feat_times_matched, d.P, d.P2, d.mm_scratch, d.mm_index,        d.pred_vis,
-                    d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,       d.HPc,      d.Ac,
+                    d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,
                     d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
                     d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.Tbuf,
@@ -83,9 +83,9 @@ void ekf_engine_destroy(EkfEngine *e)
     delete e;
 }
 
-int ekf_engine_create(const EkfEngineConfig *cfg, EkfEngine **out)
+static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngine **out)
 {
-    if (!cfg || !out || cfg->max_features <= 0) return EKF_ERR_INVALID_ARG;
+    if (!cfg || !out || cfg->max_features <= 0 || world < 1 || rank < 0 || rank >= world) return EKF_ERR_INVALID_ARG;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return EKF_ERR_NO_DEVICE;
@@ -102,6 +102,8 @@ int ekf_engine_create(const EkfEngineConfig *cfg, EkfEngine **out)
     e->par = ParD{p.linearAccelSD, p.angularAccelSD, p.matchingCompCoefSecondBestVSFirst,
                   p.ransacThresholdPredictDistance, p.ransacAllInliersProbability, p.ransacChi2Threshold};
     e->f32 = cfg->precision == EKF_PRECISION_F32;
+    e->shard_rank = rank;
+    e->shard_world = world;
     e->cap = cfg->max_features;
     e->ncap = 13 + 6 * e->cap;
     e->mcap = round_up(2 * e->cap, NB);
@@ -131,11 +133,15 @@ int ekf_engine_create(const EkfEngineConfig *cfg, EkfEngine **out)
     ALLOC(d.feat_times_matched, cap);
     {
         uint8_t *raw = nullptr;
-        if ((st = dalloc(&raw, (size_t)round_up(e->ncap, LD_ALIGN) * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc P");
+        // rows of P kept here: all of them, or (sharded) camera block + the largest share of the features
+        e->p_rows_cap = world == 1 ? round_up(e->ncap, LD_ALIGN)
+                                   : SHARD_BASE + round_up(6 * ((e->cap + world - 1) / world), LD_ALIGN) + LD_ALIGN;
+        if ((st = dalloc(&raw, (size_t)e->p_rows_cap * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc P");
         d.P = raw;
         if ((st = dalloc(&raw, (size_t)mcap * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc HP");
         d.HP = raw;
-        if ((st = dalloc(&raw, (size_t)mcap * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc A");
+        // + one row: the row operand of a sharded downdate tile may read up to 127 columns past n
+        if ((st = dalloc(&raw, (size_t)(mcap + 1) * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc A");
         d.A = raw;
     }
     ALLOC(d.mm_scratch, (size_t)60 * cap + 4 * (size_t)e->ldP + 64);
@@ -147,8 +153,6 @@ int ekf_engine_create(const EkfEngineConfig *cfg, EkfEngine **out)
     ALLOC(d.pred_S, 4 * cap);
     ALLOC(d.Hs, 14 * cap);
     ALLOC(d.Hf, 12 * cap);
-    ALLOC(d.HPc, (size_t)mcap * CS);
-    ALLOC(d.Ac, (size_t)round_up((int)mcap, TB) * CS);
     ALLOC(d.work_idx, cap);
     ALLOC(d.work_flag, cap);
     ALLOC(d.plist, cap);
@@ -183,9 +187,66 @@ int ekf_engine_create(const EkfEngineConfig *cfg, EkfEngine **out)
     for (auto &ev : e->ev)
         if ((st = hipEventCreate(&ev)) != hipSuccess) return fail(st, "hipEventCreate");
     e->h_counts.assign(CNT_COUNT, 0);
+    e->shard_feat_begin.assign(world + 1, 0);
     *out = e;
     return EKF_OK;
 }
+
+int ekf_engine_create(const EkfEngineConfig *cfg, EkfEngine **out) { return create_impl(cfg, 0, 1, out); }
+
+int ekf_engine_create_sharded(const EkfEngineConfig *cfg, int rank, int world, EkfEngine **out)
+{
+    return create_impl(cfg, rank, world, out);
+}
+
+int ekf_set_exchange(EkfEngine *e, EkfExchangeFn fn, void *user)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    e->xchg = fn;
+    e->xchg_user = user;
+    return EKF_OK;
+}
+
+int ekf_shard_info(const EkfEngine *e, int *rank, int *world, int *row_begin, int *row_end)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    if (rank) *rank = e->shard_rank;
+    if (world) *world = e->shard_world;
+    if (row_begin) *row_begin = e->shard_rank == 0 ? 0 : e->rm.r0;
+    if (row_end) *row_end = e->rm.r1;
+    return EKF_OK;
+}
+
+int ekf_device_copy(EkfEngine *e, void *dst, const void *src, size_t bytes)
+{
+    if (!e || (bytes > 0 && (!dst || !src))) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    if (bytes > 0) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+    return EKF_OK;
+}
+
+// feature partition of a sharded engine (same arithmetic as ekf_shard_rows) and the row map that follows from it
+static void refresh_row_map(EkfEngine *e)
+{
+    const int W = e->shard_world, N = e->N;
+    if (W == 1) {
+        e->rm = RowMap{13, e->n, 13};
+        e->shard_feat_begin.assign(2, 0);
+        e->shard_feat_begin[1] = N;
+        return;
+    }
+    const int per = N / W, extra = N % W;
+    for (int r = 0; r <= W; ++r) e->shard_feat_begin[r] = r * per + (r < extra ? r : extra);
+    const int f0 = e->shard_feat_begin[e->shard_rank], f1 = e->shard_feat_begin[e->shard_rank + 1];
+    auto row_of = [&](int f) { return f < N ? e->h_covpos[f] : e->n; };
+    e->rm = RowMap{row_of(f0), row_of(f1), SHARD_BASE};
+}
+
+#define NOT_WHEN_SHARDED(e)                                                \
+    if ((e)->shard_world > 1) {                                            \
+        (e)->err = "map management is not available on a sharded engine";  \
+        return EKF_ERR_INVALID_ARG;                                        \
+    }
 
 int ekf_get_map_features(EkfEngine *e, uint8_t *desc32, uint32_t *times_predicted, uint32_t *times_matched)
 {
@@ -248,27 +309,48 @@ int ekf_set_state(EkfEngine *e, const double x13[13], int n_features, const doub
         else
             HIPCHK(hipMemset(e->d.feat_desc, 0, (size_t)n_features * EKF_DESC_BYTES));
     }
-    if (P) {
-        const size_t w = e->f32 ? 4 : 8;
-        HIPCHK(hipMemset(e->d.P, 0, (size_t)round_up(e->ncap, LD_ALIGN) * e->ldP * w));
-        if (e->f32) {
-            std::vector<float> tmp((size_t)n * n);
-            for (size_t i = 0; i < (size_t)n * n; ++i) tmp[i] = (float)P[i];
-            HIPCHK(hipMemcpy2D(e->d.P, (size_t)e->ldP * 4, tmp.data(), (size_t)n * 4, (size_t)n * 4, n,
-                               hipMemcpyHostToDevice));
-        } else {
-            HIPCHK(hipMemcpy2D(e->d.P, (size_t)e->ldP * 8, P, (size_t)n * 8, (size_t)n * 8, n, hipMemcpyHostToDevice));
-        }
-        e->p_exact_sym = false;
-    }
-    HIPCHK(hipMemset(e->d.pred_vis, 0, (size_t)e->cap * sizeof(int)));
-    HIPCHK(hipMemset(e->d.feat_times_predicted, 0, (size_t)e->cap * sizeof(unsigned)));
-    HIPCHK(hipMemset(e->d.feat_times_matched, 0, (size_t)e->cap * sizeof(unsigned)));
     e->N = n_features;
     e->n = n;
     e->n_pred = 0;
     e->h_type = type;
     e->h_covpos = covpos;
+    refresh_row_map(e);
+    if (e->shard_world > 1 && SHARD_BASE + (e->rm.r1 - e->rm.r0) > e->p_rows_cap) return EKF_ERR_CAPACITY;
+    if (P) {
+        const size_t w = e->f32 ? 4 : 8;
+        HIPCHK(hipMemset(e->d.P, 0, (size_t)e->p_rows_cap * e->ldP * w));
+        const bool sharded = e->shard_world > 1;
+        // row blocks to upload: (first global row, count, first local row)
+        const int blocks[2][3] = {{0, sharded ? 13 : n, 0}, {e->rm.r0, sharded ? e->rm.r1 - e->rm.r0 : 0, e->rm.base}};
+        std::vector<float> tmp;
+        std::vector<double> sym;
+        for (const auto &b : blocks) {
+            const int g0 = b[0], cnt = b[1], l0 = b[2];
+            if (cnt <= 0) continue;
+            const double *src = P + (size_t)g0 * n;
+            if (sharded) { // no cross-rank averaging pass exists: symmetrise on the way in, in T arithmetic
+                sym.resize((size_t)cnt * n);
+                for (int i = 0; i < cnt; ++i)
+                    for (int j = 0; j < n; ++j) {
+                        const double a = P[(size_t)(g0 + i) * n + j], c = P[(size_t)j * n + g0 + i];
+                        sym[(size_t)i * n + j] = e->f32 ? (double)(0.5f * (float)a + 0.5f * (float)c) : 0.5 * a + 0.5 * c;
+                    }
+                src = sym.data();
+            }
+            uint8_t *dst = (uint8_t *)e->d.P + (size_t)l0 * e->ldP * w;
+            if (e->f32) {
+                tmp.resize((size_t)cnt * n);
+                for (size_t i = 0; i < (size_t)cnt * n; ++i) tmp[i] = (float)src[i];
+                HIPCHK(hipMemcpy2D(dst, (size_t)e->ldP * 4, tmp.data(), (size_t)n * 4, (size_t)n * 4, cnt, hipMemcpyHostToDevice));
+            } else {
+                HIPCHK(hipMemcpy2D(dst, (size_t)e->ldP * 8, src, (size_t)n * 8, (size_t)n * 8, cnt, hipMemcpyHostToDevice));
+            }
+        }
+        e->p_exact_sym = sharded;
+    }
+    HIPCHK(hipMemset(e->d.pred_vis, 0, (size_t)e->cap * sizeof(int)));
+    HIPCHK(hipMemset(e->d.feat_times_predicted, 0, (size_t)e->cap * sizeof(unsigned)));
+    HIPCHK(hipMemset(e->d.feat_times_matched, 0, (size_t)e->cap * sizeof(unsigned)));
     return EKF_OK;
 }
 
@@ -282,13 +364,22 @@ int ekf_get_state(EkfEngine *e, double x13[13], double *feature_pos, double *P)
         HIPCHK(hipMemcpy(feature_pos, e->d.feat_pos, (size_t)6 * e->N * sizeof(double), hipMemcpyDeviceToHost));
     if (P) {
         const int n = e->n;
-        if (e->f32) {
-            std::vector<float> tmp((size_t)n * n);
-            HIPCHK(hipMemcpy2D(tmp.data(), (size_t)n * 4, e->d.P, (size_t)e->ldP * 4, (size_t)n * 4, n,
-                               hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < (size_t)n * n; ++i) P[i] = (double)tmp[i];
-        } else {
-            HIPCHK(hipMemcpy2D(P, (size_t)n * 8, e->d.P, (size_t)e->ldP * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost));
+        const size_t w = e->f32 ? 4 : 8;
+        const bool sharded = e->shard_world > 1;
+        const int blocks[2][3] = {{0, sharded ? 13 : n, 0}, {e->rm.r0, sharded ? e->rm.r1 - e->rm.r0 : 0, e->rm.base}};
+        std::vector<float> tmp;
+        for (const auto &b : blocks) { // a sharded engine fills the rows it holds and leaves the others untouched
+            const int g0 = b[0], cnt = b[1], l0 = b[2];
+            if (cnt <= 0) continue;
+            const uint8_t *src = (const uint8_t *)e->d.P + (size_t)l0 * e->ldP * w;
+            double *dst = P + (size_t)g0 * n;
+            if (e->f32) {
+                tmp.resize((size_t)cnt * n);
+                HIPCHK(hipMemcpy2D(tmp.data(), (size_t)n * 4, src, (size_t)e->ldP * 4, (size_t)n * 4, cnt, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < (size_t)cnt * n; ++i) dst[i] = (double)tmp[i];
+            } else {
+                HIPCHK(hipMemcpy2D(dst, (size_t)n * 8, src, (size_t)e->ldP * 8, (size_t)n * 8, cnt, hipMemcpyDeviceToHost));
+            }
         }
     }
     return EKF_OK;
@@ -328,6 +419,7 @@ int ekf_add_features(EkfEngine *e, const double *uv, const uint8_t *desc32, int 
 {
     if (!e || count < 0 || (count > 0 && !uv)) return EKF_ERR_INVALID_ARG;
     if (count == 0) return EKF_OK;
+    NOT_WHEN_SHARDED(e)
     if (e->N + count > e->cap) return EKF_ERR_CAPACITY;
     HIPCHK(hipSetDevice(e->device));
     double *d_uv = e->d.mm_scratch, *d_Jpo = d_uv + 2 * (size_t)e->cap, *d_Jhr = d_Jpo + 42 * (size_t)count;
@@ -345,6 +437,7 @@ int ekf_add_features(EkfEngine *e, const double *uv, const uint8_t *desc32, int 
     e->N += count;
     e->n += 6 * count;
     e->n_pred = 0;
+    refresh_row_map(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     return check_async(e);
 }
@@ -352,6 +445,7 @@ int ekf_add_features(EkfEngine *e, const double *uv, const uint8_t *desc32, int 
 // drop the listed rows (sorted row flags) from P and the listed features from the SoA arrays
 static int compact_map(EkfEngine *e, const std::vector<uint8_t> &drop_feature, const std::vector<uint8_t> &drop_row)
 {
+    NOT_WHEN_SHARDED(e)
     const int N = e->N, n = e->n;
     std::vector<int> new2old;
     for (int i = 0; i < n; ++i)
@@ -406,6 +500,7 @@ static int compact_map(EkfEngine *e, const std::vector<uint8_t> &drop_feature, c
     }
     e->N = w;
     e->n = n_new;
+    refresh_row_map(e);
     e->n_pred = 0;
     return check_async(e);
 }
@@ -450,6 +545,7 @@ int ekf_convert_inverse_depth_to_depth(EkfEngine *e, int *converted_index)
     if (!e) return EKF_ERR_INVALID_ARG;
     if (converted_index) *converted_index = -1;
     if (e->N == 0) return EKF_OK;
+    NOT_WHEN_SHARDED(e)
     HIPCHK(hipSetDevice(e->device));
     double *d_li = e->d.mm_scratch;
     launch_linearity(e, d_li);
@@ -506,6 +602,25 @@ static int predict_measurements_dev(EkfEngine *e, const int *d_idx, int count, i
     launch_hp_rows(e, d_idx ? e->d.plist_sub : e->d.plist, np);
     if (!d_idx) e->n_pred = np;
     *n_out = np;
+    if (e->shard_world > 1 && np > 0) {
+        // every rank wrote the H.P rows and S_i of the features it owns: complete both tables
+        if (!e->xchg) {
+            e->err = "sharded engine without an exchange callback (ekf_set_exchange)";
+            return EKF_ERR_COMM;
+        }
+        HIPCHK(hipStreamSynchronize(e->stream));
+        std::vector<int32_t> rb(e->shard_world + 1);
+        for (int r = 0; r <= e->shard_world; ++r) rb[r] = 2 * e->shard_feat_begin[r];
+        if (e->xchg(e->xchg_user, EKF_XCHG_HP, e->d.HP, (size_t)e->ldP * (e->f32 ? 4 : 8), rb.data(), e->shard_world, e->shard_rank)) {
+            e->err = "exchange of the H.P row blocks failed";
+            return EKF_ERR_COMM;
+        }
+        for (int r = 0; r <= e->shard_world; ++r) rb[r] = e->shard_feat_begin[r];
+        if (e->xchg(e->xchg_user, EKF_XCHG_PRED_S, e->d.pred_S, 4 * sizeof(double), rb.data(), e->shard_world, e->shard_rank)) {
+            e->err = "exchange of the innovation covariance blocks failed";
+            return EKF_ERR_COMM;
+        }
+    }
     return check_async(e);
 }
 

@@ -14,10 +14,20 @@ namespace ekf {
 constexpr int NB = 32;          // Cholesky panel width
 constexpr int TB = 256;         // row block of the triangular solve B = inv(L) A
 constexpr int LD_ALIGN = 128;   // leading dimensions are multiples of this many elements
-constexpr int CS = 16;          // width of the fp64 camera strip kept beside the fp32 work matrices
 constexpr int DX_SPLIT = 16;    // k-splits of the dx = B' z reduction
 
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// Row storage of P.  A rank keeps the 13 camera rows (replicated on every rank) at local rows 0..12 and the
+// global rows [r0, r1) it owns from local row `base` on; every row holds ALL n columns.  Unsharded engine:
+// r0 = base = 13, r1 = n, i.e. the identity.  Sharded: base = SHARD_BASE so that the owned block
+// starts on a tile boundary of the downdate kernel.
+constexpr int SHARD_BASE = 128;
+struct RowMap {
+    int r0, r1, base;
+};
+__host__ __device__ inline int local_row(const RowMap &m, int i) { return i < 13 ? i : m.base + (i - m.r0); }
+__host__ __device__ inline bool owns_row(const RowMap &m, int i) { return i < 13 || (i >= m.r0 && i < m.r1); }
 
 // integer slots of the device counter block
 enum {
@@ -59,8 +69,6 @@ struct DeviceArrays {
     double *Hs = nullptr;      // 2x7 per feature
     double *Hf = nullptr;      // 2x6 per feature
     void *HP = nullptr;        // T [2*cap x ldP]: rows 2f, 2f+1 = H_f P
-    double *HPc = nullptr;     // fp64 copy of the first CS = 16 columns of HP (camera block), [2*cap x 16]
-    double *Ac = nullptr;      // fp64 camera strip of A / B, [mcap x 16]
     // work lists
     int *work_idx = nullptr;   // input feature indices of a subset prediction
     int *work_flag = nullptr;  // per work item: predicted?
@@ -130,6 +138,13 @@ struct EkfEngine {
     int ldP = 0, ldS = 0;
     int N = 0, n = 0;
     bool f32 = false;
+    // row sharding: world == 1 means the whole matrix lives here
+    int shard_rank = 0, shard_world = 1;
+    int p_rows_cap = 0;                  // rows allocated for P
+    ekf::RowMap rm{13, 13, 13};          // refreshed by set_state / map management
+    std::vector<int> shard_feat_begin;   // [world + 1] first feature of each rank
+    EkfExchangeFn xchg = nullptr;        // all-gather of per-feature row blocks between the ranks
+    void *xchg_user = nullptr;
     bool p_exact_sym = false; // P known to be bitwise symmetric (engine-maintained invariant)
     int n_pred = 0;           // predictions of the last full prediction
     int n_kp = 0;

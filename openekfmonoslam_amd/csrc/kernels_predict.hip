@@ -97,8 +97,11 @@ __global__ void k_predict_prepare(double *st, ParD par)
 // P[0:13,0:13] = F P F' + G Q G'; P[0:13,13:] = F P[0:13,13:]; P[13:,0:13] = P[13:,0:13] F'  (:226-239).
 // Block 0 owns the corner; every other thread owns one column j of the row strip and row j of the column strip
 // (13 coalesced loads + 13 contiguous loads).  The three regions are disjoint, so one launch updates in place.
+// Sharded storage (RowMap): the camera rows are replicated, so every rank computes the whole row strip; the column
+// strip only exists for the rows a rank owns.  Both strips are the same arithmetic on bitwise-equal operands, which
+// keeps P[a][j] on one rank identical to P[j][a] on the owner of row j.
 template <typename T>
-__global__ void __launch_bounds__(256) k_predict_cov(T *P, int ld, int n, const double *st)
+__global__ void __launch_bounds__(256) k_predict_cov(T *P, int ld, int n, const double *st, RowMap rm)
 {
     __shared__ double sF[169];
     __shared__ double sC[169];
@@ -130,11 +133,13 @@ __global__ void __launch_bounds__(256) k_predict_cov(T *P, int ld, int n, const 
     __syncthreads();
     const int j = 13 + (blockIdx.x - 1) * 256 + tid;
     if (j >= n) return;
+    const bool mine = owns_row(rm, j);
+    T *prow = P + (size_t)local_row(rm, j) * ld;
     double col[13], row[13];
 #pragma unroll
     for (int a = 0; a < 13; ++a) col[a] = (double)P[(size_t)a * ld + j];
 #pragma unroll
-    for (int a = 0; a < 13; ++a) row[a] = (double)P[(size_t)j * ld + a];
+    for (int a = 0; a < 13; ++a) row[a] = mine ? (double)prow[a] : 0.0;
 #pragma unroll
     for (int a = 0; a < 13; ++a) {
         double s = 0.0, t = 0.0;
@@ -144,7 +149,7 @@ __global__ void __launch_bounds__(256) k_predict_cov(T *P, int ld, int n, const 
             t += row[b] * sF[a * 13 + b];
         }
         P[(size_t)a * ld + j] = (T)s;
-        P[(size_t)j * ld + a] = (T)t;
+        if (mine) prow[a] = (T)t;
     }
 }
 
@@ -153,9 +158,9 @@ void launch_predict(EkfEngine *e)
     k_predict_prepare<<<1, 64, 0, e->stream>>>(e->d.state, e->par);
     const int nb = 1 + (e->n > 13 ? (e->n - 13 + 255) / 256 : 0);
     if (e->f32)
-        k_predict_cov<float><<<nb, 256, 0, e->stream>>>((float *)e->d.P, e->ldP, e->n, e->d.state);
+        k_predict_cov<float><<<nb, 256, 0, e->stream>>>((float *)e->d.P, e->ldP, e->n, e->d.state, e->rm);
     else
-        k_predict_cov<double><<<nb, 256, 0, e->stream>>>((double *)e->d.P, e->ldP, e->n, e->d.state);
+        k_predict_cov<double><<<nb, 256, 0, e->stream>>>((double *)e->d.P, e->ldP, e->n, e->d.state, e->rm);
 }
 
 // ------------------------------------------------------------------------------------------------------ A3
@@ -241,7 +246,7 @@ void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool sta
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, const int *feat_covpos,
-          const double *Hs_tab, const double *Hf_tab, T *HP, double *S_tab, double *HPc)
+          const double *Hs_tab, const double *Hf_tab, T *HP, double *S_tab, RowMap rm)
 {
     __shared__ double sH[26];     // Hs (2x7) then Hf (2x6)
     __shared__ double sHP[2][13]; // fp64 H P at columns 0..6 and pos..pos+d-1
@@ -249,6 +254,8 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
     const int tid = threadIdx.x;
     const int d = feat_dim(feat_type[fi]);
     const int pos = feat_covpos[fi];
+    if (!owns_row(rm, pos)) return; // sharded: the owner of the feature's rows computes them, the exchange delivers them
+    const T *Pf = P + (size_t)local_row(rm, pos) * ld;
     if (tid < 14) sH[tid] = Hs_tab[14 * fi + tid];
     else if (tid < 26) sH[tid] = Hf_tab[12 * fi + tid - 14];
     __syncthreads();
@@ -257,7 +264,7 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
     for (int j = tid; j < n; j += 256) {
         double a0 = 0.0, a1 = 0.0;
         for (int a = 0; a < d; ++a) {
-            const double p = (double)P[(size_t)(pos + a) * ld + j];
+            const double p = (double)Pf[(size_t)a * ld + j];
             a0 += sH[14 + a] * p;
             a1 += sH[20 + a] * p;
         }
@@ -272,10 +279,6 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
         a1 += b1;
         o0[j] = (T)a0;
         o1[j] = (T)a1;
-        if (j < CS) { // fp64 copy of the camera columns (used by the fp32 configuration for the camera-state update)
-            HPc[(size_t)(2 * fi) * CS + j] = a0;
-            HPc[(size_t)(2 * fi + 1) * CS + j] = a1;
-        }
         if (j < 7) {
             sHP[0][j] = a0;
             sHP[1][j] = a1;
@@ -300,11 +303,11 @@ void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list)
     if (e->f32)
         k_hp_rows<float><<<n_list, 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
                                                         e->d.feat_covpos, e->d.Hs, e->d.Hf, (float *)e->d.HP,
-                                                        e->d.pred_S, e->d.HPc);
+                                                        e->d.pred_S, e->rm);
     else
         k_hp_rows<double><<<n_list, 256, 0, e->stream>>>((const double *)e->d.P, e->ldP, e->n, d_list,
                                                          e->d.feat_type, e->d.feat_covpos, e->d.Hs, e->d.Hf,
-                                                         (double *)e->d.HP, e->d.pred_S, e->d.HPc);
+                                                         (double *)e->d.HP, e->d.pred_S, e->rm);
 }
 
 // predictMeasurementState on the current state into an EkfPrediction array (device), all features.

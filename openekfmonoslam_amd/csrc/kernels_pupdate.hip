@@ -93,9 +93,13 @@ __device__ __forceinline__ void pu_slab(const T (*sIb)[TMc], const T (*sJb)[TMc]
 #ifndef PU_MIN_WAVES
 #define PU_MIN_WAVES 3
 #endif
-template <typename T, bool AVG>
+// RECT (row-sharded storage): the rank owns row tiles, not a triangle.  Tile row 0 is the replicated
+// camera block (13 live rows), tile row t >= 1 holds the owned global rows rm.r0 + (t-1) TM ..., stored from local
+// row rm.base + (t-1) TM; every (row tile, column tile) pair is computed and written in place, nothing is mirrored.
+// Swapping the operands of an MFMA product changes no bit, so P[i][j] here equals P[j][i] on the rank that owns j.
+template <typename T, bool AVG, bool RECT>
 __global__ void __launch_bounds__(256, PU_MIN_WAVES)
-k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, const int4 *units)
+k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, const int4 *units, RowMap rm)
 {
     using M = Mma<T>;
     constexpr int MB = M::MB, TM = 4 * MB, KI = 64 / MB, VEC = M::VEC;
@@ -115,8 +119,11 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
     if (unit.x < 0) return;
     const int ti = unit.x, tj = unit.y;
     const bool full = unit.z < 0;
-    const bool diag = (ti == tj);
-    const int I0 = ti * TM, J0 = tj * TM;
+    const bool diag = RECT || (ti == tj);
+    // I0: first global row of the tile (= column of B for the row operand); p_off: local minus global row
+    const int I0 = RECT ? (ti == 0 ? 0 : rm.r0 + (ti - 1) * TM) : ti * TM, J0 = tj * TM;
+    const int p_off = RECT ? (ti == 0 ? 0 : rm.base - rm.r0) : 0;
+    const int ilim = RECT ? (ti == 0 ? 13 : rm.r1) : n;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv >> 1, wc = wv & 1;
@@ -195,7 +202,7 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
 #pragma unroll
                 for (int r = 0; r < M::NACC; ++r) {
                     const int gi = bi + M::row(r, lane), gj = bj + M::col(lane);
-                    if (gi < n && gj < n && gi <= gj) {
+                    if (!RECT && gi < n && gj < n && gi <= gj) {
                         T *pu = P + (size_t)gi * ldp + gj;
                         T *pl = P + (size_t)gj * ldp + gi;
                         const T v = ((T)0.5 * (*pu) + (T)0.5 * (*pl)) - cc[r];
@@ -210,8 +217,8 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
                 const int li = M::row(r, lane), lj = M::col(lane);
                 const int gi = bi + li, gj = bj + lj;
                 T v = (T)0;
-                if (gi < n && gj < n) {
-                    T *pu = P + (size_t)gi * ldp + gj;
+                if (gi < ilim && gj < n) {
+                    T *pu = P + (size_t)(gi + p_off) * ldp + gj;
                     v = *pu - cc[r];
                     *pu = v;
                 }
@@ -233,17 +240,26 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
         }
 }
 
-// host-built work list.  Tiles: super-tiles of 8 x 8 tiles, row-major inside, upper triangle only.  The tail
-// (ntiles mod #CUs tiles, i.e. what would occupy only part of the chip for a whole tile time) is split into half units.
-static void build_units(EkfEngine *e, int nt)
+// host-built work list.  Tiles: super-tiles of 8 x 8 tiles, row-major inside; upper triangle only (whole matrix on
+// one GPU) or all nrt x nt tiles of the owned row tiles (RECT).  The tail (ntiles mod #CUs tiles, i.e. what would
+// occupy only part of the chip for a whole tile time) is split into half units.
+static void build_units(EkfEngine *e, int nt, int nrt, bool rect)
 {
-    if (e->pu_tilemap_nt == nt && e->d.pu_tilemap) return;
+    const int key = rect ? -(nt * 4096 + nrt) : nt;
+    if (e->pu_tilemap_nt == key && e->d.pu_tilemap) return;
     std::vector<int4> tiles;
     const int ST = 8, NCU = 256, NX = 8;
-    for (int si = 0; si < nt; si += ST)
-        for (int sj = si; sj < nt; sj += ST)
-            for (int i = si; i < si + ST && i < nt; ++i)
-                for (int j = (sj > i ? sj : i); j < sj + ST && j < nt; ++j) tiles.push_back(make_int4(i, j, -1, 0));
+    if (rect) {
+        for (int si = 0; si < nrt; si += ST)
+            for (int sj = 0; sj < nt; sj += ST)
+                for (int i = si; i < si + ST && i < nrt; ++i)
+                    for (int j = sj; j < sj + ST && j < nt; ++j) tiles.push_back(make_int4(i, j, -1, 0));
+    } else {
+        for (int si = 0; si < nt; si += ST)
+            for (int sj = si; sj < nt; sj += ST)
+                for (int i = si; i < si + ST && i < nt; ++i)
+                    for (int j = (sj > i ? sj : i); j < sj + ST && j < nt; ++j) tiles.push_back(make_int4(i, j, -1, 0));
+    }
     const int ntiles = (int)tiles.size();
     const int n_full = ntiles >= NCU ? (ntiles / NCU) * NCU : 0;
     std::vector<int4> halves;
@@ -263,8 +279,22 @@ static void build_units(EkfEngine *e, int nt)
     (void)hipMalloc((void **)&e->d.pu_tilemap, table.size() * sizeof(int4));
     (void)hipMemcpyAsync(e->d.pu_tilemap, table.data(), table.size() * sizeof(int4), hipMemcpyHostToDevice, e->stream);
     (void)hipStreamSynchronize(e->stream);
-    e->pu_tilemap_nt = nt;
+    e->pu_tilemap_nt = key;
     e->pu_per_xcd = per;
+}
+
+template <typename T>
+static void launch_p_update_t(EkfEngine *e, int m_pad, int grid, const int4 *tm, bool avg, bool rect)
+{
+    hipStream_t s = e->stream;
+    T *P = (T *)e->d.P;
+    const T *B = (const T *)e->d.A;
+    if (rect)
+        k_p_update<T, false, true><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm);
+    else if (avg)
+        k_p_update<T, true, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm);
+    else
+        k_p_update<T, false, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm);
 }
 
 void launch_p_update(EkfEngine *e, int m_pad)
@@ -273,9 +303,11 @@ void launch_p_update(EkfEngine *e, int m_pad)
     const int n = e->n;
     const int TM = e->f32 ? 128 : 64;
     const int nt = (n + TM - 1) / TM;
-    build_units(e, nt);
+    const bool rect = e->shard_world > 1;
+    const int owned = e->rm.r1 - e->rm.r0;
+    const int nrt = 1 + (owned + TM - 1) / TM; // camera tile + owned row tiles
+    build_units(e, nt, nrt, rect);
     const int grid = e->pu_per_xcd * 8;
-    const int ntiles = e->pu_per_xcd;
     const int4 *tm = (const int4 *)e->d.pu_tilemap;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (e->timing) {
@@ -284,25 +316,13 @@ void launch_p_update(EkfEngine *e, int m_pad)
         (void)hipEventRecord(e0, s);
     }
     const bool avg = !e->p_exact_sym;
-    if (e->f32) {
-        if (avg)
-            k_p_update<float, true><<<grid, 256, 0, s>>>((float *)e->d.P, e->ldP, n, (const float *)e->d.A, e->ldP, m_pad,
-                                                        ntiles, tm);
-        else
-            k_p_update<float, false><<<grid, 256, 0, s>>>((float *)e->d.P, e->ldP, n, (const float *)e->d.A, e->ldP,
-                                                         m_pad, ntiles, tm);
-    } else {
-        if (avg)
-            k_p_update<double, true><<<grid, 256, 0, s>>>((double *)e->d.P, e->ldP, n, (const double *)e->d.A, e->ldP,
-                                                         m_pad, ntiles, tm);
-        else
-            k_p_update<double, false><<<grid, 256, 0, s>>>((double *)e->d.P, e->ldP, n, (const double *)e->d.A, e->ldP,
-                                                          m_pad, ntiles, tm);
-    }
+    if (e->f32) launch_p_update_t<float>(e, m_pad, grid, tm, avg, rect);
+    else launch_p_update_t<double>(e, m_pad, grid, tm, avg, rect);
     if (e->timing) {
         (void)hipEventRecord(e1, s);
         e->pu_events.emplace_back(e0, e1);
-        e->pu_work.push_back((double)n * (double)n * (double)m_pad);
+        // flops of this launch / 1 (n^2 m counts the symmetric downdate; a rank computes owned x n x m x 2 / 2)
+        e->pu_work.push_back(rect ? (double)(owned + 13) * (double)n * (double)m_pad * 2.0 : (double)n * (double)n * (double)m_pad);
         e->pu_m.push_back(m_pad);
     }
     e->p_exact_sym = true;

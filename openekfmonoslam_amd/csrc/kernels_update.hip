@@ -23,7 +23,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
          const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
-         double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Ac)
+         double *mHs, double *mHf, int *mpos, int *mdim)
 {
     const int row = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -32,7 +32,6 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
         const int i = row >> 1, r = row & 1;
         const int fi = matches[i].featureIndex;
         if (j < n_pad) A[(size_t)row * ld + j] = HP[(size_t)(2 * fi + r) * ld + j];
-        if (j < CS) Ac[(size_t)row * CS + j] = HPc[(size_t)(2 * fi + r) * CS + j];
         if (blockIdx.x == 0 && r == 0) {
             const int t = threadIdx.x;
             if (t < 14) mHs[14 * i + t] = Hs_tab[14 * fi + t];
@@ -47,7 +46,6 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
         }
     } else if (row < m_pad) {
         if (j < n_pad) A[(size_t)row * ld + j] = (T)0;
-        if (j < CS) Ac[(size_t)row * CS + j] = 0.0;
         if (blockIdx.x == 0 && threadIdx.x == 0) nu[row] = 0.0;
     }
 }
@@ -405,25 +403,6 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
     part[(size_t)ks * ldpart + j] = s;
 }
 
-// fp32 configuration: the 13 camera components of dx from the fp64 strip Bc = inv(L) (H P)[:, 0:16], so the camera
-// state does not inherit the rounding accumulated in the fp32 forward substitution.  Overwrites the partial sums
-// of columns 0..12.
-__global__ void __launch_bounds__(1024) k_dx_cam(const double *Bc, int m, const double *z, double *part, int ldpart)
-{
-    __shared__ double red[64][CS + 1];
-    const int j = threadIdx.x % CS, g = threadIdx.x / CS; // 64 row groups x 16 columns
-    double s = 0.0;
-    for (int k = g; k < m; k += 64) s += Bc[(size_t)k * CS + j] * z[k];
-    red[g][j] = s;
-    __syncthreads();
-    if (threadIdx.x < 13) {
-        double t = 0.0;
-        for (int q = 0; q < 64; ++q) t += red[q][threadIdx.x];
-        part[threadIdx.x] = t;
-        for (int ks = 1; ks < DX_SPLIT; ++ks) part[(size_t)ks * ldpart + threadIdx.x] = 0.0;
-    }
-}
-
 // stateUpdate (Update.cpp:147-204): x += dx with the DELTA dead-band on every component; R(q) recomputed from
 // the un-normalised q (:168).
 __global__ void __launch_bounds__(256)
@@ -471,7 +450,7 @@ __global__ void k_quat_norm(double *st)
 // normalizeCovariance (Update.cpp:64-85): P <- D P D', D = diag(I3, J, I).  Five disjoint blocks; block 0 owns
 // the 7x7 corner pieces, every other thread owns column j of the row strip 3..6 and row j of the column strip.
 template <typename T>
-__global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, const double *st)
+__global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, const double *st, RowMap rm)
 {
     __shared__ double J[16];
     __shared__ double C[7][7];
@@ -508,11 +487,13 @@ __global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, cons
     __syncthreads();
     const int j = 7 + (blockIdx.x - 1) * 256 + tid;
     if (j >= n) return;
+    const bool mine = owns_row(rm, j); // sharded storage: the column strip exists only for owned rows
+    T *prow = P + (size_t)local_row(rm, j) * ld;
     double col[4], row[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         col[k] = (double)P[(size_t)(3 + k) * ld + j];
-        row[k] = (double)P[(size_t)j * ld + 3 + k];
+        row[k] = mine ? (double)prow[3 + k] : 0.0;
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -523,7 +504,7 @@ __global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, cons
             t += row[k] * J[a * 4 + k];
         }
         P[(size_t)(3 + a) * ld + j] = (T)s;
-        P[(size_t)j * ld + 3 + a] = (T)t;
+        if (mine) prow[3 + a] = (T)t;
     }
 }
 
@@ -542,7 +523,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         dim3 grid((n_pad + 255) / 256, m_pad);
         k_gather<T><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const T *)e->d.HP, A, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
-                                         e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Ac);
+                                         e->d.mHf, e->d.mpos, e->d.mdim);
     }
     {
         dim3 grid((M + 15) / 16, (M + 15) / 16);
@@ -582,7 +563,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     launch_p_update(e, m_pad);
     k_quat_norm<<<1, 64, 0, s>>>(e->d.state);
     const int nb = 1 + (n > 7 ? (n - 7 + 255) / 256 : 0);
-    k_normalize_cov<T><<<nb, 256, 0, s>>>((T *)e->d.P, ld, n, e->d.state);
+    k_normalize_cov<T><<<nb, 256, 0, s>>>((T *)e->d.P, ld, n, e->d.state, e->rm);
 }
 
 void launch_update(EkfEngine *e, int M, bool update_cov)

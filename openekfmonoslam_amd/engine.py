@@ -92,7 +92,15 @@ ABI = {
     "ekf_synchronize": (_i, [_vp]),
     "ekf_timing_p_update_launches": (_i, [_vp, _i, _vp, _vp, C.POINTER(_i)]),
     "ekf_shard_rows": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "ekf_engine_create_sharded": (_i, [C.POINTER(EkfEngineConfig), _i, _i, C.POINTER(_vp)]),
+    "ekf_set_exchange": (_i, [_vp, _vp, _vp]),
+    "ekf_shard_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "ekf_device_copy": (_i, [_vp, _vp, _vp, C.c_size_t]),
 }
+
+# int fn(void *user, int what, void *device_base, size_t row_bytes, const int32_t *row_begin, int world, int rank)
+EXCHANGE_FN = C.CFUNCTYPE(_i, _vp, _i, _vp, C.c_size_t, C.POINTER(C.c_int32), _i, _i)
+XCHG_HP, XCHG_PRED_S = 0, 1
 
 _lib = None
 
@@ -141,19 +149,50 @@ def shard_rows(n_features, world, rank):
 class EkfEngine:
     """One device-resident filter (state, covariance, map, per-frame tables) on one MI355X."""
 
-    def __init__(self, cam, par, max_features, max_keypoints=0, precision=PRECISION_F64, device=-1, ransac_batch=0):
+    def __init__(self, cam, par, max_features, max_keypoints=0, precision=PRECISION_F64, device=-1, ransac_batch=0,
+                 shard=None):
+        """shard = (rank, world) creates one rank of a row-sharded filter; install the exchange with
+        set_exchange before the first prediction."""
         self.L = load_library()
         cfg = EkfEngineConfig()
         cfg.cam, cfg.par = cam, par
         cfg.max_features, cfg.max_keypoints = int(max_features), int(max_keypoints)
         cfg.precision, cfg.device, cfg.ransac_batch, cfg.flags = int(precision), int(device), int(ransac_batch), 0
         h = _vp()
-        rc = self.L.ekf_engine_create(C.byref(cfg), C.byref(h))
+        if shard is None:
+            rc = self.L.ekf_engine_create(C.byref(cfg), C.byref(h))
+        else:
+            rc = self.L.ekf_engine_create_sharded(C.byref(cfg), int(shard[0]), int(shard[1]), C.byref(h))
+        self._xchg_ref = None
         if rc:
             raise EkfError(rc, "ekf_engine_create failed (no MI355X visible?)")
         self.h = h
         self.cap = int(max_features)
         self.precision = precision
+
+    def set_exchange(self, fn):
+        """fn(what, device_base, row_bytes, row_begin[world+1], world, rank) -> 0 on success; called by the engine
+        (from C, with its stream idle) whenever a replicated per-feature table has to be completed across ranks."""
+        def tramp(_user, what, base, row_bytes, rb, world, rank):
+            try:
+                return int(fn(int(what), int(base), int(row_bytes), [int(rb[i]) for i in range(world + 1)], int(world),
+                              int(rank)) or 0)
+            except Exception:  # an exception must not unwind through the C frames
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._xchg_ref = EXCHANGE_FN(tramp)
+        self._chk(self.L.ekf_set_exchange(self.h, C.cast(self._xchg_ref, _vp), None))
+
+    def shard_info(self):
+        r, w, lo, hi = _i(0), _i(1), _i(0), _i(0)
+        self._chk(self.L.ekf_shard_info(self.h, C.byref(r), C.byref(w), C.byref(lo), C.byref(hi)))
+        return r.value, w.value, lo.value, hi.value
+
+    def device_copy(self, dst, src, nbytes):
+        self._chk(self.L.ekf_device_copy(self.h, _vp(dst), _vp(src), nbytes))
 
     def close(self):
         if getattr(self, "h", None):
@@ -185,10 +224,12 @@ class EkfEngine:
         Pm = None if P is None else np.ascontiguousarray(P, dtype=np.float64)
         self._chk(self.L.ekf_set_state(self.h, _p(x13), len(fp), _p(fp), _p(ft), _p(d), _p(Pm)))
 
-    def get_state(self, want_P=True):
+    def get_state(self, want_P=True, P_out=None):
+        """P_out: an existing [n, n] float64 array to fill (a sharded engine writes only the rows it holds, so the
+        ranks of a group can assemble the whole matrix in one buffer)."""
         x = np.zeros(13)
         fp = np.zeros((max(self.N, 1), 6))
-        P = np.zeros((self.n, self.n)) if want_P else None
+        P = P_out if P_out is not None else (np.zeros((self.n, self.n)) if want_P else None)
         self._chk(self.L.ekf_get_state(self.h, _p(x), _p(fp), _p(P)))
         return x, fp[: self.N], P
 

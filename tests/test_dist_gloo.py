@@ -1,7 +1,7 @@
 """N > 1 plumbing on CPU: world_size-2 gloo process group.  Covers what bench.py --gpus N relies on (rendezvous,
-barrier, max-over-ranks timing, aggregate throughput) and the exchange step of the row-sharded update: each rank
-downdates only its own row block of P with the all-gathered B and the assembled result equals the unsharded
-downdate."""
+barrier, max-over-ranks timing, aggregate throughput) and the exchange step of the row-sharded filter
+(shard.exchange_rows, the function the RCCL callback runs, on uneven row blocks) plus the storage rule of the sharded
+downdate: camera rows replicated, feature rows owned."""
 import os
 import socket
 import subprocess
@@ -34,18 +34,34 @@ WORKER = textwrap.dedent(
     N = 7
     lo, hi = dist.shard_rows(N, r.world, r.rank)
     assert (lo, hi) == engine.shard_rows(N, r.world, r.rank)
-    # sharded downdate P <- P - B'B: B rows are produced per rank (here: split by rows of B), all-gathered, and each
-    # rank updates only P[lo:hi, :]
+    # the exchange the sharded engine asks for (shard.exchange_rows is the function the RCCL callback runs): every
+    # rank has written the H.P rows of the features it owns (2 rows per feature, ld elements each) and ends up with
+    # the whole table
+    import torch
+    import torch.distributed as tdist
+    from openekfmonoslam_amd import shard
     rng = np.random.default_rng(5)
-    n, m = 13 + 6 * N, 10
+    n, ld = 13 + 6 * N, 64
+    HP_true = rng.standard_normal((2 * N, ld))
+    per, extra = divmod(N, r.world)
+    fb = [q * per + min(q, extra) for q in range(r.world + 1)]
+    row_begin = [2 * f for f in fb]
+    table = np.full((2 * N, ld), np.nan)
+    table[row_begin[r.rank]:row_begin[r.rank + 1]] = HP_true[row_begin[r.rank]:row_begin[r.rank + 1]]
+    buf = torch.from_numpy(table).view(torch.uint8).reshape(-1)
+    shard.exchange_rows(tdist, buf, ld * 8, row_begin, r.rank)
+    np.testing.assert_array_equal(table, HP_true)
+    # sharded downdate P <- P - B'B with the engine's storage: every rank keeps the 13 camera rows and the rows of its
+    # own features, downdates those with the replicated B, and the assembled result equals the unsharded downdate
+    m = 10
     A = rng.standard_normal((n, n)); P = A @ A.T
     B = rng.standard_normal((m, n))
-    mlo, mhi = (0, 6) if r.rank == 0 else (6, m)
-    Bfull = r.all_gather_rows(np.ascontiguousarray(B[mlo:mhi]), m)
-    np.testing.assert_array_equal(Bfull, B)
-    mine = P[lo:hi] - Bfull[:, lo:hi].T @ Bfull
-    blocks = r.all_gather_rows(np.ascontiguousarray(mine), n)
-    np.testing.assert_allclose(blocks, P - B.T @ B, rtol=1e-12, atol=1e-12)
+    own0, own1 = max(lo, 13), hi
+    cam = P[0:13] - B[:, 0:13].T @ B
+    mine = P[own0:own1] - B[:, own0:own1].T @ B
+    blocks = r.all_gather_rows(np.ascontiguousarray(mine), n - 13)
+    full = np.concatenate([cam, blocks])
+    np.testing.assert_allclose(full, P - B.T @ B, rtol=1e-12, atol=1e-12)
     r.close()
     print("rank", r.rank, "ok")
     """

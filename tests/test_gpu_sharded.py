@@ -1,0 +1,117 @@
+"""Row-sharded filter on ONE GPU: `world` engines, each holding the camera rows and its own feature
+rows of P, exchanging the H.P row blocks by device-to-device copies (openekfmonoslam_amd.shard.LocalShardGroup: the
+same engine code path and partition as the one-process-per-GPU run, only the transport differs).  Checked against the
+unsharded engine (same kernels, so agreement far below the parity tolerance is expected) and against the oracle."""
+import numpy as np
+import pytest
+
+from openekfmonoslam_amd.shard import LocalShardGroup
+from openekfmonoslam_amd.synth import SyntheticSequence
+from tests.oracle_lib import ALGORITHMIC
+from tests.test_gpu_parity import F32_TOL, F64_TOL, eng_mod, rel_max, state_err  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+INFO_FIELDS = ("n_predicted", "n_matches", "n_hypotheses", "n_inliers", "n_outliers", "n_rescued", "status")
+
+
+def _sym(P):
+    return 0.5 * (P + P.T)
+
+
+def _run_group(seq, world, precision, frames, transport="hip"):
+    P0 = _sym(seq.P0)
+    grp = LocalShardGroup(seq.cam, seq.par, seq.n_features, world, max_keypoints=4 * seq.n_features + 64,
+                          precision=precision, transport=transport)
+    grp.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, P0)
+
+    def work(rank, e):
+        return [e.step(*seq.frames[t]) for t in range(frames)]
+
+    infos = grp.run(work)
+    return grp, infos
+
+
+@pytest.mark.parametrize("nfeat,world,precision", [(50, 2, 0), (50, 3, 0), (23, 4, 0), (200, 2, 1), (200, 3, 1)])
+def test_sharded_steps_match_unsharded(eng_mod, oracle_lib, nfeat, world, precision):
+    frames = 3
+    seq = SyntheticSequence(nfeat, frames)
+    grp, infos = _run_group(seq, world, precision, frames)
+    ref = eng_mod.EkfEngine(seq.cam, seq.par, nfeat, max_keypoints=4 * nfeat + 64, precision=precision)
+    ref.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, _sym(seq.P0))
+    ref_infos = [ref.step(*seq.frames[t]) for t in range(frames)]
+    for r in range(world):  # every rank walks the same control flow
+        for t in range(frames):
+            for f in INFO_FIELDS:
+                assert getattr(infos[r][t], f) == getattr(ref_infos[t], f), (r, t, f)
+    x, fp, P = grp.get_state()
+    xr, fpr, Pr = ref.get_state()
+    assert not np.isnan(P).any(), "some rows of P were returned by no rank"
+    tol = 1e-12 if precision == 0 else 1e-6
+    assert state_err(x, fp, xr, fpr) <= tol
+    assert rel_max(P, Pr) <= tol
+    # replicated pieces are bitwise identical on every rank
+    for e in grp.engines[1:]:
+        xe, fpe, _ = e.get_state(want_P=False)
+        np.testing.assert_array_equal(xe, x)
+        np.testing.assert_array_equal(fpe, fp)
+    # P stays symmetric ACROSS ranks (P[i][j] on the owner of i equals P[j][i] on the owner of j)
+    np.testing.assert_array_equal(P, P.T)
+    assert grp.bytes_exchanged > 0
+    grp.close()
+
+
+def test_sharded_fp64_against_oracle(eng_mod, oracle_lib):
+    frames = 3
+    seq = SyntheticSequence(50, frames)
+    grp, infos = _run_group(seq, 2, 0, frames)
+    o = oracle_lib.Oracle(seq.cam, seq.par, 50)
+    o.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, _sym(seq.P0))
+    for t in range(frames):
+        oi = o.step(*seq.frames[t], ALGORITHMIC)
+        for f in INFO_FIELDS:
+            assert getattr(infos[0][t], f) == getattr(oi, f), (t, f)
+    x, fp, P = grp.get_state()
+    assert state_err(x, fp, o.x13(), o.feature_pos()) <= F64_TOL
+    assert rel_max(P, o.P()) <= F64_TOL
+    grp.close()
+
+
+def test_torch_aliased_transport_gives_the_same_result(eng_mod):
+    """the exchange through torch tensors aliasing the engine buffers (what the RCCL path does) == the hip copies"""
+    seq = SyntheticSequence(50, 2)
+    g1, i1 = _run_group(seq, 2, 0, 2, transport="hip")
+    g2, i2 = _run_group(seq, 2, 0, 2, transport="torch")
+    x1, f1, P1 = g1.get_state()
+    x2, f2, P2 = g2.get_state()
+    np.testing.assert_array_equal(x1, x2)
+    np.testing.assert_array_equal(P1, P2)
+    g1.close()
+    g2.close()
+
+
+def test_shard_layout_and_guards(eng_mod):
+    seq = SyntheticSequence(23, 1)
+    grp = LocalShardGroup(seq.cam, seq.par, 23, 3)
+    grp.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, _sym(seq.P0))
+    covered = []
+    for r, e in enumerate(grp.engines):
+        rank, world, lo, hi = e.shard_info()
+        assert (rank, world) == (r, 3)
+        assert (lo, hi) == eng_mod.shard_rows(23, 3, r)
+        covered.append((lo, hi))
+    assert covered[0][0] == 0 and covered[-1][1] == 13 + 6 * 23
+    assert all(covered[i][1] == covered[i + 1][0] for i in range(2))
+    with pytest.raises(eng_mod.EkfError):  # map management is not available on a sharded engine
+        grp.engines[0].remove_features([1])
+    grp.close()
+
+
+def test_sharded_engine_needs_an_exchange(eng_mod):
+    seq = SyntheticSequence(12, 1)
+    e = eng_mod.EkfEngine(seq.cam, seq.par, 12, shard=(0, 2))
+    e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, _sym(seq.P0))
+    e.predict()
+    with pytest.raises(eng_mod.EkfError) as ei:
+        e.predict_measurements()
+    assert ei.value.code == 7  # EKF_ERR_COMM
