@@ -68,7 +68,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,
                     d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
-                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.Tbuf,
+                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.Tbuf, d.W, d.Wf, d.G,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.pu_tilemap,
                     e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.raw, e->img.seq};
     for (void *p : ptrs)
@@ -109,7 +109,7 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     e->mcap = round_up(2 * e->cap, NB);
     e->kcap = cfg->max_keypoints > 0 ? cfg->max_keypoints : 4 * e->cap;
     e->ldP = round_up(e->ncap, LD_ALIGN);
-    e->ldS = round_up(e->mcap, 32);
+    e->ldS = round_up(e->mcap, 128) + 128;
     auto fail = [&](hipError_t st, const char *what) {
         e->err = std::string(what) + ": " + hipGetErrorString(st);
         std::fprintf(stderr, "ekf_engine_create: %s\n", e->err.c_str());
@@ -143,6 +143,8 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
         // + one row: the row operand of a sharded downdate tile may read up to 127 columns past n
         if ((st = dalloc(&raw, (size_t)(mcap + 1) * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc A");
         d.A = raw;
+        if ((st = dalloc(&raw, (size_t)(mcap + 1) * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc G");
+        d.G = raw;
     }
     ALLOC(d.mm_scratch, (size_t)60 * cap + 4 * (size_t)e->ldP + 64);
     ALLOC(d.mm_index, (size_t)e->ncap + 8);
@@ -172,10 +174,15 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     ALLOC(d.hyp_count, (size_t)e->cfg.ransac_batch);
     ALLOC(d.hyp_flags, (size_t)e->cfg.ransac_batch * mcap);
     ALLOC(d.best_flags, mcap);
-    ALLOC(d.S, (size_t)mcap * e->ldS);
+    // tiles of the GEMM-shaped kernels read whole 128-wide slabs: leading dimensions and row counts carry slack
+    e->ldW = round_up((int)mcap, 128) + 128;
+    const size_t mw = (size_t)round_up((int)mcap, 128) + 128;
+    ALLOC(d.S, mw * e->ldS);
     ALLOC(d.nu, mcap);
-    ALLOC(d.Dinv, (size_t)round_up((int)mcap, TB) * TB);
-    ALLOC(d.Tbuf, (size_t)round_up((int)mcap, TB) * (TB / 2));
+    ALLOC(d.Dinv, mw * e->ldW);
+    ALLOC(d.W, mw * e->ldW);
+    ALLOC(d.Tbuf, mw * e->ldW);
+    if (e->f32) ALLOC(d.Wf, mw * e->ldW);
     ALLOC(d.mHs, 14 * cap);
     ALLOC(d.mHf, 12 * cap);
     ALLOC(d.mpos, cap);

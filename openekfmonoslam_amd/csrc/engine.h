@@ -94,11 +94,14 @@ struct DeviceArrays {
     uint8_t *hyp_flags = nullptr;  // batch x mcap
     uint8_t *best_flags = nullptr; // mcap
     // update
-    void *A = nullptr;   // T [mcap x ldP] : rows of H P for the selected matches, overwritten by B = inv(L) A
-    double *S = nullptr; // mcap x ldS (lower triangle used)
+    void *G = nullptr;   // T [(mcap + 1) x ldP] : rows of H P gathered for the selected matches
+    void *A = nullptr;   // T [(mcap + 1) x ldP] : B = inv(L) G  (k-major operand of the downdate)
+    double *S = nullptr; // (mcap + slack) x ldS: lower triangle S then L; the panels also leave L' in the upper triangle
     double *nu = nullptr;
-    double *Dinv = nullptr; // [mcap256 x TB]: inverses of the 256x256 diagonal blocks of L (row-wise)
-    double *Tbuf = nullptr; // [mcap256 x TB/2] scratch of the doubling steps
+    double *Dinv = nullptr; // V = inv(L), row-major [mw x ldW], built up from 32x32 diagonal blocks by doubling
+    double *W = nullptr;    // W = inv(L)' (upper triangular), row-major [mw x ldW]: the k-major operand of B = W' G
+    float *Wf = nullptr;    // fp32 copy of W (fp32 configuration)
+    double *Tbuf = nullptr; // [mw x ldW] scratch of the doubling steps (T = L21 X11)
     double *mHs = nullptr;  // per selected match
     double *mHf = nullptr;
     int *mpos = nullptr;
@@ -135,7 +138,7 @@ struct EkfEngine {
     ekf::ParD par;
     int device = 0;
     int cap = 0, ncap = 0, mcap = 0, kcap = 0;
-    int ldP = 0, ldS = 0;
+    int ldP = 0, ldS = 0, ldW = 0;
     int N = 0, n = 0;
     bool f32 = false;
     // row sharding: world == 1 means the whole matrix lives here
@@ -169,6 +172,21 @@ struct EkfEngine {
 };
 
 namespace ekf {
+
+// C[i][j] = alpha sum_k X[k][i] Y[k][j] (kernels_gemm.hip); batch element b adds b * (xb, yb, cb, ctb) elements
+struct XtyArgs {
+    const void *X; int ldx; long long xb;
+    const void *Y; int ldy; long long yb;
+    void *C; int ldc; long long cb;       // may be null
+    void *Ct; int ldct; long long ctb;    // transposed copy in fp64, may be null
+    float *Ctf;                           // transposed copy in fp32 (same layout as Ct), may be null
+    int M, N, K;                          // output rows / columns / k-depth per batch element
+    int row0_first, row0_stride, m_lim;   // rows of element b that exist: min(M, m_lim - (row0_first + b row0_stride))
+    int tri;                              // 0: all k; 1: Y[k][j] = 0 for k < j; 2: X[k][i] = 0 for k > i
+    int tiles_i, tiles_j;
+    double alpha;
+};
+void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32);
 
 // ---- launchers (kernels_*.hip) ; T selected by e->f32 ----------------------------------------------------
 void launch_predict(EkfEngine *e);

@@ -95,20 +95,23 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 //   panel : L_ik = S_ik inv(L_kk)' for the row blocks below (inverse read from Dinv), z_k = inv(L_kk) nu_k
 //   trail : S_ij -= L_ik L_jk' (i >= j > k), nu_i -= L_ik z_k, + the look-ahead factorisation of block k+1
 // B = inv(L) A is NOT part of the sweep: it is independent per column of A and runs afterwards as one launch
-// (k_trsm) on the MFMA pipe.
+// (k_xty, kernels_gemm.hip) on the MFMA pipe, against the explicitly inverted factor.
 
-// its 256-block's row
-__device__ __forceinline__ void store_linv(double *Dinv, int k0, const double (*x)[NB + 1])
+// inv(L_kk) goes to V (row-major inv(L)), its transpose to W (and to the fp32 copy of W, when present)
+__device__ __forceinline__ void store_linv(double *V, double *W, float *Wf, int ldw, int k0, const double (*x)[NB + 1])
 {
-    const int cb = k0 % TB;
     for (int i = threadIdx.x; i < NB * NB; i += 256) {
         const int r = i / NB, c = i % NB;
-        Dinv[(size_t)(k0 + r) * TB + cb + c] = x[r][c];
+        V[(size_t)(k0 + r) * ldw + k0 + c] = x[r][c];
+        const double t = x[c][r]; // W[k0 + r][k0 + c] = inv(L)[k0 + c][k0 + r]
+        W[(size_t)(k0 + r) * ldw + k0 + c] = t;
+        if (Wf) Wf[(size_t)(k0 + r) * ldw + k0 + c] = (float)t;
     }
 }
 
 // first panel only: factorise block 0
-__global__ void __launch_bounds__(256) k_chol_diag0(const double *S, int ldS, int kb, double *Dinv, int *counts)
+__global__ void __launch_bounds__(256)
+k_chol_diag0(const double *S, int ldS, int kb, double *V, double *W, float *Wf, int ldw, int *counts)
 {
     __shared__ double sa[NB][NB + 1], sx[NB][NB + 1];
     for (int i = threadIdx.x; i < NB * NB; i += 256) {
@@ -117,22 +120,19 @@ __global__ void __launch_bounds__(256) k_chol_diag0(const double *S, int ldS, in
     }
     __syncthreads();
     if (!block_chol_inv32_bp(sa, sx) && threadIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
-    store_linv(Dinv, 0, sx);
+    store_linv(V, W, Wf, ldw, 0, sx);
 }
 
 // grid.x = nrb row blocks below the panel + 1 (z_k)
 __global__ void __launch_bounds__(256)
-k_chol_panel(double *S, int ldS, int m, int k0, int kb, const double *Dinv, double *nu, int nrb)
+k_chol_panel(double *S, int ldS, int m, int m_pad, int k0, int kb, const double *V, int ldw, double *nu, int nrb)
 {
     __shared__ double sLi[NB][NB + 1]; // inv(L_kk)
     __shared__ double sS[NB][NB + 1];
     const int tid = threadIdx.x;
-    {
-        const int cb = k0 % TB;
-        for (int i = tid; i < NB * NB; i += 256) {
-            const int r = i / NB, c = i % NB;
-            sLi[r][c] = Dinv[(size_t)(k0 + r) * TB + cb + c];
-        }
+    for (int i = tid; i < NB * NB; i += 256) {
+        const int r = i / NB, c = i % NB;
+        sLi[r][c] = V[(size_t)(k0 + r) * ldw + k0 + c];
     }
     const int k1 = k0 + kb;
     if ((int)blockIdx.x < nrb) {
@@ -142,13 +142,21 @@ k_chol_panel(double *S, int ldS, int m, int k0, int kb, const double *Dinv, doub
             sS[r][c] = (i0 + r < m && c < kb) ? S[(size_t)(i0 + r) * ldS + k0 + c] : 0.0;
         }
         __syncthreads();
+        __shared__ double sO[NB][NB + 1];
         for (int i = tid; i < NB * NB; i += 256) {
             const int r = i / NB, c = i % NB;
+            double s = 0.0;
             if (i0 + r < m && c < kb) {
-                double s = 0.0;
                 for (int k2 = 0; k2 <= c; ++k2) s += sS[r][k2] * sLi[c][k2];
                 S[(size_t)(i0 + r) * ldS + k0 + c] = s;
             }
+            sO[r][c] = s;
+        }
+        __syncthreads();
+        // L' into the upper triangle (k-major operand of the inverse's upper levels); rows m..m_pad are zero rows of L
+        for (int i = tid; i < NB * NB; i += 256) {
+            const int c = i / NB, r = i % NB;
+            if (i0 + r < m_pad && c < kb) S[(size_t)(k0 + c) * ldS + i0 + r] = sO[r][c];
         }
     } else {
         __shared__ double sn[NB];
@@ -165,7 +173,8 @@ k_chol_panel(double *S, int ldS, int m, int k0, int kb, const double *Dinv, doub
 // grid.x : [0, n_stiles) lower-triangular 32x32 tiles of the trailing S (tile 0 = block (k+1, k+1): look-ahead
 // factorisation), then one block for nu.
 __global__ void __launch_bounds__(256)
-k_chol_trailing(double *S, int ldS, int m, int k0, int kb, double *nu, int n_stiles, double *Dinv, int *counts)
+k_chol_trailing(double *S, int ldS, int m, int k0, int kb, double *nu, int n_stiles, double *V, double *W, float *Wf,
+                int ldw, int *counts)
 {
     __shared__ double sA[NB][NB + 1];
     __shared__ double sB[NB][NB + 1];
@@ -210,7 +219,7 @@ k_chol_trailing(double *S, int ldS, int m, int k0, int kb, double *nu, int n_sti
         }
         __syncthreads();
         if (!block_chol_inv32_bp(sA, sB) && tid == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
-        store_linv(Dinv, k1, sB);
+        store_linv(V, W, Wf, ldw, k1, sB);
         return;
     }
     for (int i = k1 + tid; i < m; i += 256) {
@@ -220,13 +229,16 @@ k_chol_trailing(double *S, int ldS, int m, int k0, int kb, double *nu, int n_sti
     }
 }
 
-// ------------------------------------------------------------------------------ inverse of the 256-blocks of L
-// Doubling step s -> 2s inside each TB = 256 diagonal block of L:  inv([L11 0; L21 L22]) has the off-diagonal
-// block X21 = -X22 L21 X11.  Two batched small products per level (T = L21 X11, X21 = -X22 T), 32x32 output tile
-// per workgroup.  O(m s^2) flops per level: negligible.
+// ------------------------------------------------------------------------------------------ inverse of L
+// Doubling step s -> 2s:  inv([L11 0; L21 L22]) has the off-diagonal block X21 = -X22 L21 X11.  Two batched products
+// per level (T = L21 X11, X21 = -X22 T).  Levels s = 32, 64, 128 run here (32x32 output tile per workgroup, fp64
+// FMA: the whole level is a few microseconds of work); from s = 256 on the same two products go through the MFMA
+// GEMM (k_xty<double>, kernels_gemm.hip).  V = inv(L) row-major, W = V' (+ fp32 copy): after the last level
+// B = inv(L) A is ONE GEMM, B = W' A, with no dependency between row blocks.
 // mode 0: T[pair] = L21 * X11 ;  mode 1: X21 = -X22 * T
 __global__ void __launch_bounds__(256)
-k_triinv_level(const double *S, int ldS, int m, double *Dinv, double *Tbuf, int s, int mode)
+k_triinv_level(const double *S, int ldS, int m, int m_pad, double *V, double *W, float *Wf, double *Tbuf, int ldw,
+               int s, int mode)
 {
     __shared__ double sA[NB][NB + 1];
     __shared__ double sB[NB][NB + 1];
@@ -235,8 +247,7 @@ k_triinv_level(const double *S, int ldS, int m, double *Dinv, double *Tbuf, int 
     const int t = blockIdx.x % (tiles * tiles);
     const int tr = t / tiles, tc = t % tiles;
     const int r0 = pair * 2 * s; // first row of the pair's 2s x 2s diagonal block
-    if (r0 + s >= m) return;     // no second half
-    const int cb = r0 % TB;      // column offset of the pair inside its 256-block
+    if (r0 + s + tr * NB >= m_pad) return; // no such rows in the second half
     const int tid = threadIdx.x;
     double acc[4] = {0, 0, 0, 0};
     for (int kk = 0; kk < s; kk += NB) {
@@ -244,12 +255,12 @@ k_triinv_level(const double *S, int ldS, int m, double *Dinv, double *Tbuf, int 
             const int r = i / NB, c = i % NB;
             double av, bv;
             if (mode == 0) {
-                const int gr = r0 + s + tr * NB + r, gc = r0 + kk + c; // L21
+                const int gr = r0 + s + tr * NB + r, gc = r0 + kk + c; // L21 (rows m..m_pad of L are zero)
                 av = (gr < m) ? S[(size_t)gr * ldS + gc] : 0.0;
-                bv = Dinv[(size_t)(r0 + kk + r) * TB + cb + tc * NB + c]; // X11[kk + r][tc*32 + c]
+                bv = V[(size_t)(r0 + kk + r) * ldw + r0 + tc * NB + c]; // X11[kk + r][tc*32 + c]
             } else {
-                av = Dinv[(size_t)(r0 + s + tr * NB + r) * TB + cb + s + kk + c]; // X22[tr*32 + r][kk + c]
-                bv = Tbuf[(size_t)(r0 + s + kk + r) * (TB / 2) + tc * NB + c];   // T[kk + r][tc*32 + c]
+                av = V[(size_t)(r0 + s + tr * NB + r) * ldw + r0 + s + kk + c]; // X22[tr*32 + r][kk + c]
+                bv = Tbuf[(size_t)(r0 + s + kk + r) * ldw + tc * NB + c];       // T[kk + r][tc*32 + c]
             }
             sA[r][c] = av;
             sB[r][c] = bv;
@@ -270,121 +281,14 @@ k_triinv_level(const double *S, int ldS, int m, double *Dinv, double *Tbuf, int 
     for (int q = 0; q < 4; ++q) {
         const int i = tid + q * 256;
         const int r = i / NB, c = i % NB;
-        if (mode == 0) Tbuf[(size_t)(r0 + s + tr * NB + r) * (TB / 2) + tc * NB + c] = acc[q];
-        else Dinv[(size_t)(r0 + s + tr * NB + r) * TB + cb + tc * NB + c] = -acc[q];
-    }
-}
-
-// ------------------------------------------------------------------------------------------ B = inv(L) A
-// Forward substitution in TB = 256 row blocks, independent per column of A: one workgroup owns a CT-column strip
-// (CT = MFMA block width) and walks the row blocks K = 0, 1, ...:
-//     C   = A_K - L[K, 0:K] B[0:K]      (GEMM, k-depth 256 K, MFMA; L read as fp64 and converted)
-//     B_K = inv(L_KK) C                  (GEMM, k-depth 256, triangular)
-// No inter-workgroup dependency, so the whole solve is ONE launch.  Each wavefront owns 64 of the 256 rows.
-template <typename T>
-struct MmaU;
-template <>
-struct MmaU<float> {
-    static constexpr int MB = 32, NACC = 16;
-    typedef float acc_t __attribute__((ext_vector_type(16)));
-    __device__ static __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
-    __device__ static __forceinline__ int row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
-    __device__ static __forceinline__ int col(int lane) { return lane & 31; }
-};
-template <>
-struct MmaU<double> {
-    static constexpr int MB = 16, NACC = 4;
-    typedef double acc_t __attribute__((ext_vector_type(4)));
-    __device__ static __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-    __device__ static __forceinline__ int row(int reg, int lane) { return (lane >> 4) + 4 * reg; }
-    __device__ static __forceinline__ int col(int lane) { return lane & 15; }
-};
-
-constexpr int TR_KS = 16; // k-slab
-
-template <typename T>
-__global__ void __launch_bounds__(256)
-k_trsm(const double *L, int ldS, int m, int m_pad, const double *Dinv, T *A, int ld)
-{
-    using M = MmaU<T>;
-    constexpr int MB = M::MB, CT = MB, KI = 64 / MB, RB = 64 / MB; // RB row blocks per wavefront
-    __shared__ T sL[TR_KS][TB];
-    __shared__ T sB[TR_KS][CT];
-    __shared__ T sC[TB][CT];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int klane = lane / MB, idx = lane % MB;
-    const int col0 = blockIdx.x * CT;
-    const int nK = (m_pad + TB - 1) / TB;
-    for (int K = 0; K < nK; ++K) {
-        const int rows0 = K * TB;
-        typename M::acc_t acc[RB];
-#pragma unroll
-        for (int x = 0; x < RB; ++x)
-#pragma unroll
-            for (int r = 0; r < M::NACC; ++r) acc[x][r] = (T)0;
-        // phase 1: acc = L[rows0 + r, 0:rows0] * B[0:rows0, strip]
-        for (int kk = 0; kk < rows0; kk += TR_KS) {
-            {
-                const int gr = rows0 + tid;
-                const double *src = L + (size_t)gr * ldS + kk;
-#pragma unroll
-                for (int k = 0; k < TR_KS; ++k) sL[k][tid] = (gr < m) ? (T)src[k] : (T)0;
-            }
-            for (int i = tid; i < TR_KS * CT; i += 256) {
-                const int k = i / CT, c = i % CT;
-                sB[k][c] = A[(size_t)(kk + k) * ld + col0 + c];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < TR_KS; k += KI) {
-                const T b = sB[k + klane][idx];
-#pragma unroll
-                for (int x = 0; x < RB; ++x) acc[x] = M::mma(sL[k + klane][wv * 64 + x * MB + idx], b, acc[x]);
-            }
-            __syncthreads();
+        const int gi = r0 + s + tr * NB + r, gj = tc * NB + c;
+        if (mode == 0) {
+            Tbuf[(size_t)gi * ldw + gj] = acc[q];
+        } else {
+            V[(size_t)gi * ldw + r0 + gj] = -acc[q];
+            W[(size_t)(r0 + gj) * ldw + gi] = -acc[q];
+            if (Wf) Wf[(size_t)(r0 + gj) * ldw + gi] = (float)(-acc[q]);
         }
-        // C = A_K - acc
-#pragma unroll
-        for (int x = 0; x < RB; ++x)
-#pragma unroll
-            for (int r = 0; r < M::NACC; ++r) {
-                const int lr = wv * 64 + x * MB + M::row(r, lane), lc = M::col(lane);
-                const int gr = rows0 + lr;
-                const T a = (gr < m_pad) ? A[(size_t)gr * ld + col0 + lc] : (T)0;
-                sC[lr][lc] = a - acc[x][r];
-            }
-        __syncthreads();
-        // phase 2: B_K = inv(L_KK) C  (lower triangular: this wavefront's rows need k < its last row)
-#pragma unroll
-        for (int x = 0; x < RB; ++x)
-#pragma unroll
-            for (int r = 0; r < M::NACC; ++r) acc[x][r] = (T)0;
-        for (int kk = 0; kk < TB; kk += TR_KS) {
-            {
-                const double *src = Dinv + (size_t)(rows0 + tid) * TB + kk;
-                const bool live = rows0 + tid < m_pad;
-#pragma unroll
-                for (int k = 0; k < TR_KS; ++k) sL[k][tid] = live ? (T)src[k] : (T)0;
-            }
-            __syncthreads();
-            if (kk < wv * 64 + 64) {
-#pragma unroll
-                for (int k = 0; k < TR_KS; k += KI) {
-                    const T b = sC[kk + k + klane][idx];
-#pragma unroll
-                    for (int x = 0; x < RB; ++x) acc[x] = M::mma(sL[k + klane][wv * 64 + x * MB + idx], b, acc[x]);
-                }
-            }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int x = 0; x < RB; ++x)
-#pragma unroll
-            for (int r = 0; r < M::NACC; ++r) {
-                const int gr = rows0 + wv * 64 + x * MB + M::row(r, lane);
-                if (gr < m_pad) A[(size_t)gr * ld + col0 + M::col(lane)] = acc[x][r];
-            }
-        __syncthreads();
     }
 }
 
@@ -515,42 +419,75 @@ template <typename T>
 static void update_impl(EkfEngine *e, int M, bool update_cov)
 {
     hipStream_t s = e->stream;
-    const int m = 2 * M, n = e->n, ld = e->ldP, ldS = e->ldS;
+    const int m = 2 * M, n = e->n, ld = e->ldP, ldS = e->ldS, ldw = e->ldW;
     const int m_pad = round_up(m, NB);
     const int n_pad = round_up(n, LD_ALIGN);
-    T *A = (T *)e->d.A;
+    T *G = (T *)e->d.G; // gathered rows of H P
+    T *A = (T *)e->d.A; // B = inv(L) G
+    double *V = e->d.Dinv, *W = e->d.W;
+    float *Wf = e->f32 ? e->d.Wf : nullptr;
     {
         dim3 grid((n_pad + 255) / 256, m_pad);
-        k_gather<T><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const T *)e->d.HP, A, ld, n_pad, e->d.pred_uv,
+        k_gather<T><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const T *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
                                          e->d.mHf, e->d.mpos, e->d.mdim);
     }
     {
         dim3 grid((M + 15) / 16, (M + 15) / 16);
-        k_assemble_S<T><<<grid, 256, 0, s>>>(A, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
+        k_assemble_S<T><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS);
     }
-    k_chol_diag0<<<1, 256, 0, s>>>(e->d.S, ldS, min(NB, m), e->d.Dinv, e->d.counts);
+    k_chol_diag0<<<1, 256, 0, s>>>(e->d.S, ldS, min(NB, m), V, W, Wf, ldw, e->d.counts);
     for (int k0 = 0; k0 < m; k0 += NB) {
         const int kb = min(NB, m - k0);
         const int k1 = k0 + kb;
         const int nrb = (m - k1 + NB - 1) / NB; // row blocks below the panel
-        k_chol_panel<<<nrb + 1, 256, 0, s>>>(e->d.S, ldS, m, k0, kb, e->d.Dinv, e->d.nu, nrb);
+        k_chol_panel<<<nrb + 1, 256, 0, s>>>(e->d.S, ldS, m, m_pad, k0, kb, V, ldw, e->d.nu, nrb);
         if (nrb > 0) {
             const int n_stiles = nrb * (nrb + 1) / 2;
-            k_chol_trailing<<<n_stiles + 1, 256, 0, s>>>(e->d.S, ldS, m, k0, kb, e->d.nu, n_stiles, e->d.Dinv,
+            k_chol_trailing<<<n_stiles + 1, 256, 0, s>>>(e->d.S, ldS, m, k0, kb, e->d.nu, n_stiles, V, W, Wf, ldw,
                                                          e->d.counts);
         }
     }
-    for (int sz = NB; sz < TB; sz *= 2) {
-        const int npairs = (m_pad + 2 * sz - 1) / (2 * sz);
-        const int tiles = (sz / NB) * (sz / NB);
-        k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.S, ldS, m, e->d.Dinv, e->d.Tbuf, sz, 0);
-        k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.S, ldS, m, e->d.Dinv, e->d.Tbuf, sz, 1);
+    // inv(L) by doubling: 32 -> 64 -> ... until one block covers all rows
+    for (int sz = NB; sz < m_pad; sz *= 2) {
+        const int npairs = (m_pad - sz + 2 * sz - 1) / (2 * sz); // pairs whose second half has rows
+        if (sz < 256) {
+            const int tiles = (sz / NB) * (sz / NB);
+            k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.S, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 0);
+            k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.S, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 1);
+        } else {
+            const long long dS = 2LL * sz * (ldS + 1), dW = 2LL * sz * (ldw + 1), dT = 2LL * sz * ldw;
+            XtyArgs t1{};   // T1 = L21 X11 : X = L' (upper triangle of S), Y = X11 (lower triangular)
+            t1.X = e->d.S + sz;              t1.ldx = ldS; t1.xb = dS;
+            t1.Y = V;                        t1.ldy = ldw; t1.yb = dW;
+            t1.C = e->d.Tbuf + (size_t)sz * ldw; t1.ldc = ldw; t1.cb = dT;
+            t1.M = sz; t1.N = sz; t1.K = sz;
+            t1.row0_first = sz; t1.row0_stride = 2 * sz; t1.m_lim = m_pad;
+            t1.tri = 1; t1.tiles_i = sz / 64; t1.tiles_j = sz / 64; t1.alpha = 1.0;
+            launch_xty(e, t1, npairs, false);
+            XtyArgs x2{};   // X21 = -X22 T1 : X = W22 = X22' (upper triangular), Y = T1
+            x2.X = W + (size_t)sz * (ldw + 1);   x2.ldx = ldw; x2.xb = dW;
+            x2.Y = e->d.Tbuf + (size_t)sz * ldw; x2.ldy = ldw; x2.yb = dT;
+            x2.C = V + (size_t)sz * ldw;         x2.ldc = ldw; x2.cb = dW;
+            x2.Ct = W + sz;                      x2.ldct = ldw; x2.ctb = dW;
+            x2.Ctf = Wf ? Wf + sz : nullptr;
+            x2.M = sz; x2.N = sz; x2.K = sz;
+            x2.row0_first = sz; x2.row0_stride = 2 * sz; x2.m_lim = m_pad;
+            x2.tri = 2; x2.tiles_i = sz / 64; x2.tiles_j = sz / 64; x2.alpha = -1.0;
+            launch_xty(e, x2, npairs, false);
+        }
     }
-    {
-        const int CT = sizeof(T) == 4 ? 32 : 16;
-        k_trsm<T><<<n_pad / CT, 256, 0, s>>>(e->d.S, ldS, m, m_pad, e->d.Dinv, A, ld);
+    {   // B = inv(L) G = W' G : one GEMM, k <= row (W upper triangular)
+        const int TM = sizeof(T) == 4 ? 128 : 64;
+        XtyArgs g{};
+        g.X = e->f32 ? (const void *)Wf : (const void *)W; g.ldx = ldw;
+        g.Y = G; g.ldy = ld;
+        g.C = A; g.ldc = ld;
+        g.M = m_pad; g.N = n_pad; g.K = m_pad;
+        g.row0_first = 0; g.row0_stride = 0; g.m_lim = m_pad;
+        g.tri = 2; g.tiles_i = (m_pad + TM - 1) / TM; g.tiles_j = (n_pad + TM - 1) / TM; g.alpha = 1.0;
+        launch_xty(e, g, 1, e->f32);
     }
     {
         dim3 grid((n + 255) / 256, DX_SPLIT);
