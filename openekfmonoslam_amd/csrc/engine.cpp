@@ -68,7 +68,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,
                     d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
-                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.Tbuf, d.W, d.Wf, d.G,
+                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.Tbuf, d.W, d.Wf, d.G, d.LL,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.pu_tilemap,
                     e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.raw, e->img.seq};
     for (void *p : ptrs)
@@ -178,6 +178,7 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     e->ldW = round_up((int)mcap, 128) + 128;
     const size_t mw = (size_t)round_up((int)mcap, 128) + 128;
     ALLOC(d.S, mw * e->ldS);
+    ALLOC(d.LL, mw * e->ldS);
     ALLOC(d.nu, mcap);
     ALLOC(d.Dinv, mw * e->ldW);
     ALLOC(d.W, mw * e->ldW);

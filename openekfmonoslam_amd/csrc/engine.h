@@ -96,7 +96,8 @@ struct DeviceArrays {
     // update
     void *G = nullptr;   // T [(mcap + 1) x ldP] : rows of H P gathered for the selected matches
     void *A = nullptr;   // T [(mcap + 1) x ldP] : B = inv(L) G  (k-major operand of the downdate)
-    double *S = nullptr; // (mcap + slack) x ldS: lower triangle S then L; the panels also leave L' in the upper triangle
+    double *S = nullptr;  // (mcap + slack) x ldS: lower triangle of S, updated in place by the sweep
+    double *LL = nullptr; // same shape: L below the 32x32 diagonal blocks and L' mirrored above them
     double *nu = nullptr;
     double *Dinv = nullptr; // V = inv(L), row-major [mw x ldW], built up from 32x32 diagonal blocks by doubling
     double *W = nullptr;    // W = inv(L)' (upper triangular), row-major [mw x ldW]: the k-major operand of B = W' G

@@ -87,13 +87,13 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 }
 
 // -------------------------------------------------------------------------------------- blocked Cholesky sweep
-// Right-looking sweep over [ S | nu ], panel width NB = 32.  The only serial piece is the 32x32 diagonal block:
-// its Cholesky factor and the inverse of that factor.  It is computed by ONE workgroup with all 256 threads working
-// in LDS (block_chol_inv32_bp in chol32.h: 4x4 block pivots, one barrier per block column) and -- look-ahead -- inside the trailing-update launch of the
-// PREVIOUS panel, by the workgroup that owns tile (k+1, k+1): while the other workgroups of that launch update
-// their tiles, this one finishes tile (k+1, k+1), factorises it and stores inv(L_{k+1,k+1}) into Dinv.  Per panel:
-//   panel : L_ik = S_ik inv(L_kk)' for the row blocks below (inverse read from Dinv), z_k = inv(L_kk) nu_k
-//   trail : S_ij -= L_ik L_jk' (i >= j > k), nu_i -= L_ik z_k, + the look-ahead factorisation of block k+1
+// Right-looking sweep over [ S | nu ], panel width NB = 32, ONE launch per panel (k_chol_step).  The only serial
+// piece is the 32x32 diagonal block: its Cholesky factor and the inverse of that factor.  It is computed by one
+// workgroup with all 256 threads working in LDS (block_chol_inv32_bp in chol32.h: 4x4 block pivots, one barrier per
+// block column) and -- look-ahead -- inside the launch of the PREVIOUS panel, by the workgroup that owns tile
+// (k+1, k+1): while the other workgroups of that launch update their tiles, this one finishes its tile, factorises
+// it and stores inv(L_{k+1,k+1}) into V / W.  The panel solve L_ik = S_ik inv(L_kk)' is not a launch of its own:
+// every tile workgroup forms the two panel tiles it needs itself.
 // B = inv(L) A is NOT part of the sweep: it is independent per column of A and runs afterwards as one launch
 // (k_xty, kernels_gemm.hip) on the MFMA pipe, against the explicitly inverted factor.
 
@@ -123,65 +123,31 @@ k_chol_diag0(const double *S, int ldS, int kb, double *V, double *W, float *Wf, 
     store_linv(V, W, Wf, ldw, 0, sx);
 }
 
-// grid.x = nrb row blocks below the panel + 1 (z_k)
+// One launch per panel k (width NB = 32), Linv_k = inv(L_kk) already in V (look-ahead of the previous launch):
+//   grid.x : [0, n_stiles) lower-triangular 32x32 tiles (i >= j > k) of the trailing matrix, then one block for nu.
+//   tile (i, j): L_ik = S_ik Linv_k' and L_jk = S_jk Linv_k' are formed IN the workgroup (two 32^3 triangular
+//   products from LDS; cheaper than a separate panel launch on the serial path), then S_ij -= L_ik L_jk'.
+//   The tiles of the first tile column (j = k+1) also store L_ik into LL (row-major L below the diagonal blocks and,
+//   mirrored, L' above them: the operands of the inverse's doubling levels).  S itself is only read in column k, so
+//   nothing races.  Tile 0 = block (k+1, k+1): look-ahead factorisation, publishes Linv_{k+1}.
+//   nu block: z_k = Linv_k nu_k, then nu_i -= L_ik z_k = S_ik (Linv_k' z_k) for all rows below.
 __global__ void __launch_bounds__(256)
-k_chol_panel(double *S, int ldS, int m, int m_pad, int k0, int kb, const double *V, int ldw, double *nu, int nrb)
+k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, double *nu, int n_stiles, double *V,
+            double *W, float *Wf, int ldw, int *counts)
 {
+    __shared__ double sA[NB][NB + 1];
+    __shared__ double sB[NB][NB + 1];
     __shared__ double sLi[NB][NB + 1]; // inv(L_kk)
-    __shared__ double sS[NB][NB + 1];
     const int tid = threadIdx.x;
+    const int k1 = k0 + kb;
+    const int b = blockIdx.x;
     for (int i = tid; i < NB * NB; i += 256) {
         const int r = i / NB, c = i % NB;
         sLi[r][c] = V[(size_t)(k0 + r) * ldw + k0 + c];
     }
-    const int k1 = k0 + kb;
-    if ((int)blockIdx.x < nrb) {
-        const int i0 = k1 + blockIdx.x * NB;
-        for (int i = tid; i < NB * NB; i += 256) {
-            const int r = i / NB, c = i % NB;
-            sS[r][c] = (i0 + r < m && c < kb) ? S[(size_t)(i0 + r) * ldS + k0 + c] : 0.0;
-        }
-        __syncthreads();
-        __shared__ double sO[NB][NB + 1];
-        for (int i = tid; i < NB * NB; i += 256) {
-            const int r = i / NB, c = i % NB;
-            double s = 0.0;
-            if (i0 + r < m && c < kb) {
-                for (int k2 = 0; k2 <= c; ++k2) s += sS[r][k2] * sLi[c][k2];
-                S[(size_t)(i0 + r) * ldS + k0 + c] = s;
-            }
-            sO[r][c] = s;
-        }
-        __syncthreads();
-        // L' into the upper triangle (k-major operand of the inverse's upper levels); rows m..m_pad are zero rows of L
-        for (int i = tid; i < NB * NB; i += 256) {
-            const int c = i / NB, r = i % NB;
-            if (i0 + r < m_pad && c < kb) S[(size_t)(k0 + c) * ldS + i0 + r] = sO[r][c];
-        }
-    } else {
-        __shared__ double sn[NB];
-        if (tid < NB) sn[tid] = tid < kb ? nu[k0 + tid] : 0.0;
-        __syncthreads();
-        if (tid < kb) {
-            double s = 0.0;
-            for (int c = 0; c <= tid; ++c) s += sLi[tid][c] * sn[c];
-            nu[k0 + tid] = s;
-        }
-    }
-}
-
-// grid.x : [0, n_stiles) lower-triangular 32x32 tiles of the trailing S (tile 0 = block (k+1, k+1): look-ahead
-// factorisation), then one block for nu.
-__global__ void __launch_bounds__(256)
-k_chol_trailing(double *S, int ldS, int m, int k0, int kb, double *nu, int n_stiles, double *V, double *W, float *Wf,
-                int ldw, int *counts)
-{
-    __shared__ double sA[NB][NB + 1];
-    __shared__ double sB[NB][NB + 1];
-    const int tid = threadIdx.x;
-    const int k1 = k0 + kb;
-    const int b = blockIdx.x;
     if (b < n_stiles) {
+        __shared__ double sLI[NB][NB + 1];
+        __shared__ double sLJ[NB][NB + 1];
         int ti = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
         while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
         while (ti * (ti + 1) / 2 > b) --ti;
@@ -193,6 +159,28 @@ k_chol_trailing(double *S, int ldS, int m, int k0, int kb, double *nu, int n_sti
             sB[r][c] = (j0 + r < m && c < kb) ? S[(size_t)(j0 + r) * ldS + k0 + c] : 0.0;
         }
         __syncthreads();
+        for (int i = tid; i < NB * NB; i += 256) {
+            const int r = i / NB, c = i % NB;
+            double si = 0.0, sj = 0.0;
+            for (int k2 = 0; k2 <= c; ++k2) {
+                const double l = sLi[c][k2];
+                si += sA[r][k2] * l;
+                sj += sB[r][k2] * l;
+            }
+            sLI[r][c] = si;
+            sLJ[r][c] = sj;
+        }
+        __syncthreads();
+        if (tj == 0) { // L_ik for the doubling levels: below the diagonal and, mirrored, above it (zero rows m..m_pad)
+            for (int i = tid; i < NB * NB; i += 256) {
+                const int r = i / NB, c = i % NB;
+                if (i0 + r < m_pad && c < kb) LL[(size_t)(i0 + r) * ldS + k0 + c] = sLI[r][c];
+            }
+            for (int i = tid; i < NB * NB; i += 256) {
+                const int c = i / NB, r = i % NB;
+                if (i0 + r < m_pad && c < kb) LL[(size_t)(k0 + c) * ldS + i0 + r] = sLI[r][c];
+            }
+        }
         double v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -202,7 +190,7 @@ k_chol_trailing(double *S, int ldS, int m, int k0, int kb, double *nu, int n_sti
             if (i0 + r < m && j0 + c < m && j0 + c <= i0 + r) {
                 double s = 0.0;
 #pragma unroll
-                for (int k2 = 0; k2 < NB; ++k2) s += sA[r][k2] * sB[c][k2];
+                for (int k2 = 0; k2 < NB; ++k2) s += sLI[r][k2] * sLJ[c][k2];
                 v[q] = S[(size_t)(i0 + r) * ldS + j0 + c] - s;
                 if (b != 0) S[(size_t)(i0 + r) * ldS + j0 + c] = v[q];
             }
@@ -222,9 +210,27 @@ k_chol_trailing(double *S, int ldS, int m, int k0, int kb, double *nu, int n_sti
         store_linv(V, W, Wf, ldw, k1, sB);
         return;
     }
+    // nu block
+    __shared__ double sz[NB], sw[NB];
+    if (tid < NB) sz[tid] = tid < kb ? nu[k0 + tid] : 0.0;
+    __syncthreads();
+    double zk = 0.0;
+    if (tid < NB) {
+        for (int c = 0; c <= tid; ++c) zk += sLi[tid][c] * sz[c];
+        if (tid < kb) nu[k0 + tid] = zk;
+    }
+    __syncthreads();
+    if (tid < NB) sz[tid] = tid < kb ? zk : 0.0;
+    __syncthreads();
+    if (tid < NB) { // w = Linv_k' z_k
+        double w = 0.0;
+        for (int r = tid; r < NB; ++r) w += sLi[r][tid] * sz[r];
+        sw[tid] = w;
+    }
+    __syncthreads();
     for (int i = k1 + tid; i < m; i += 256) {
         double s = 0.0;
-        for (int c = 0; c < kb; ++c) s += S[(size_t)i * ldS + k0 + c] * nu[k0 + c];
+        for (int c = 0; c < kb; ++c) s += S[(size_t)i * ldS + k0 + c] * sw[c];
         nu[i] -= s;
     }
 }
@@ -442,24 +448,21 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const int kb = min(NB, m - k0);
         const int k1 = k0 + kb;
         const int nrb = (m - k1 + NB - 1) / NB; // row blocks below the panel
-        k_chol_panel<<<nrb + 1, 256, 0, s>>>(e->d.S, ldS, m, m_pad, k0, kb, V, ldw, e->d.nu, nrb);
-        if (nrb > 0) {
-            const int n_stiles = nrb * (nrb + 1) / 2;
-            k_chol_trailing<<<n_stiles + 1, 256, 0, s>>>(e->d.S, ldS, m, k0, kb, e->d.nu, n_stiles, V, W, Wf, ldw,
-                                                         e->d.counts);
-        }
+        const int n_stiles = nrb * (nrb + 1) / 2;
+        k_chol_step<<<n_stiles + 1, 256, 0, s>>>(e->d.S, e->d.LL, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles, V, W, Wf, ldw,
+                                                 e->d.counts);
     }
     // inv(L) by doubling: 32 -> 64 -> ... until one block covers all rows
     for (int sz = NB; sz < m_pad; sz *= 2) {
         const int npairs = (m_pad - sz + 2 * sz - 1) / (2 * sz); // pairs whose second half has rows
         if (sz < 256) {
             const int tiles = (sz / NB) * (sz / NB);
-            k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.S, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 0);
-            k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.S, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 1);
+            k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.LL, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 0);
+            k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.LL, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 1);
         } else {
             const long long dS = 2LL * sz * (ldS + 1), dW = 2LL * sz * (ldw + 1), dT = 2LL * sz * ldw;
-            XtyArgs t1{};   // T1 = L21 X11 : X = L' (upper triangle of S), Y = X11 (lower triangular)
-            t1.X = e->d.S + sz;              t1.ldx = ldS; t1.xb = dS;
+            XtyArgs t1{};   // T1 = L21 X11 : X = L' (upper triangle of LL), Y = X11 (lower triangular)
+            t1.X = e->d.LL + sz;             t1.ldx = ldS; t1.xb = dS;
             t1.Y = V;                        t1.ldy = ldw; t1.yb = dW;
             t1.C = e->d.Tbuf + (size_t)sz * ldw; t1.ldc = ldw; t1.cb = dT;
             t1.M = sz; t1.N = sz; t1.K = sz;
