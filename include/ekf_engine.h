@@ -179,6 +179,19 @@ int ekf_capture_templates(EkfEngine *e, const int32_t *feat_idx, const double *u
 int ekf_match_ncc(EkfEngine *e, EkfMatch *matches, int *n_matches);
 int ekf_step_image(EkfEngine *e, const uint8_t *image, int width, int height, int stride, int channels,
                    EkfStepInfo *info);
+/* detectNewImageFeatures(image, featuresPrediction, newImageFeaturesMaxSize, newImageFeatures)
+ *                                                              EKF/DetectNewImageFeatures.cpp:337
+ * on the CURRENT image, masked by the gate ellipses of the last full prediction made while an image was loaded
+ * (buildImageMask :102).  The detector is this build's own (integer Harris-type measure, best unmasked pixel per
+ * 16x16 cell, kernels_detect.hip; the reference's OpenCV STAR is third-party code that is not here); the zone
+ * heuristic is the reference's searchFeaturesByZone (:171) with rand() replaced by "strongest candidate of the
+ * zone".  divide_times = DetectNewFeaturesImageAreasDivideTimes, mask_ellipse_size =
+ * DetectNewFeaturesImageMaskEllipseSize, min_response = detector threshold on the integer measure.
+ * Writes up to max_new pixel positions (x, y) to uv_out; the caller then adds them (ekf_add_features) and cuts their
+ * templates (ekf_capture_templates). */
+int ekf_detect_new_features(EkfEngine *e, int max_new, int divide_times, double mask_ellipse_size,
+                            double min_response, double *uv_out, int *count);
+
 /* pre-staged image sequence (n_frames images of identical geometry, concatenated) */
 int ekf_images_upload(EkfEngine *e, int n_frames, const uint8_t *images, int width, int height, int stride,
                       int channels);

@@ -8,10 +8,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libekf_engine.so")
 SOURCES = ["engine.cpp", "kernels_predict.hip", "kernels_match.hip", "kernels_ransac.hip", "kernels_update.hip",
-           "kernels_pupdate.hip", "kernels_map.hip", "kernels_ncc.hip", "kernels_gemm.hip"]
+           "kernels_pupdate.hip", "kernels_map.hip", "kernels_ncc.hip", "kernels_gemm.hip", "kernels_detect.hip"]
 # the decision-making stages (projection, gates, dead-bands) are compiled without FMA contraction so their fp64
 # arithmetic rounds like the reference's scalar C++; the GEMM-shaped kernels keep contraction
-NO_CONTRACT = {"kernels_predict.hip", "kernels_match.hip", "kernels_ransac.hip", "kernels_ncc.hip"}
+NO_CONTRACT = {"kernels_predict.hip", "kernels_match.hip", "kernels_ransac.hip", "kernels_ncc.hip", "kernels_detect.hip"}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-x", "hip"]
 FLAGS += os.environ.get("EKF_EXTRA_FLAGS", "").split()  # tuning experiments, e.g. -DPU_BK_VALUE=32

@@ -68,7 +68,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,
                     d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
-                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.Tbuf, d.W, d.Wf, d.G, d.LL,
+                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.Tbuf, d.W, d.Wf, d.G, d.LL, d.gates, d.cell_resp, d.cell_xy,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.pu_tilemap,
                     e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.raw, e->img.seq};
     for (void *p : ptrs)
@@ -167,6 +167,7 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     ALLOC(d.mt_dist, cap);
     ALLOC(d.mt_xy, cap);
     ALLOC(d.tmpl, (size_t)3 * 121 * cap);
+    ALLOC(d.gates, (size_t)8 * cap);
     ALLOC(d.matches, cap);
     ALLOC(d.msel, cap);
     ALLOC(d.mout, cap);
@@ -320,6 +321,7 @@ int ekf_set_state(EkfEngine *e, const double x13[13], int n_features, const doub
     e->N = n_features;
     e->n = n;
     e->n_pred = 0;
+    e->n_gates = 0;
     e->h_type = type;
     e->h_covpos = covpos;
     refresh_row_map(e);
@@ -628,6 +630,10 @@ static int predict_measurements_dev(EkfEngine *e, const int *d_idx, int count, i
             e->err = "exchange of the innovation covariance blocks failed";
             return EKF_ERR_COMM;
         }
+    }
+    if (!d_idx && e->img.valid) { // image mode: keep the gates of this prediction for detectNewImageFeatures' mask
+        launch_gate_snapshot(e, np);
+        e->n_gates = np;
     }
     return check_async(e);
 }
@@ -1078,6 +1084,121 @@ int ekf_capture_templates(EkfEngine *e, const int32_t *feat_idx, const double *u
     launch_ncc_capture(e, e->d.work_idx, e->d.pred_uv2, count);
     HIPCHK(hipStreamSynchronize(e->stream)); // the host arrays may be reused by the caller
     return check_async(e);
+}
+
+// detectNewImageFeatures (EKF/DetectNewImageFeatures.cpp:337-367) on the current image: device = masked corner
+// candidates (kernels_detect.hip), host = the zone heuristic of searchFeaturesByZone (:171-330), with the two
+// nondeterministic choices of the reference made deterministic: zones of equal population keep their id order (qsort
+// is unstable) and the pick inside a zone is its strongest remaining candidate (the reference draws rand()).
+int ekf_detect_new_features(EkfEngine *e, int max_new, int divide_times, double mask_ellipse_size, double min_response,
+                            double *uv_out, int *count)
+{
+    if (!e || !count || max_new < 0 || divide_times < 0 || divide_times > 6 || (max_new > 0 && !uv_out)) return EKF_ERR_INVALID_ARG;
+    *count = 0;
+    if (!e->img.valid) {
+        e->err = "new-feature detection: no image uploaded";
+        return EKF_ERR_INVALID_ARG;
+    }
+    if (max_new == 0) return EKF_OK;
+    HIPCHK(hipSetDevice(e->device));
+    const int w = e->img.w[0], h = e->img.h[0];
+    const int cells_x = w / 16, cells_y = h / 16, ncell = cells_x * cells_y;
+    if (ncell <= 0) return EKF_OK;
+    if (e->cells_cap < ncell) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->d.cell_resp) (void)hipFree(e->d.cell_resp);
+        if (e->d.cell_xy) (void)hipFree(e->d.cell_xy);
+        e->d.cell_resp = nullptr;
+        e->d.cell_xy = nullptr;
+        HIPCHK(hipMalloc((void **)&e->d.cell_resp, (size_t)ncell * sizeof(long long)));
+        HIPCHK(hipMalloc((void **)&e->d.cell_xy, (size_t)ncell * 2 * sizeof(int)));
+        e->cells_cap = ncell;
+    }
+    launch_detect_cells(e, e->n_gates, cells_x, cells_y, e->d.cell_resp, e->d.cell_xy);
+    std::vector<long long> resp(ncell);
+    std::vector<int> xy(2 * (size_t)ncell);
+    std::vector<double> gates(8 * (size_t)std::max(e->n_gates, 1));
+    HIPCHK(hipMemcpyAsync(resp.data(), e->d.cell_resp, resp.size() * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(xy.data(), e->d.cell_xy, xy.size() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    if (e->n_gates > 0)
+        HIPCHK(hipMemcpyAsync(gates.data(), e->d.gates, (size_t)e->n_gates * 8 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int rc = check_async(e);
+    if (rc) return rc;
+
+    struct Cand { int x, y; long long r; };
+    std::vector<Cand> cands;
+    const long long thr = min_response >= 9.2e18 ? 0x7fffffffffffffffLL : (min_response <= 0 ? 0 : (long long)min_response);
+    for (int c = 0; c < ncell; ++c)
+        if (resp[c] >= 0 && resp[c] >= thr) cands.push_back(Cand{xy[2 * c], xy[2 * c + 1], resp[c]});
+    if ((int)cands.size() <= max_new) { // :357-370: fewer than asked for -> all of them
+        for (size_t i = 0; i < cands.size(); ++i) {
+            uv_out[2 * i] = cands[i].x;
+            uv_out[2 * i + 1] = cands[i].y;
+        }
+        *count = (int)cands.size();
+        return EKF_OK;
+    }
+    const int zones_row = 1 << divide_times;
+    const int zw = std::max(w / zones_row, 1), zh = std::max(h / zones_row, 1);
+    const int nzone = zones_row * zones_row;
+    auto zone_of = [&](double x, double y) { // getPointZone :87-92
+        const int id = ((int)y / zh) * (w / zw) + (int)x / zw;
+        return std::min(std::max(id, 0), nzone - 1);
+    };
+    struct Zone { int id, count; std::vector<int> cand; };
+    std::vector<Zone> zones(nzone);
+    for (int z = 0; z < nzone; ++z) zones[z] = Zone{z, 0, {}};
+    for (size_t i = 0; i < cands.size(); ++i) zones[zone_of(cands[i].x, cands[i].y)].cand.push_back((int)i);
+    for (int k = 0; k < e->n_gates; ++k) zones[zone_of(gates[8 * (size_t)k + 5], gates[8 * (size_t)k + 6])].count++;
+    std::vector<int> order(nzone);
+    for (int z = 0; z < nzone; ++z) order[z] = z;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return zones[a].count < zones[b].count; });
+    // mask of the features added in this call: the "ellipse" of diag(size, size), a disc of integer radius
+    const int radius = (int)std::nearbyint((float)(2.0 * std::sqrt(mask_ellipse_size * EKF_CHISQ_95_2)));
+    std::vector<std::pair<int, int>> added;
+    int left = max_new, n_out = 0;
+    size_t head = 0; // order[head..] is the list; zones without candidates are popped from the front
+    while (head < order.size() && left > 0) {
+        Zone &z = zones[order[head]];
+        if (z.cand.empty()) {
+            ++head;
+            continue;
+        }
+        size_t best = 0;
+        for (size_t i = 1; i < z.cand.size(); ++i) { // strongest, ties -> first in cell order
+            const Cand &a = cands[z.cand[i]], &bb = cands[z.cand[best]];
+            if (a.r > bb.r || (a.r == bb.r && z.cand[i] < z.cand[best])) best = i;
+        }
+        const Cand c = cands[z.cand[best]];
+        bool free_px = true;
+        for (const auto &a : added) {
+            const double dx = (double)(float)c.x - (double)(float)a.first, dy = (double)(float)c.y - (double)(float)a.second;
+            if (2.0 * std::sqrt(dx * dx + dy * dy) <= 2.0 * radius) { free_px = false; break; }
+        }
+        if (free_px) {
+            uv_out[2 * n_out] = c.x;
+            uv_out[2 * n_out + 1] = c.y;
+            ++n_out;
+            z.count++;
+            for (size_t p = head; p + 1 < order.size(); ++p) { // :272-296: keep the list ordered by population
+                if (zones[order[p]].count >= zones[order[p + 1]].count) std::swap(order[p], order[p + 1]);
+                else break;
+            }
+            added.emplace_back(c.x, c.y);
+            --left;
+        }
+        // the candidate is consumed either way (:314-318); z may have moved, so erase through the zone object
+        Zone &zz = zones[zone_of(c.x, c.y)];
+        for (size_t i = 0; i < zz.cand.size(); ++i)
+            if (cands[zz.cand[i]].x == c.x && cands[zz.cand[i]].y == c.y) {
+                zz.cand[i] = zz.cand.back();
+                zz.cand.pop_back();
+                break;
+            }
+    }
+    *count = n_out;
+    return EKF_OK;
 }
 
 static int match_ncc_dev(EkfEngine *e, int *n_matches)

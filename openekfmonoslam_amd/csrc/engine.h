@@ -84,6 +84,9 @@ struct DeviceArrays {
     float *mt_dist = nullptr;
     EkfKeypoint *mt_xy = nullptr; // NCC matcher: matched pixel per prediction slot
     uint8_t *tmpl = nullptr;      // NCC matcher: 3 levels x 121 bytes per feature
+    double *gates = nullptr;      // new-feature detector: gate + centre + radius (8 doubles) per prediction of the last full prediction
+    long long *cell_resp = nullptr; // detector: best response per 16x16 cell
+    int *cell_xy = nullptr;         // detector: its pixel
     EkfMatch *matches = nullptr; // compacted matches (prediction order) / uploaded matches
     EkfMatch *msel = nullptr;    // matches selected for an update (inliers / rescued), update order
     EkfMatch *mout = nullptr;    // outlier matches
@@ -151,6 +154,8 @@ struct EkfEngine {
     void *xchg_user = nullptr;
     bool p_exact_sym = false; // P known to be bitwise symmetric (engine-maintained invariant)
     int n_pred = 0;           // predictions of the last full prediction
+    int n_gates = 0;          // gates snapshotted for the new-feature detector
+    int cells_cap = 0;        // detector cell buffers allocated for this many cells
     int n_kp = 0;
     int pu_tilemap_nt = -1;
     int pu_per_xcd = 0;
@@ -209,6 +214,8 @@ void launch_convert(EkfEngine *e, int fi, int pos, double *d_J, double *d_T3);
 void launch_ncc_pyramid(EkfEngine *e, const uint8_t *d_raw, int stride, int channels);
 void launch_ncc_capture(EkfEngine *e, const int *d_idx, const double *d_uv, int count);
 void launch_match_ncc(EkfEngine *e, int n_pred);
+void launch_gate_snapshot(EkfEngine *e, int n_pred);
+void launch_detect_cells(EkfEngine *e, int n_gates, int cells_x, int cells_y, long long *d_resp, int *d_xy);
 void launch_map_update(EkfEngine *e, const EkfMatch *d_sel, int count, const uint8_t *d_kdesc);
 
 } // namespace ekf

@@ -153,16 +153,30 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
         while (ti * (ti + 1) / 2 > b) --ti;
         const int tj = b - ti * (ti + 1) / 2;
         const int i0 = k1 + ti * NB, j0 = k1 + tj * NB;
+        // the tile's own values first: their latency hides behind the two panel products
+        double v[4];
+        bool live[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * 256;
+            const int r = i / NB, c = i % NB;
+            live[q] = i0 + r < m && j0 + c < m && j0 + c <= i0 + r;
+            v[q] = live[q] ? S[(size_t)(i0 + r) * ldS + j0 + c] : 0.0;
+        }
         for (int i = tid; i < NB * NB; i += 256) {
             const int r = i / NB, c = i % NB;
             sA[r][c] = (i0 + r < m && c < kb) ? S[(size_t)(i0 + r) * ldS + k0 + c] : 0.0;
             sB[r][c] = (j0 + r < m && c < kb) ? S[(size_t)(j0 + r) * ldS + k0 + c] : 0.0;
         }
         __syncthreads();
-        for (int i = tid; i < NB * NB; i += 256) {
+        // L_ik = S_ik Linv', L_jk = S_jk Linv' (Linv lower triangular, zeros above its diagonal: fixed trip count)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * 256;
             const int r = i / NB, c = i % NB;
             double si = 0.0, sj = 0.0;
-            for (int k2 = 0; k2 <= c; ++k2) {
+#pragma unroll
+            for (int k2 = 0; k2 < NB; ++k2) {
                 const double l = sLi[c][k2];
                 si += sA[r][k2] * l;
                 sj += sB[r][k2] * l;
@@ -181,17 +195,15 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
                 if (i0 + r < m_pad && c < kb) LL[(size_t)(k0 + c) * ldS + i0 + r] = sLI[r][c];
             }
         }
-        double v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = tid + q * 256;
             const int r = i / NB, c = i % NB;
-            v[q] = 0.0;
-            if (i0 + r < m && j0 + c < m && j0 + c <= i0 + r) {
+            if (live[q]) {
                 double s = 0.0;
 #pragma unroll
                 for (int k2 = 0; k2 < NB; ++k2) s += sLI[r][k2] * sLJ[c][k2];
-                v[q] = S[(size_t)(i0 + r) * ldS + j0 + c] - s;
+                v[q] -= s;
                 if (b != 0) S[(size_t)(i0 + r) * ldS + j0 + c] = v[q];
             }
         }

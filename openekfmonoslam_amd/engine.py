@@ -83,6 +83,7 @@ ABI = {
     "ekf_capture_templates": (_i, [_vp, _vp, _vp, _i]),
     "ekf_match_ncc": (_i, [_vp, _vp, C.POINTER(_i)]),
     "ekf_step_image": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(EkfStepInfo)]),
+    "ekf_detect_new_features": (_i, [_vp, _i, _i, C.c_double, C.c_double, _vp, C.POINTER(_i)]),
     "ekf_images_upload": (_i, [_vp, _i, _vp, _i, _i, _i, _i]),
     "ekf_select_staged_image": (_i, [_vp, _i]),
     "ekf_step_staged_image": (_i, [_vp, _i, C.POINTER(EkfStepInfo)]),
@@ -379,6 +380,14 @@ class EkfEngine:
         info = EkfStepInfo()
         self._chk(self.L.ekf_step_image(self.h, _p(img), w, h, stride, ch, C.byref(info)))
         return info
+
+    def detect_new_features(self, max_new, divide_times=2, mask_ellipse_size=10.0, min_response=1e9):
+        """detectNewImageFeatures on the current image -> [k, 2] pixel positions (k <= max_new)."""
+        out = np.zeros((max(int(max_new), 1), 2))
+        n = C.c_int(0)
+        self._chk(self.L.ekf_detect_new_features(self.h, int(max_new), int(divide_times), float(mask_ellipse_size),
+                                                 float(min_response), _p(out), C.byref(n)))
+        return out[: n.value].copy()
 
     def upload_images(self, images):
         arr = np.ascontiguousarray(np.stack(images), dtype=np.uint8)

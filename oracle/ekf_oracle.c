@@ -1262,6 +1262,116 @@ int orc_match_ncc(const OrcFilter *f, const EkfPrediction *preds, int n_pred, Ek
     return nm;
 }
 
+/* ------------------------------------------------------------------------- new-feature detection (mode B) */
+/* detectNewImageFeatures, EKF/DetectNewImageFeatures.cpp:337-367, on the current image (orc_image_set): mask =
+ * uncertainty ellipses of the predictions (buildImageMask :102-127); detector = the build's own integer Harris-type
+ * measure (the reference's OpenCV STAR is absent third-party code), best unmasked pixel of every 16x16 cell; zone
+ * heuristic = searchFeaturesByZone :171-330 with its two nondeterministic choices fixed (stable zone order, strongest
+ * candidate instead of rand()). */
+static long long corner_response(int x, int y)
+{
+    long long sxx = 0, syy = 0, sxy = 0;
+    for (int dy = -2; dy <= 2; ++dy)
+        for (int dx = -2; dx <= 2; ++dx) {
+            int cx = x + dx, cy = y + dy;
+            int a = img_at(0, cx - 1, cy - 1), b = img_at(0, cx, cy - 1), c = img_at(0, cx + 1, cy - 1);
+            int d = img_at(0, cx - 1, cy), e2 = img_at(0, cx + 1, cy);
+            int g = img_at(0, cx - 1, cy + 1), h = img_at(0, cx, cy + 1), k = img_at(0, cx + 1, cy + 1);
+            long long ix = (c + 2 * e2 + k) - (a + 2 * d + g);
+            long long iy = (g + 2 * h + k) - (a + 2 * b + c);
+            sxx += ix * ix; syy += iy * iy; sxy += ix * iy;
+        }
+    long long tr = sxx + syy;
+    return 16 * (sxx * syy - sxy * sxy) - tr * tr;
+}
+
+typedef struct { int x, y; long long r; } OrcCand;
+
+int orc_detect_new_features(const EkfPrediction *preds, int n_pred, int max_new, int divide_times,
+                            double mask_ellipse_size, double min_response, double *uv_out)
+{
+    const int w = g_img.w[0], h = g_img.h[0];
+    const int cells_x = w / 16, cells_y = h / 16, ncell = cells_x * cells_y;
+    if (ncell <= 0 || max_new <= 0) return 0;
+    float *axes = (float *)malloc(sizeof(float) * 2 * (size_t)(n_pred + 1));
+    double *ang = (double *)malloc(sizeof(double) * (size_t)(n_pred + 1));
+    for (int k = 0; k < n_pred; ++k) orc_ellipse(preds[k].covarianceMatrix, &axes[2 * k], &ang[k]);
+    OrcCand *cands = (OrcCand *)malloc(sizeof(OrcCand) * (size_t)ncell);
+    int nc = 0;
+    const long long thr = min_response >= 9.2e18 ? 0x7fffffffffffffffLL : (min_response <= 0 ? 0 : (long long)min_response);
+    for (int c = 0; c < ncell; ++c) {
+        const int cx0 = (c % cells_x) * 16, cy0 = (c / cells_x) * 16;
+        long long best = -1;
+        int bx = cx0, by = cy0;
+        for (int ly = 0; ly < 16; ++ly)
+            for (int lx = 0; lx < 16; ++lx) {
+                const int x = cx0 + lx, y = cy0 + ly;
+                if (x < 16 || y < 16 || x >= w - 16 || y >= h - 16) continue;
+                int masked = 0;
+                for (int k = 0; k < n_pred && !masked; ++k)
+                    masked = orc_point_in_ellipse((float)x, (float)y, (float)preds[k].imagePos[0], (float)preds[k].imagePos[1],
+                                                  (int)lrintf(axes[2 * k]), (int)lrintf(axes[2 * k + 1]), ang[k]);
+                if (masked) continue;
+                long long r = corner_response(x, y);
+                if (r > best) { best = r; bx = x; by = y; }
+            }
+        if (best >= 0 && best >= thr) { cands[nc].x = bx; cands[nc].y = by; cands[nc].r = best; ++nc; }
+    }
+    free(axes); free(ang);
+    int n_out = 0;
+    if (nc <= max_new) {
+        for (int i = 0; i < nc; ++i) { uv_out[2 * i] = cands[i].x; uv_out[2 * i + 1] = cands[i].y; }
+        n_out = nc;
+        free(cands);
+        return n_out;
+    }
+    const int zones_row = 1 << divide_times, nzone = zones_row * zones_row;
+    const int zw = w / zones_row > 0 ? w / zones_row : 1, zh = h / zones_row > 0 ? h / zones_row : 1;
+    int *zcount = (int *)calloc((size_t)nzone, sizeof(int));
+    int *order = (int *)malloc(sizeof(int) * (size_t)nzone);
+    int *czone = (int *)malloc(sizeof(int) * (size_t)nc);
+    char *used = (char *)calloc((size_t)nc, 1);
+#define ZONE_OF(px, py) clampi(((int)(py) / zh) * (w / zw) + (int)(px) / zw, 0, nzone - 1)
+    for (int i = 0; i < nc; ++i) czone[i] = ZONE_OF(cands[i].x, cands[i].y);
+    for (int k = 0; k < n_pred; ++k) zcount[ZONE_OF((float)preds[k].imagePos[0], (float)preds[k].imagePos[1])]++;
+    for (int z = 0; z < nzone; ++z) order[z] = z;
+    for (int a = 1; a < nzone; ++a) { /* stable insertion sort by population */
+        int v = order[a], b = a - 1;
+        while (b >= 0 && zcount[order[b]] > zcount[v]) { order[b + 1] = order[b]; --b; }
+        order[b + 1] = v;
+    }
+    const int radius = (int)lrintf((float)(2.0 * sqrt(mask_ellipse_size * EKF_CHISQ_95_2)));
+    int *ax = (int *)malloc(sizeof(int) * 2 * (size_t)max_new);
+    int left = max_new, head = 0;
+    while (head < nzone && left > 0) {
+        const int z = order[head];
+        int best = -1;
+        for (int i = 0; i < nc; ++i)
+            if (!used[i] && czone[i] == z && (best < 0 || cands[i].r > cands[best].r)) best = i;
+        if (best < 0) { ++head; continue; }
+        int free_px = 1;
+        for (int a = 0; a < n_out && free_px; ++a) {
+            double dx = (double)(float)cands[best].x - (double)(float)ax[2 * a], dy = (double)(float)cands[best].y - (double)(float)ax[2 * a + 1];
+            if (2.0 * sqrt(dx * dx + dy * dy) <= 2.0 * radius) free_px = 0;
+        }
+        if (free_px) {
+            uv_out[2 * n_out] = cands[best].x; uv_out[2 * n_out + 1] = cands[best].y;
+            ax[2 * n_out] = cands[best].x; ax[2 * n_out + 1] = cands[best].y;
+            ++n_out;
+            zcount[z]++;
+            for (int p = head; p + 1 < nzone; ++p) {
+                if (zcount[order[p]] >= zcount[order[p + 1]]) { int t = order[p]; order[p] = order[p + 1]; order[p + 1] = t; }
+                else break;
+            }
+            --left;
+        }
+        used[best] = 1;
+    }
+#undef ZONE_OF
+    free(zcount); free(order); free(czone); free(used); free(ax); free(cands);
+    return n_out;
+}
+
 /* ------------------------------------------------------------------------------------------ state update */
 
 /* stateUpdate: EKF/Update.cpp:147-204 -- apply K*nu with the DELTA dead-band on every component */

@@ -133,6 +133,9 @@ int orc_capture_templates(OrcFilter *f, const int32_t *feat_idx, const double *u
 const uint8_t *orc_templates(void);
 int orc_match_ncc(const OrcFilter *f, const EkfPrediction *preds, int n_pred, EkfMatch *out);
 int orc_step_image(OrcFilter *f, int variant, OrcStepInfo *info);
+/* detectNewImageFeatures (EKF/DetectNewImageFeatures.cpp:337) on the current image, the build's own detector; returns count */
+int orc_detect_new_features(const EkfPrediction *preds, int n_pred, int max_new, int divide_times,
+                            double mask_ellipse_size, double min_response, double *uv_out);
 
 /* Timing helper for bench.py's cpu_baseline: runs the three dense products of the LITERAL covariance update
  * (K H, I - K H, (I - K H) P ; EKF/Update.cpp:214-218) restricted to the first `rows` rows of the result and

@@ -65,6 +65,7 @@ def lib():
         L.orc_templates.restype = C.POINTER(C.c_uint8)
         L.orc_match_ncc.argtypes = [vp, vp, i32, vp]
         L.orc_step_image.argtypes = [vp, i32, vp]
+        L.orc_detect_new_features.argtypes = [vp, i32, i32, i32, C.c_double, C.c_double, vp]
         L.orc_time_literal_rows.restype = C.c_double
         L.orc_time_literal_rows.argtypes = [i32, i32, i32, vp, vp, vp, vp]
         _lib = L
@@ -267,6 +268,13 @@ class Oracle:
         preds = np.ascontiguousarray(preds, dtype=PREDICTION_DTYPE)
         out = np.zeros(max(len(preds), 1), dtype=MATCH_DTYPE)
         k = self.L.orc_match_ncc(self.h, _p(preds), len(preds), _p(out))
+        return out[:k].copy()
+
+    def detect_new_features(self, preds, max_new, divide_times=2, mask_ellipse_size=10.0, min_response=1e9):
+        preds = np.ascontiguousarray(preds, dtype=PREDICTION_DTYPE)
+        out = np.zeros((max(int(max_new), 1), 2))
+        k = self.L.orc_detect_new_features(_p(preds), len(preds), int(max_new), int(divide_times),
+                                           float(mask_ellipse_size), float(min_response), _p(out))
         return out[:k].copy()
 
     def step_image(self, image, variant=LITERAL):

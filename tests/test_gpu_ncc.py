@@ -137,3 +137,81 @@ def test_ncc_requires_an_image(eng_mod, oracle_lib):
     e.predict_measurements()
     with pytest.raises(eng_mod.EkfError):
         e.match_ncc()
+
+
+@pytest.mark.parametrize("nfeat,max_new", [(40, 25), (40, 500), (150, 60)])
+def test_detect_new_features_identical(eng_mod, oracle_lib, nfeat, max_new):
+    """masked corner candidates + zone heuristic: device/host engine path == oracle (integer measure: identical)"""
+    seq = SyntheticSequence(nfeat, 2)
+    e, o = _with_templates(eng_mod, oracle_lib, seq)
+    # no predictions yet (EKF::init: detectNewImageFeatures(image, noPredictions, ...), EKF.cpp:196)
+    none = np.zeros(0, dtype=oracle_lib.PREDICTION_DTYPE)
+    np.testing.assert_array_equal(e.detect_new_features(max_new), o.detect_new_features(none, max_new))
+    # with the predictions of a frame masking their ellipses
+    img = seq.render_image(1)
+    e.upload_image(img)
+    o.set_image(img)
+    e.predict()
+    o.predict()
+    e.predict_measurements()
+    preds, _, _ = o.predict_measurements()
+    ug, uo = e.detect_new_features(max_new), o.detect_new_features(preds, max_new)
+    assert len(uo) > 0
+    np.testing.assert_array_equal(ug, uo)
+    # a high threshold leaves nothing
+    assert len(e.detect_new_features(max_new, min_response=1e30)) == 0
+
+
+def test_image_pipeline_init_track_and_grow(eng_mod, oracle_lib):
+    """EKF::init(image) / step(image) / map management in matcher mode B, engine vs oracle, same calls on both:
+    reset -> detect -> add -> capture templates; frames: step_image; then remove bad, convert, detect, add."""
+    seq = SyntheticSequence(60, 4)
+    e = eng_mod.EkfEngine(seq.cam, seq.par, 128)
+    o = oracle_lib.Oracle(seq.cam, seq.par, 128)
+    img0 = seq.render_image(0)
+    e.reset()
+    o.reset()
+    e.upload_image(img0)
+    o.set_image(img0)
+    none = np.zeros(0, dtype=oracle_lib.PREDICTION_DTYPE)
+    uv = e.detect_new_features(40)
+    np.testing.assert_array_equal(uv, o.detect_new_features(none, 40))
+    assert len(uv) == 40
+    e.add_features(uv)
+    for p in uv:
+        o.add_feature(p)
+    idx = np.arange(len(uv))
+    e.capture_templates(idx, uv)
+    o.capture_templates(idx, uv)
+    # the synthetic camera moves with a known velocity; give both filters the same prior
+    x, fp, P = e.get_state()
+    x[7:10] = [0.01, 0.0, 0.002]
+    x[10:13] = [2.22e-16, 0.002, 2.22e-16]
+    ftype = np.full(len(uv), 2, dtype=np.int32)
+    e.set_state(x, fp, ftype, None, P)
+    o.set_state(x, fp, ftype, None, P)
+    e.upload_image(img0)
+    e.capture_templates(idx, uv)
+    for t in range(1, 4):
+        img = seq.render_image(t, outlier_fraction=0.0)
+        gi = e.step_image(img)
+        oi = o.step_image(img, ALGORITHMIC)
+        for f in ("n_predicted", "n_matches", "n_inliers", "n_rescued", "status"):
+            assert getattr(gi, f) == getattr(oi, f), (t, f, getattr(gi, f), getattr(oi, f))
+        assert gi.n_matches >= 25
+    assert_state_close(e, o, 1e-8, "image pipeline, 3 frames")
+    # map management, reference order (EKF.cpp:575-612)
+    assert e.remove_bad_features() == o.remove_bad_features()
+    assert e.convert_inverse_depth_to_depth() == o.convert_inverse_depth_to_depth()
+    preds = o.predict_measurements()[0]  # the oracle is handed this step's gates explicitly
+    e.predict_measurements()
+    want = 10
+    uvn = e.detect_new_features(want)
+    np.testing.assert_array_equal(uvn, o.detect_new_features(preds, want))
+    n0 = e.N
+    e.add_features(uvn)
+    for p in uvn:
+        o.add_feature(p)
+    e.capture_templates(np.arange(n0, n0 + len(uvn)), uvn)
+    assert e.N == o.N == n0 + len(uvn)
+    assert_state_close(e, o, 1e-8, "after map management")

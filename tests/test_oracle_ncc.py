@@ -105,3 +105,35 @@ def test_step_image_tracks(oracle_lib):
         assert info.n_inliers + info.n_rescued >= 0.8 * info.n_matches
     x = o.x13()
     assert np.linalg.norm(x[0:3] - seq.truth_r[4]) < 0.05
+
+
+def test_detector_finds_unmasked_corners(oracle_lib):
+    """new-feature detection (the build's own corner measure + the reference's zone heuristic)"""
+    seq = SyntheticSequence(40, 2)
+    o = _seeded(seq)
+    img = seq.render_image(0)
+    o.set_image(img)
+    none = np.zeros(0, dtype=[("featureIndex", "<i4"), ("_pad", "<i4"), ("imagePos", "<f8", (2,)),
+                              ("covarianceMatrix", "<f8", (4,))])
+    uv = o.detect_new_features(none, 25)
+    assert len(uv) == 25
+    # picks sit on the pasted texture patches (the only structure in the frame), away from the border
+    px = seq.pixel_positions(0)
+    d = np.abs(uv[:, None, :] - px[None, :, :]).max(axis=2).min(axis=1)
+    assert (d <= 10).mean() > 0.9
+    assert uv[:, 0].min() >= 16 and uv[:, 1].min() >= 16 and uv[:, 0].max() < 640 - 16 and uv[:, 1].max() < 480 - 16
+    # spread: with 16 zones and 25 picks no zone that has candidates is left empty while another holds > 3
+    zones = (uv[:, 1].astype(int) // 120) * 4 + uv[:, 0].astype(int) // 160
+    assert np.bincount(zones, minlength=16).max() <= 4
+    # mask of the picks themselves: no two closer than the disc radius (15 px)
+    dd = np.sqrt(((uv[:, None, :] - uv[None, :, :]) ** 2).sum(-1)) + np.eye(len(uv)) * 1e9
+    assert dd.min() > 15
+    # predictions mask their ellipses: nothing is picked inside a predicted feature's gate
+    o.predict()
+    preds, _, _ = o.predict_measurements()
+    uv2 = o.detect_new_features(preds, 25)
+    for p in preds:
+        ax, ang = o.ellipse(p["covarianceMatrix"])
+        for q in uv2:
+            assert not o.point_in_ellipse(float(q[0]), float(q[1]), float(p["imagePos"][0]), float(p["imagePos"][1]),
+                                          int(np.rint(ax[0])), int(np.rint(ax[1])), ang)
