@@ -111,6 +111,13 @@ int ekf_remove_bad_features(EkfEngine *e, int *n_removed);
 /* convertMapFeaturesInverseDepthToDepth(state, P)         EKF/MapManagement.cpp:494-521 (at most one per call;
  * converted_index receives the feature index or -1) */
 int ekf_convert_inverse_depth_to_depth(EkfEngine *e, int *converted_index);
+/* the 13x13 camera block of the covariance, row-major: what EKF::step logs as StateCovarianceMatrixEstimation
+ * (EKF/EKF.cpp:626) -- without moving the whole matrix */
+int ekf_get_camera_covariance(EkfEngine *e, double P13[169]);
+/* features the last full prediction did not see (unseenFeatures of predictCameraMeasurements,
+ * EKF/MeasurementPrediction.cpp:705; EKF::step removes them under the conditions of EKF/EKF.cpp:583-592).
+ * Ascending feature indices; feat_idx may be NULL to get the count only. */
+int ekf_get_unseen_features(EkfEngine *e, int32_t *feat_idx, int *count);
 /* MapFeature::featureType / covarianceMatrixPos of every feature (EKF/MapFeature.h:60-68) */
 int ekf_get_feature_layout(EkfEngine *e, int32_t *type, int32_t *covpos);
 

@@ -415,6 +415,40 @@ int ekf_reset(EkfEngine *e)
     return ekf_set_state(e, x, 0, nullptr, nullptr, nullptr, P);
 }
 
+int ekf_get_camera_covariance(EkfEngine *e, double P13[169])
+{
+    if (!e || !P13) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->f32) {
+        float tmp[169];
+        HIPCHK(hipMemcpy2D(tmp, 13 * 4, e->d.P, (size_t)e->ldP * 4, 13 * 4, 13, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 169; ++i) P13[i] = (double)tmp[i];
+    } else {
+        HIPCHK(hipMemcpy2D(P13, 13 * 8, e->d.P, (size_t)e->ldP * 8, 13 * 8, 13, hipMemcpyDeviceToHost));
+    }
+    return EKF_OK;
+}
+
+int ekf_get_unseen_features(EkfEngine *e, int32_t *feat_idx, int *count)
+{
+    if (!e || !count) return EKF_ERR_INVALID_ARG;
+    *count = 0;
+    if (e->N == 0) return EKF_OK;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    std::vector<int> vis(e->N);
+    HIPCHK(hipMemcpy(vis.data(), e->d.pred_vis, (size_t)e->N * sizeof(int), hipMemcpyDeviceToHost));
+    int k = 0;
+    for (int i = 0; i < e->N; ++i)
+        if (!vis[i]) {
+            if (feat_idx) feat_idx[k] = i;
+            ++k;
+        }
+    *count = k;
+    return EKF_OK;
+}
+
 int ekf_get_feature_layout(EkfEngine *e, int32_t *type, int32_t *covpos)
 {
     if (!e) return EKF_ERR_INVALID_ARG;

@@ -65,6 +65,8 @@ ABI = {
     "ekf_remove_bad_features": (_i, [_vp, C.POINTER(_i)]),
     "ekf_convert_inverse_depth_to_depth": (_i, [_vp, C.POINTER(_i)]),
     "ekf_get_feature_layout": (_i, [_vp, _vp, _vp]),
+    "ekf_get_camera_covariance": (_i, [_vp, _vp]),
+    "ekf_get_unseen_features": (_i, [_vp, _vp, C.POINTER(_i)]),
     "ekf_state_dim": (_i, [_vp]),
     "ekf_num_features": (_i, [_vp]),
     "ekf_predict": (_i, [_vp]),
@@ -233,6 +235,17 @@ class EkfEngine:
         P = P_out if P_out is not None else (np.zeros((self.n, self.n)) if want_P else None)
         self._chk(self.L.ekf_get_state(self.h, _p(x), _p(fp), _p(P)))
         return x, fp[: self.N], P
+
+    def camera_covariance(self):
+        P = np.zeros((13, 13))
+        self._chk(self.L.ekf_get_camera_covariance(self.h, _p(P)))
+        return P
+
+    def unseen_features(self):
+        idx = np.zeros(max(self.N, 1), dtype=np.int32)
+        n = C.c_int(0)
+        self._chk(self.L.ekf_get_unseen_features(self.h, _p(idx), C.byref(n)))
+        return idx[: n.value].copy()
 
     # ---- map management
     def reset(self):
