@@ -153,39 +153,72 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
         while (ti * (ti + 1) / 2 > b) --ti;
         const int tj = b - ti * (ti + 1) / 2;
         const int i0 = k1 + ti * NB, j0 = k1 + tj * NB;
-        // the tile's own values first: their latency hides behind the two panel products
+        // Each wavefront owns one 16x16 block (bi, bj) of the 32x32 tile; the three 32^3 products run on the fp64 MFMA
+        // (v_mfma_f64_16x16x4: lane l feeds a[l % 16][l / 16] and b[l / 16][l % 16], holds rows (l >> 4) + 4 v of column
+        // l & 15) -- as plain FMA loops they were LDS-bound and cost 4 of the 19 us of this launch's critical path.
+        typedef double acc4 __attribute__((ext_vector_type(4)));
+        const int lane = tid & 63, wv = tid >> 6;
+        const int bi = wv >> 1, bj = wv & 1;
+        const int lr = lane & 15, lk = lane >> 4;
+        const bool diag_tile = ti == tj;
+        // the tile's own values first (accumulator layout): their latency hides behind the panel products
         double v[4];
         bool live[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int i = tid + q * 256;
-            const int r = i / NB, c = i % NB;
+            const int r = 16 * bi + lk + 4 * q, c = 16 * bj + lr;
             live[q] = i0 + r < m && j0 + c < m && j0 + c <= i0 + r;
             v[q] = live[q] ? S[(size_t)(i0 + r) * ldS + j0 + c] : 0.0;
         }
         for (int i = tid; i < NB * NB; i += 256) {
             const int r = i / NB, c = i % NB;
             sA[r][c] = (i0 + r < m && c < kb) ? S[(size_t)(i0 + r) * ldS + k0 + c] : 0.0;
-            sB[r][c] = (j0 + r < m && c < kb) ? S[(size_t)(j0 + r) * ldS + k0 + c] : 0.0;
+            if (!diag_tile) sB[r][c] = (j0 + r < m && c < kb) ? S[(size_t)(j0 + r) * ldS + k0 + c] : 0.0;
         }
         __syncthreads();
-        // L_ik = S_ik Linv', L_jk = S_jk Linv' (Linv lower triangular, zeros above its diagonal: fixed trip count)
+        // L_ik = S_ik Linv', L_jk = S_jk Linv'
+        {
+            acc4 ci = {0, 0, 0, 0}, cj = {0, 0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + q * 256;
-            const int r = i / NB, c = i % NB;
-            double si = 0.0, sj = 0.0;
-#pragma unroll
-            for (int k2 = 0; k2 < NB; ++k2) {
-                const double l = sLi[c][k2];
-                si += sA[r][k2] * l;
-                sj += sB[r][k2] * l;
+            for (int k4 = 0; k4 < NB; k4 += 4) {
+                const double l = sLi[16 * bj + lr][k4 + lk]; // b[k][c] = Linv[c][k]
+                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[16 * bi + lr][k4 + lk], l, ci, 0, 0, 0);
+                if (!diag_tile) cj = __builtin_amdgcn_mfma_f64_16x16x4f64(sB[16 * bi + lr][k4 + lk], l, cj, 0, 0, 0);
             }
-            sLI[r][c] = si;
-            sLJ[r][c] = sj;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sLI[16 * bi + lk + 4 * q][16 * bj + lr] = ci[q];
+                sLJ[16 * bi + lk + 4 * q][16 * bj + lr] = diag_tile ? ci[q] : cj[q];
+            }
         }
         __syncthreads();
-        if (tj == 0) { // L_ik for the doubling levels: below the diagonal and, mirrored, above it (zero rows m..m_pad)
+        {
+            acc4 cu = {0, 0, 0, 0};
+#pragma unroll
+            for (int k4 = 0; k4 < NB; k4 += 4)
+                cu = __builtin_amdgcn_mfma_f64_16x16x4f64(sLI[16 * bi + lr][k4 + lk], sLJ[16 * bj + lr][k4 + lk], cu, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (live[q]) {
+                    v[q] -= cu[q];
+                    if (b != 0) S[(size_t)(i0 + 16 * bi + lk + 4 * q) * ldS + j0 + 16 * bj + lr] = v[q];
+                }
+        }
+        if (b == 0) {
+            // look-ahead: this workgroup owns block (k+1, k+1); finish it in LDS, factorise, publish its inverse
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 16 * bi + lk + 4 * q, c = 16 * bj + lr;
+                const bool lv = (k1 + r < m) && (c <= r);
+                sA[r][c] = lv ? v[q] : ((r == c) ? 1.0 : 0.0);
+            }
+            __syncthreads();
+            if (!block_chol_inv32_bp(sA, sB) && tid == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
+            store_linv(V, W, Wf, ldw, k1, sB);
+        }
+        if (tj == 0) { // L_ik for the doubling levels: below the diagonal and, mirrored, above it (zero rows m..m_pad);
+                       // after the factorisation in tile 0, off its critical path
             for (int i = tid; i < NB * NB; i += 256) {
                 const int r = i / NB, c = i % NB;
                 if (i0 + r < m_pad && c < kb) LL[(size_t)(i0 + r) * ldS + k0 + c] = sLI[r][c];
@@ -195,31 +228,6 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
                 if (i0 + r < m_pad && c < kb) LL[(size_t)(k0 + c) * ldS + i0 + r] = sLI[r][c];
             }
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + q * 256;
-            const int r = i / NB, c = i % NB;
-            if (live[q]) {
-                double s = 0.0;
-#pragma unroll
-                for (int k2 = 0; k2 < NB; ++k2) s += sLI[r][k2] * sLJ[c][k2];
-                v[q] -= s;
-                if (b != 0) S[(size_t)(i0 + r) * ldS + j0 + c] = v[q];
-            }
-        }
-        if (b != 0) return;
-        // look-ahead: this workgroup owns block (k+1, k+1); finish it in LDS, factorise, publish its inverse
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + q * 256;
-            const int r = i / NB, c = i % NB;
-            const bool live = (k1 + r < m) && (c <= r);
-            sA[r][c] = live ? v[q] : ((r == c) ? 1.0 : 0.0);
-        }
-        __syncthreads();
-        if (!block_chol_inv32_bp(sA, sB) && tid == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
-        store_linv(V, W, Wf, ldw, k1, sB);
         return;
     }
     // nu block
