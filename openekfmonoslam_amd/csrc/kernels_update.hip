@@ -89,7 +89,7 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 // -------------------------------------------------------------------------------------- blocked Cholesky sweep
 // Right-looking sweep over [ S | nu ], panel width NB = 32, ONE launch per panel (k_chol_step).  The only serial
 // piece is the 32x32 diagonal block: its Cholesky factor and the inverse of that factor.  It is computed by one
-// workgroup with all 256 threads working in LDS (block_chol_inv32_bp in chol32.h: 4x4 block pivots, one barrier per
+// workgroup with all 256 threads working in LDS (block_chol_inv32_mf in chol32.h: 4x4 block pivots, rank-4 updates on the fp64 MFMA, one barrier per
 // block column) and -- look-ahead -- inside the launch of the PREVIOUS panel, by the workgroup that owns tile
 // (k+1, k+1): while the other workgroups of that launch update their tiles, this one finishes its tile, factorises
 // it and stores inv(L_{k+1,k+1}) into V / W.  The panel solve L_ik = S_ik inv(L_kk)' is not a launch of its own:
@@ -119,7 +119,7 @@ k_chol_diag0(const double *S, int ldS, int kb, double *V, double *W, float *Wf, 
         sa[r][c] = (r < kb && c <= r) ? S[(size_t)r * ldS + c] : ((r == c) ? 1.0 : 0.0);
     }
     __syncthreads();
-    if (!block_chol_inv32_bp(sa, sx) && threadIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
+    if (!block_chol_inv32_mf(sa, sx) && threadIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
     store_linv(V, W, Wf, ldw, 0, sx);
 }
 
@@ -214,7 +214,7 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
                 sA[r][c] = lv ? v[q] : ((r == c) ? 1.0 : 0.0);
             }
             __syncthreads();
-            if (!block_chol_inv32_bp(sA, sB) && tid == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
+            if (!block_chol_inv32_mf(sA, sB) && tid == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
             store_linv(V, W, Wf, ldw, k1, sB);
         }
         if (tj == 0) { // L_ik for the doubling levels: below the diagonal and, mirrored, above it (zero rows m..m_pad);
@@ -275,7 +275,11 @@ k_triinv_level(const double *S, int ldS, int m, int m_pad, double *V, double *W,
     const int r0 = pair * 2 * s; // first row of the pair's 2s x 2s diagonal block
     if (r0 + s + tr * NB >= m_pad) return; // no such rows in the second half
     const int tid = threadIdx.x;
-    double acc[4] = {0, 0, 0, 0};
+    // 16x16 block (bi, bj) of the 32x32 output tile per wavefront, products on the fp64 MFMA (as in k_chol_step)
+    typedef double acc4 __attribute__((ext_vector_type(4)));
+    const int lane = tid & 63, wv = tid >> 6;
+    const int bi = wv >> 1, bj = wv & 1, lr = lane & 15, lk = lane >> 4;
+    acc4 acc = {0, 0, 0, 0};
     for (int kk = 0; kk < s; kk += NB) {
         for (int i = tid; i < NB * NB; i += 256) {
             const int r = i / NB, c = i % NB;
@@ -293,20 +297,13 @@ k_triinv_level(const double *S, int ldS, int m, int m_pad, double *V, double *W,
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + q * 256;
-            const int r = i / NB, c = i % NB;
-            double sacc = 0.0;
-#pragma unroll
-            for (int k2 = 0; k2 < NB; ++k2) sacc += sA[r][k2] * sB[k2][c];
-            acc[q] += sacc;
-        }
+        for (int k4 = 0; k4 < NB; k4 += 4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[16 * bi + lr][k4 + lk], sB[k4 + lk][16 * bj + lr], acc, 0, 0, 0);
         __syncthreads();
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int i = tid + q * 256;
-        const int r = i / NB, c = i % NB;
+        const int r = 16 * bi + lk + 4 * q, c = 16 * bj + lr;
         const int gi = r0 + s + tr * NB + r, gj = tc * NB + c;
         if (mode == 0) {
             Tbuf[(size_t)gi * ldw + gj] = acc[q];
