@@ -1,0 +1,160 @@
+"""Edge cases of the path, HIP engine through the C ABI vs the oracle: empty and ragged inputs (no keypoints, no
+visible features, empty map), update sizes that straddle every blocking boundary of the solver (32-wide panels,
+64/128-wide GEMM tiles, the 256 threshold between the small and the MFMA inverse levels), a frame in which every
+match is an outlier, an indefinite innovation covariance, and the fp32-covariance drift over a long run."""
+import numpy as np
+import pytest
+
+from openekfmonoslam_amd.ekftypes import KEYPOINT_DTYPE, MATCH_DTYPE
+from openekfmonoslam_amd.synth import SyntheticSequence
+from tests.oracle_lib import ALGORITHMIC, align_to_matches
+from tests.test_gpu_parity import (F32_TOL, F32_TOL_OMEGA, F64_TOL, assert_state_close, block_errs, eng_mod, make_pair,  # noqa: F401
+                                   rel_fro, rel_max)
+
+pytestmark = pytest.mark.gpu
+INFO = ("n_predicted", "n_matches", "n_hypotheses", "n_inliers", "n_outliers", "n_rescued", "status")
+
+
+def _same_info(gi, oi, where):
+    for f in INFO:
+        assert getattr(gi, f) == getattr(oi, f), (where, f, getattr(gi, f), getattr(oi, f))
+
+
+def _matches_from_predictions(preds, M):
+    """M matches: the first M predicted features, measured at their prediction plus a fraction of a pixel"""
+    assert len(preds) >= M
+    rng = np.random.default_rng(100 + M)
+    m = np.zeros(M, dtype=MATCH_DTYPE)
+    m["featureIndex"] = preds["featureIndex"][:M]
+    m["keypointIndex"] = np.arange(M)
+    m["imagePos"] = preds["imagePos"][:M] + rng.normal(0.0, 0.3, (M, 2))
+    return m
+
+
+def test_frame_without_keypoints(eng_mod, oracle_lib, seq12):
+    """no detections: prediction only, nothing matched, no update (EKF.cpp:337-430 with empty vectors)"""
+    e, o = make_pair(eng_mod, oracle_lib, seq12)
+    kps = np.zeros(0, dtype=KEYPOINT_DTYPE)
+    desc = np.zeros((0, 32), dtype=np.uint8)
+    gi = e.step(kps, desc)
+    oi = o.step(kps, desc, ALGORITHMIC)
+    _same_info(gi, oi, "empty frame")
+    assert gi.n_matches == 0 and gi.n_predicted == 12
+    assert_state_close(e, o, 1e-12, "empty frame")
+    # and a normal frame afterwards
+    gi = e.step(*seq12.frames[1])
+    oi = o.step(*seq12.frames[1], ALGORITHMIC)
+    _same_info(gi, oi, "frame after the empty one")
+    assert_state_close(e, o, F64_TOL, "frame after the empty one")
+
+
+def test_no_feature_visible(eng_mod, oracle_lib, seq12):
+    """camera turned away: every feature fails the visibility test (MeasurementPrediction.cpp:233-262)"""
+    e, o = make_pair(eng_mod, oracle_lib, seq12)
+    x = np.array(seq12.x13)
+    x[3:7] = [0.0, 0.0, 1.0, 0.0]  # half a turn about y: the map is behind the camera
+    for f in (e, o):
+        f.set_state(x, seq12.feature_pos, seq12.feature_type, seq12.feature_desc, seq12.P0)
+    gi = e.step(*seq12.frames[0])
+    oi = o.step(*seq12.frames[0], ALGORITHMIC)
+    _same_info(gi, oi, "nothing visible")
+    assert gi.n_predicted == 0 and gi.n_matches == 0
+    assert_state_close(e, o, 1e-12, "nothing visible")
+    assert len(e.unseen_features()) == 12
+
+
+def test_empty_map(eng_mod, oracle_lib, seq12):
+    """N = 0: the 13-state filter alone (initState / initCovariance, then steps)"""
+    e = eng_mod.EkfEngine(seq12.cam, seq12.par, 16)
+    o = oracle_lib.Oracle(seq12.cam, seq12.par, 16)
+    e.reset()
+    o.reset()
+    for t in range(2):
+        gi = e.step(*seq12.frames[t])
+        oi = o.step(*seq12.frames[t], ALGORITHMIC)
+        _same_info(gi, oi, f"empty map, frame {t}")
+    assert e.n == 13
+    assert_state_close(e, o, 1e-12, "empty map")
+
+
+@pytest.mark.parametrize("M", [1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 160])
+def test_update_sizes_across_block_boundaries(eng_mod, oracle_lib, M):
+    """m = 2M rows of S: 2 .. 320, i.e. below / at / above one panel, one fp64 GEMM tile (64), one fp32 tile (128), and
+    the 256 switch of the inverse's doubling levels"""
+    seq = SyntheticSequence(170, 1, outlier_fraction=0.0, distractors_per_feature=0.0, max_bit_flips=0)
+    e, o = make_pair(eng_mod, oracle_lib, seq)
+    e.predict()
+    o.predict()
+    e.predict_measurements()
+    preds, Hs, Hf = o.predict_measurements()
+    mo = _matches_from_predictions(preds, M)
+    mp, mHs, mHf = align_to_matches(preds, Hs, Hf, mo)
+    assert o.update(mo, mp, mHs, mHf, ALGORITHMIC) == 0
+    e.update(mo)
+    assert_state_close(e, o, F64_TOL, f"update with M = {M}")
+
+
+def test_update_sizes_fp32(eng_mod, oracle_lib):
+    seq = SyntheticSequence(170, 1, outlier_fraction=0.0, distractors_per_feature=0.0, max_bit_flips=0)
+    for M in (17, 64, 129, 160):
+        e, o = make_pair(eng_mod, oracle_lib, seq, precision=1)
+        e.predict()
+        o.predict()
+        e.predict_measurements()
+        preds, Hs, Hf = o.predict_measurements()
+        mo = _matches_from_predictions(preds, M)
+        mp, mHs, mHf = align_to_matches(preds, Hs, Hf, mo)
+        assert o.update(mo, mp, mHs, mHf, ALGORITHMIC) == 0
+        e.update(mo)
+        x, fp, P = e.get_state()
+        assert rel_max(P, o.P()) <= F32_TOL and rel_fro(P, o.P()) <= F32_TOL, M
+
+
+def test_all_matches_are_outliers(eng_mod, oracle_lib, seq12):
+    """every keypoint displaced by the same gross offset: RANSAC keeps its one-point hypothesis, the rest go through
+    the re-prediction / rescue path (EKF.cpp:441-556)"""
+    e, o = make_pair(eng_mod, oracle_lib, seq12)
+    kps, desc = seq12.frames[0]
+    bad = kps.copy()
+    rng = np.random.default_rng(9)
+    bad["x"] += rng.uniform(-6, 6, len(bad)).astype(np.float32)
+    bad["y"] += rng.uniform(-6, 6, len(bad)).astype(np.float32)
+    gi = e.step(bad, desc)
+    oi = o.step(bad, desc, ALGORITHMIC)
+    _same_info(gi, oi, "scattered keypoints")
+    assert_state_close(e, o, F64_TOL, "scattered keypoints")
+
+
+def test_indefinite_innovation_covariance_is_reported(eng_mod, seq12):
+    """S = H P H' + R not positive definite (P made indefinite on purpose): the engine reports it
+    (EKF_ERR_NOT_POSITIVE_DEFINITE) instead of returning cv::invert's silent zeros (Update.cpp:101-103)"""
+    e = eng_mod.EkfEngine(seq12.cam, seq12.par, 16, max_keypoints=128)
+    P = -1e3 * np.eye(seq12.state_dim)
+    e.set_state(seq12.x13, seq12.feature_pos, seq12.feature_type, seq12.feature_desc, P)
+    e.predict()
+    preds, _, _ = e.predict_measurements()
+    m = np.zeros(4, dtype=MATCH_DTYPE)
+    m["featureIndex"] = preds["featureIndex"][:4]
+    m["imagePos"] = preds["imagePos"][:4] + 0.5
+    with pytest.raises(eng_mod.EkfError) as ei:
+        e.update(m)
+    assert ei.value.code == 3
+
+
+def test_fp32_covariance_drift_over_90_frames(eng_mod, oracle_lib):
+    """'for fp32 configs also report the drift after 90 frames' -- N = 100, fp32 covariance vs the fp64
+    oracle, same frames; decisions (matches / inliers / rescued) must stay identical, errors inside the stated bars"""
+    seq = SyntheticSequence(100, 90)
+    e, o = make_pair(eng_mod, oracle_lib, seq, precision=1)
+    for t in range(90):
+        gi = e.step(*seq.frames[t])
+        oi = o.step(*seq.frames[t], ALGORITHMIC)
+        _same_info(gi, oi, f"frame {t}")
+    x, fp, P = e.get_state()
+    be = block_errs(x, fp, o.x13(), o.feature_pos())
+    pm, pf = rel_max(P, o.P()), rel_fro(P, o.P())
+    print(f"fp32 drift after 90 frames: P max {pm:.2e} fro {pf:.2e} blocks {be}")
+    assert pm <= F32_TOL and pf <= F32_TOL
+    for name in ("r", "q", "v", "features"):
+        assert be[name] <= F32_TOL, (name, be[name])
+    assert be["w"] <= F32_TOL_OMEGA
