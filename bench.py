@@ -102,6 +102,10 @@ def main():
     ap.add_argument("--emulate-shards", type=int, default=0,
                     help="functional check on ONE GPU: run the sharded filter with this many ranks in one process "
                          "(device-to-device exchange); not a scaling number")
+    ap.add_argument("--matcher", default="descriptors", choices=["descriptors", "ncc"],
+                    help="descriptors: matcher mode A, keypoints + 32-byte descriptors per frame (the reference's "
+                         "matcher downstream of its detector); ncc: mode B, rendered frames staged in HBM, gray "
+                         "pyramid + template NCC per frame (BASELINE configs[3-4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-pass", action="store_true")
     args = ap.parse_args()
@@ -140,14 +144,23 @@ def main():
             eng.set_exchange(DistributedExchange(ranks.dist, ranks.device))
         eng.upload_frames(seq.frames)
     P0 = 0.5 * (seq.P0 + seq.P0.T) if (sharded or group) else seq.P0
+    ncc = args.matcher == "ncc"
+    if ncc:  # frames 1..n rendered on the host, staged in HBM; templates cut from frame 0
+        images = [seq.render_image(t) for t in range(1, n_frames + 1)]
+        img0, uv0 = seq.render_image(0), seq.pixel_positions(0).astype(np.float64)
+        for e in (group.engines if group else [eng]):
+            e.upload_images(images)
 
     def run(timing):
         for e in (group.engines if group else [eng]):
             e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, P0)
+            if ncc:
+                e.upload_image(img0)
+                e.capture_templates(np.arange(N), uv0)
             e.timing(timing)
 
         def frames(e, lo, hi):
-            return [e.step_frame(t) for t in range(lo, hi)]
+            return [(e.step_staged_image(t) if ncc else e.step_frame(t)) for t in range(lo, hi)]
 
         if group:
             group.run(lambda r, e: frames(e, 0, args.warmup))
@@ -171,7 +184,7 @@ def main():
     elapsed = ranks.max_over_ranks(elapsed)
 
     roof, stages = None, None
-    pmc_traffic = committed_pmc_traffic(args.workload)
+    pmc_traffic = committed_pmc_traffic(args.workload) if args.matcher == "descriptors" else (None, None)
     if not args.no_roofline_pass:
         _, _ = run(True)
         tm = eng.timing_get()
@@ -240,8 +253,10 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"synthetic {W}x{H} sequence, N={N} inverse-depth features (n={13 + 6 * N}), "
-                        f"{'fp32' if precision else 'fp64'} covariance, {len(seq.frames[0][0])} keypoints/frame, "
-                        "fixed map",
+                        f"{'fp32' if precision else 'fp64'} covariance, "
+                        + (f"{len(seq.frames[0][0])} keypoints/frame (matcher mode A)" if not ncc else
+                           "rendered frames staged in HBM, 3-level pyramid + 11x11 NCC templates (matcher mode B)")
+                        + ", fixed map",
             "name": args.workload,
             "parallelism": par_desc,
             "mean_matches": float(np.mean([i.n_matches for i in infos])),
@@ -252,7 +267,7 @@ def main():
         "roofline": roof,
         "stage_ms_per_step": stages,
     }
-    if world == 1 and not group and not args.no_cpu_baseline:
+    if world == 1 and not group and not ncc and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(seq, args.workload)
     else:
         out["cpu_baseline"] = None
