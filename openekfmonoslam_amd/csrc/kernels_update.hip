@@ -141,9 +141,17 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
     const int tid = threadIdx.x;
     const int k1 = k0 + kb;
     const int b = blockIdx.x;
-    for (int i = tid; i < NB * NB; i += 256) {
-        const int r = i / NB, c = i % NB;
-        sLi[r][c] = V[(size_t)(k0 + r) * ldw + k0 + c];
+    // every global load of the prologue is issued before the first LDS store waits on one of them (the look-ahead
+    // workgroup's inputs are cold: they were written by the previous launch on other XCDs)
+    double gv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid + q * 256;
+        gv[q] = V[(size_t)(k0 + i / NB) * ldw + k0 + i % NB];
+    }
+    if (b >= n_stiles) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sLi[(tid + q * 256) / NB][(tid + q * 256) % NB] = gv[q];
     }
     if (b < n_stiles) {
         __shared__ double sLI[NB][NB + 1];
@@ -170,10 +178,21 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
             live[q] = i0 + r < m && j0 + c < m && j0 + c <= i0 + r;
             v[q] = live[q] ? S[(size_t)(i0 + r) * ldS + j0 + c] : 0.0;
         }
-        for (int i = tid; i < NB * NB; i += 256) {
+        double ga[4], gb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * 256;
             const int r = i / NB, c = i % NB;
-            sA[r][c] = (i0 + r < m && c < kb) ? S[(size_t)(i0 + r) * ldS + k0 + c] : 0.0;
-            if (!diag_tile) sB[r][c] = (j0 + r < m && c < kb) ? S[(size_t)(j0 + r) * ldS + k0 + c] : 0.0;
+            ga[q] = (i0 + r < m && c < kb) ? S[(size_t)(i0 + r) * ldS + k0 + c] : 0.0;
+            gb[q] = (!diag_tile && j0 + r < m && c < kb) ? S[(size_t)(j0 + r) * ldS + k0 + c] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * 256;
+            const int r = i / NB, c = i % NB;
+            sLi[r][c] = gv[q];
+            sA[r][c] = ga[q];
+            if (!diag_tile) sB[r][c] = gb[q];
         }
         __syncthreads();
         // L_ik = S_ik Linv', L_jk = S_jk Linv'
