@@ -5,22 +5,24 @@
 //     one GEMM with no sequential dependency between row blocks]
 //   * the upper levels (block size >= 256) of the recursive inverse of L:  X21 = -X22 L21 X11
 // Same tiling as the covariance downdate (kernels_pupdate.hip): 256 threads = 2 x 2 wavefronts x (2 x 2 MFMA
-// blocks), tile TM = 4 MB (fp32 128, fp64 64), k-slab 16, register-staged double buffering through LDS.
+// blocks), tile TM = 4 MB (fp32 128, fp64 64), k-slab 16 (fp32) / 32 (fp64), register-staged double buffering through LDS.
 #include "engine.h"
 #include "mma_tile.h"
 
 namespace ekf {
 
-template <typename T>
+// BK: k-slab depth.  The fp64 instances are small, latency-bound GEMMs (a 64x64 tile's MFMAs of one 16-deep slab take
+// 0.2 us, a global load round trip over 1 us), so they run with 32-deep slabs: half as many round trips.
+template <typename T, int BK>
 __global__ void __launch_bounds__(256, 2) k_xty(XtyArgs a)
 {
     using M = Mma<T>;
     constexpr int MB = M::MB, TM = 4 * MB, VEC = M::VEC;
-    constexpr int LOADS = PU_BK * TM / (256 * VEC);
-    static_assert(LOADS == 2, "two 16-byte pieces per thread and slab");
-    __shared__ __attribute__((aligned(16))) T smem[4 * PU_BK * TM];
-    T(*sI)[PU_BK][TM] = reinterpret_cast<T(*)[PU_BK][TM]>(smem);
-    T(*sJ)[PU_BK][TM] = reinterpret_cast<T(*)[PU_BK][TM]>(smem + 2 * PU_BK * TM);
+    constexpr int LOADS = BK * TM / (256 * VEC);
+    static_assert(LOADS == 2 || LOADS == 4, "two or four 16-byte pieces per thread and slab");
+    __shared__ __attribute__((aligned(16))) T smem[4 * BK * TM];
+    T(*sI)[BK][TM] = reinterpret_cast<T(*)[BK][TM]>(smem);
+    T(*sJ)[BK][TM] = reinterpret_cast<T(*)[BK][TM]>(smem + 2 * BK * TM);
 
     const int per = a.tiles_i * a.tiles_j;
     const int b = blockIdx.x / per, t = blockIdx.x % per;
@@ -43,21 +45,28 @@ __global__ void __launch_bounds__(256, 2) k_xty(XtyArgs a)
     // k-range: tri 1: Y[k][j] = 0 for k < j ; tri 2: X[k][i] = 0 for k > i
     const int k_lo = a.tri == 1 ? J0 : 0;
     const int k_hi = a.tri == 2 ? min(a.K, I0 + TM) : a.K;
-    const int nk = (k_hi - k_lo) / PU_BK;
+    const int nk = (k_hi - k_lo) / BK; // K, the tile edges and BK are multiples of 32 (16 for fp32): whole slabs
     using V = typename M::vec_t;
-    const size_t xslab = (size_t)PU_BK * a.ldx, yslab = (size_t)PU_BK * a.ldy;
+    const size_t xslab = (size_t)BK * a.ldx, yslab = (size_t)BK * a.ldy;
 #define XT_PIECE(q)                                                                                              \
     const int lk##q = ((tid + q * 256) * VEC) / TM, lc##q = ((tid + q * 256) * VEC) % TM;                         \
     const T *gI##q = X + (size_t)(k_lo + lk##q) * a.ldx + I0 + lc##q;                                            \
     const T *gJ##q = Y + (size_t)(k_lo + lk##q) * a.ldy + J0 + lc##q;                                            \
-    V rI##q = *(const V *)gI##q, rJ##q = *(const V *)gJ##q;
+    V rI##q = V(), rJ##q = V();                                                                                  \
+    if (q < LOADS) { rI##q = *(const V *)gI##q; rJ##q = *(const V *)gJ##q; }
     XT_PIECE(0)
     XT_PIECE(1)
+    XT_PIECE(2)
+    XT_PIECE(3)
 #undef XT_PIECE
 #define XT_STORE(q, bf) *(V *)(&sI[bf][lk##q][lc##q]) = rI##q; *(V *)(&sJ[bf][lk##q][lc##q]) = rJ##q;
 #define XT_LOAD(q, kt) rI##q = *(const V *)(gI##q + (kt) * xslab); rJ##q = *(const V *)(gJ##q + (kt) * yslab);
     XT_STORE(0, 0)
     XT_STORE(1, 0)
+    if (LOADS == 4) {
+        XT_STORE(2, 0)
+        XT_STORE(3, 0)
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -65,11 +74,19 @@ __global__ void __launch_bounds__(256, 2) k_xty(XtyArgs a)
         if (more) {
             XT_LOAD(0, (size_t)(kt + 1))
             XT_LOAD(1, (size_t)(kt + 1))
+            if (LOADS == 4) {
+                XT_LOAD(2, (size_t)(kt + 1))
+                XT_LOAD(3, (size_t)(kt + 1))
+            }
         }
-        pu_slab<T, true, TM>(sI[buf], sJ[buf], klane, wr * 2 * MB + idx, wc * 2 * MB + idx, c00, c01, c10, c11);
+        pu_slab<T, true, TM, BK>(sI[buf], sJ[buf], klane, wr * 2 * MB + idx, wc * 2 * MB + idx, c00, c01, c10, c11);
         if (more) {
             XT_STORE(0, buf ^ 1)
             XT_STORE(1, buf ^ 1)
+            if (LOADS == 4) {
+                XT_STORE(2, buf ^ 1)
+                XT_STORE(3, buf ^ 1)
+            }
         }
         __syncthreads();
     }
@@ -103,8 +120,8 @@ void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32)
 {
     const int grid = batch * a.tiles_i * a.tiles_j;
     if (grid <= 0) return;
-    if (f32) k_xty<float><<<grid, 256, 0, e->stream>>>(a);
-    else k_xty<double><<<grid, 256, 0, e->stream>>>(a);
+    if (f32) k_xty<float, 16><<<grid, 256, 0, e->stream>>>(a);
+    else k_xty<double, 32><<<grid, 256, 0, e->stream>>>(a);
 }
 
 } // namespace ekf

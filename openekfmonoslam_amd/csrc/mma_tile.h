@@ -45,7 +45,7 @@ constexpr int PU_BK = PU_BK_VALUE;
 
 // MFMAs of one k-slab held in LDS.  Operands of k-step kk+KI are fetched BEFORE the MFMAs of k-step kk are issued:
 // a wavefront issues in order, so without this its matrix pipe idles for one LDS round trip per k-step.
-template <typename T, bool FULL, int TMc>
+template <typename T, bool FULL, int TMc, int BKc = PU_BK>
 __device__ __forceinline__ void pu_slab(const T (*sIb)[TMc], const T (*sJb)[TMc], int klane, int ra, int cb,
                                         typename Mma<T>::acc_t &c00, typename Mma<T>::acc_t &c01,
                                         typename Mma<T>::acc_t &c10, typename Mma<T>::acc_t &c11)
@@ -55,9 +55,9 @@ __device__ __forceinline__ void pu_slab(const T (*sIb)[TMc], const T (*sJb)[TMc]
     T a0 = sIb[klane][ra], a1 = FULL ? sIb[klane][ra + MB] : (T)0;
     T b0 = sJb[klane][cb], b1 = sJb[klane][cb + MB];
 #pragma unroll
-    for (int kk = 0; kk < PU_BK; kk += KI) {
+    for (int kk = 0; kk < BKc; kk += KI) {
         T na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
-        if (kk + KI < PU_BK) {
+        if (kk + KI < BKc) {
             na0 = sIb[kk + KI + klane][ra];
             if (FULL) na1 = sIb[kk + KI + klane][ra + MB];
             nb0 = sJb[kk + KI + klane][cb];
