@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <new>
 
@@ -79,6 +80,7 @@ void ekf_engine_destroy(EkfEngine *e)
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
+    if (e->h_mirror) (void)hipHostFree(e->h_mirror);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -196,6 +198,19 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     for (auto &ev : e->ev)
         if ((st = hipEventCreate(&ev)) != hipSuccess) return fail(st, "hipEventCreate");
     e->h_counts.assign(CNT_COUNT, 0);
+    {   // host mirror of the counter block (optional: without it read_counts falls back to memcpy + synchronise)
+        void *hp = nullptr;
+        if (hipHostMalloc(&hp, 64 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            std::memset(hp, 0, 64 * sizeof(int));
+            void *dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+                e->h_mirror = (int *)hp;
+                e->d_mirror = (int *)dp;
+            } else {
+                (void)hipHostFree(hp);
+            }
+        }
+    }
     e->shard_feat_begin.assign(world + 1, 0);
     *out = e;
     return EKF_OK;
@@ -614,8 +629,25 @@ int ekf_convert_inverse_depth_to_depth(EkfEngine *e, int *converted_index)
 }
 
 // ----------------------------------------------------------------------------------------------- utilities
+// The device counter block is mirrored into a page of host memory the GPU can write (hipHostMallocMapped, coherent):
+// a one-wavefront kernel copies the 16 ints and then a sequence number, the host polls the sequence number.  The
+// per-frame control flow needs ~6 of these round trips (how many predictions / matches / inliers / rescued decide the
+// next launches); a memcpy + stream synchronise costs ~20 us each, the poll a few.
 static int read_counts(EkfEngine *e)
 {
+    if (e->h_mirror) {
+        const int seq = ++e->mirror_seq;
+        launch_publish_counts(e, e->d_mirror, seq);
+        volatile int *m = e->h_mirror;
+        for (long spin = 0; spin < 400000000L; ++spin) {
+            if (m[CNT_COUNT] == seq) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                for (int i = 0; i < CNT_COUNT; ++i) e->h_counts[i] = m[i];
+                return EKF_OK;
+            }
+            if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(e->stream) == hipSuccess && m[CNT_COUNT] != seq) break; // stream drained without the write: fall back
+        }
+    }
     HIPCHK(hipMemcpyAsync(e->h_counts.data(), e->d.counts, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return EKF_OK;

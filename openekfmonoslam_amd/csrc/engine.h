@@ -174,6 +174,8 @@ struct EkfEngine {
     std::vector<std::pair<int, float>> pu_log;                 // harvested (m, ms) per launch
     // host scratch
     std::vector<int> h_counts;
+    int *h_mirror = nullptr, *d_mirror = nullptr; // GPU-writable host page: counters + sequence number (read_counts)
+    int mirror_seq = 0;
     std::vector<int> h_type, h_covpos; // host mirror of the map layout (type, covariance position per feature)
 };
 
@@ -216,6 +218,7 @@ void launch_ncc_capture(EkfEngine *e, const int *d_idx, const double *d_uv, int 
 void launch_match_ncc(EkfEngine *e, int n_pred);
 void launch_gate_snapshot(EkfEngine *e, int n_pred);
 void launch_detect_cells(EkfEngine *e, int n_gates, int cells_x, int cells_y, long long *d_resp, int *d_xy);
+void launch_publish_counts(EkfEngine *e, int *d_mirror, int seq);
 void launch_map_update(EkfEngine *e, const EkfMatch *d_sel, int count, const uint8_t *d_kdesc);
 
 } // namespace ekf

@@ -247,4 +247,22 @@ void launch_outlier_idx(EkfEngine *e, const EkfMatch *src, int M, int *idx)
     if (M > 0) k_outlier_idx<<<(M + 255) / 256, 256, 0, e->stream>>>(src, M, idx);
 }
 
+// counter block -> GPU-writable host page, then the sequence number the host polls (engine.cpp read_counts)
+__global__ void k_publish_counts(const int *counts, int *mirror, int seq)
+{
+    const int t = threadIdx.x;
+    if (t < CNT_COUNT) __hip_atomic_store(&mirror[t], counts[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __builtin_amdgcn_wave_barrier();
+    if (t == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&mirror[CNT_COUNT], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+void launch_publish_counts(EkfEngine *e, int *d_mirror, int seq)
+{
+    k_publish_counts<<<1, 64, 0, e->stream>>>(e->d.counts, d_mirror, seq);
+}
+
 } // namespace ekf
