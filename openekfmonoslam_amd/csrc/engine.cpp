@@ -71,7 +71,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
                     d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.Tbuf, d.W, d.Wf, d.G, d.LL, d.gates, d.cell_resp, d.cell_xy,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.pu_tilemap,
-                    e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.raw, e->img.seq};
+                    e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &ev : e->ev)
@@ -81,6 +81,9 @@ void ekf_engine_destroy(EkfEngine *e)
         (void)hipEventDestroy(pr.second);
     }
     if (e->h_mirror) (void)hipHostFree(e->h_mirror);
+    if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
+    if (e->ev_main) (void)hipEventDestroy(e->ev_main);
+    if (e->ev_prefetch) (void)hipEventDestroy(e->ev_prefetch);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -121,6 +124,9 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     hipError_t st;
     if ((st = hipSetDevice(e->device)) != hipSuccess) return fail(st, "hipSetDevice");
     if ((st = hipStreamCreate(&e->stream)) != hipSuccess) return fail(st, "hipStreamCreate");
+    if ((st = hipStreamCreate(&e->stream2)) != hipSuccess) return fail(st, "hipStreamCreate");
+    if ((st = hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
+    if ((st = hipEventCreateWithFlags(&e->ev_prefetch, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
     DeviceArrays &d = e->d;
     const size_t w = e->f32 ? 4 : 8;
     const size_t cap = e->cap, mcap = e->mcap;
@@ -1087,13 +1093,17 @@ static int ensure_pyramid(EkfEngine *e, int w, int h)
 {
     if (e->img.w[0] == w && e->img.h[0] == h && e->img.px[0]) return EKF_OK;
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->stream2) HIPCHK(hipStreamSynchronize(e->stream2));
+    e->img.prefetched = -1;
     int lw = w, lh = h;
     for (int l = 0; l < 3; ++l) {
         if (e->img.px[l]) (void)hipFree(e->img.px[l]);
-        e->img.px[l] = nullptr;
+        if (e->img.px2[l]) (void)hipFree(e->img.px2[l]);
+        e->img.px[l] = e->img.px2[l] = nullptr;
         e->img.w[l] = lw;
         e->img.h[l] = lh;
         HIPCHK(hipMalloc((void **)&e->img.px[l], (size_t)std::max(lw, 1) * std::max(lh, 1)));
+        HIPCHK(hipMalloc((void **)&e->img.px2[l], (size_t)std::max(lw, 1) * std::max(lh, 1)));
         lw /= 2;
         lh /= 2;
     }
@@ -1304,6 +1314,8 @@ int ekf_images_upload(EkfEngine *e, int n_frames, const uint8_t *images, int wid
     if (!e || n_frames < 0 || (n_frames > 0 && !valid_image_args(images, width, height, stride, channels))) return EKF_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->stream2) HIPCHK(hipStreamSynchronize(e->stream2));
+    e->img.prefetched = -1;
     if (e->img.seq) (void)hipFree(e->img.seq);
     e->img.seq = nullptr;
     e->img.seq_n = 0;
@@ -1324,8 +1336,25 @@ static int staged_pyramid(EkfEngine *e, int frame)
     if (frame < 0 || frame >= e->img.seq_n) return EKF_ERR_INVALID_ARG;
     int rc = ensure_pyramid(e, e->img.seq_w, e->img.seq_h);
     if (rc) return rc;
-    launch_ncc_pyramid(e, e->img.seq + (size_t)frame * e->img.seq_stride * e->img.seq_h, e->img.seq_stride, e->img.seq_channels);
+    const size_t frame_bytes = (size_t)e->img.seq_stride * e->img.seq_h;
+    if (frame == e->img.prefetched) { // reduced on stream2 while the previous frame was being filtered
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_prefetch, 0));
+        for (int l = 0; l < 3; ++l) std::swap(e->img.px[l], e->img.px2[l]);
+    } else {
+        launch_ncc_pyramid(e, e->img.seq + (size_t)frame * frame_bytes, e->img.seq_stride, e->img.seq_channels);
+    }
+    e->img.prefetched = -1;
     e->img.valid = true;
+    // image-only work of the NEXT staged frame goes to the second stream, behind everything already queued on the main
+    // stream (the last readers of the buffer it overwrites), and runs concurrently with this frame's filter step
+    if (frame + 1 < e->img.seq_n && e->stream2) {
+        HIPCHK(hipEventRecord(e->ev_main, e->stream));
+        HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_main, 0));
+        launch_ncc_pyramid_on(e, e->stream2, e->img.px2, e->img.seq + (size_t)(frame + 1) * frame_bytes, e->img.seq_stride,
+                              e->img.seq_channels);
+        HIPCHK(hipEventRecord(e->ev_prefetch, e->stream2));
+        e->img.prefetched = frame + 1;
+    }
     return EKF_OK;
 }
 

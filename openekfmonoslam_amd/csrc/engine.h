@@ -118,6 +118,8 @@ struct DeviceArrays {
 // current frame of the NCC matcher: gray pyramid (level 0 = full resolution) + the raw upload staging buffer
 struct Image {
     uint8_t *px[3] = {nullptr, nullptr, nullptr};
+    uint8_t *px2[3] = {nullptr, nullptr, nullptr}; // second pyramid: the NEXT staged frame is reduced into it on stream2
+    int prefetched = -1;                           // staged frame whose pyramid sits (or is being built) in px2
     int w[3] = {0, 0, 0}, h[3] = {0, 0, 0};
     uint8_t *raw = nullptr;
     size_t raw_cap = 0;
@@ -160,6 +162,8 @@ struct EkfEngine {
     int pu_tilemap_nt = -1;
     int pu_per_xcd = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;             // image-only work of the next frame, overlapped with the update
+    hipEvent_t ev_main = nullptr, ev_prefetch = nullptr;
     ekf::DeviceArrays d;
     ekf::Frames frames;
     ekf::Image img;
@@ -192,6 +196,7 @@ struct XtyArgs {
     int row0_first, row0_stride, m_lim;   // rows of element b that exist: min(M, m_lim - (row0_first + b row0_stride))
     int tri;                              // 0: all k; 1: Y[k][j] = 0 for k < j; 2: X[k][i] = 0 for k > i
     int tiles_i, tiles_j;
+    int n_split;                          // bottom row tiles cut into two half units (tri == 2, batch 1 only)
     double alpha;
 };
 void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32);
@@ -214,6 +219,7 @@ void launch_compact_P(EkfEngine *e, int n_new, const int *d_new2old);
 void launch_linearity(EkfEngine *e, double *d_out);
 void launch_convert(EkfEngine *e, int fi, int pos, double *d_J, double *d_T3);
 void launch_ncc_pyramid(EkfEngine *e, const uint8_t *d_raw, int stride, int channels);
+void launch_ncc_pyramid_on(EkfEngine *e, hipStream_t stream, uint8_t *const px[3], const uint8_t *d_raw, int stride, int channels);
 void launch_ncc_capture(EkfEngine *e, const int *d_idx, const double *d_uv, int count);
 void launch_match_ncc(EkfEngine *e, int n_pred);
 void launch_gate_snapshot(EkfEngine *e, int n_pred);

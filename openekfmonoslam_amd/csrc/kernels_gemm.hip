@@ -14,7 +14,7 @@ namespace ekf {
 // BK: k-slab depth.  The fp64 instances are small, latency-bound GEMMs (a 64x64 tile's MFMAs of one 16-deep slab take
 // 0.2 us, a global load round trip over 1 us), so they run with 32-deep slabs: half as many round trips.
 template <typename T, int BK>
-__global__ void __launch_bounds__(256, 2) k_xty(XtyArgs a)
+__global__ void __launch_bounds__(256, 3) k_xty(XtyArgs a)
 {
     using M = Mma<T>;
     constexpr int MB = M::MB, TM = 4 * MB, VEC = M::VEC;
@@ -24,10 +24,21 @@ __global__ void __launch_bounds__(256, 2) k_xty(XtyArgs a)
     T(*sI)[BK][TM] = reinterpret_cast<T(*)[BK][TM]>(smem);
     T(*sJ)[BK][TM] = reinterpret_cast<T(*)[BK][TM]>(smem + 2 * BK * TM);
 
-    const int per = a.tiles_i * a.tiles_j;
-    const int b = blockIdx.x / per, t = blockIdx.x % per;
-    // longest k-ranges first: with tri == 2 the bottom row tiles carry the most work
-    const int ti = a.tri == 2 ? a.tiles_i - 1 - t / a.tiles_j : t / a.tiles_j, tj = t % a.tiles_j;
+    // Work units.  Row tiles are walked from the bottom (tri == 2: the bottom rows have the longest k-range); the
+    // a.n_split bottom row tiles are cut into two HALF units (64 of the 128 / 32 of the 64 tile rows each) so that the
+    // longest unit, which bounds the launch when every unit is resident at once, is half as long.
+    const int per = (a.tiles_i + a.n_split) * a.tiles_j;
+    const int b = blockIdx.x / per;
+    int t = blockIdx.x % per, ti, tj, half = -1;
+    if (t < 2 * a.n_split * a.tiles_j) {
+        ti = a.tiles_i - 1 - t / (2 * a.tiles_j);
+        tj = (t % (2 * a.tiles_j)) >> 1;
+        half = t & 1;
+    } else {
+        t -= 2 * a.n_split * a.tiles_j;
+        ti = a.tri == 2 ? a.tiles_i - 1 - a.n_split - t / a.tiles_j : a.n_split + t / a.tiles_j;
+        tj = t % a.tiles_j;
+    }
     const int I0 = ti * TM, J0 = tj * TM;
     // rows of this batch element that exist (the last pair of a level may be cut by m_pad)
     const int Mb = min(a.M, a.m_lim - (a.row0_first + b * a.row0_stride));
@@ -37,6 +48,8 @@ __global__ void __launch_bounds__(256, 2) k_xty(XtyArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv >> 1, wc = wv & 1;
+    const bool full = half < 0;
+    const int rbase = full ? wr * 2 * MB : half * 2 * MB + wr * MB; // as in the downdate's half units
     const int klane = lane / MB, idx = lane % MB;
     typename M::acc_t c00, c01, c10, c11;
 #pragma unroll
@@ -79,7 +92,8 @@ __global__ void __launch_bounds__(256, 2) k_xty(XtyArgs a)
                 XT_LOAD(3, (size_t)(kt + 1))
             }
         }
-        pu_slab<T, true, TM, BK>(sI[buf], sJ[buf], klane, wr * 2 * MB + idx, wc * 2 * MB + idx, c00, c01, c10, c11);
+        if (full) pu_slab<T, true, TM, BK>(sI[buf], sJ[buf], klane, rbase + idx, wc * 2 * MB + idx, c00, c01, c10, c11);
+        else pu_slab<T, false, TM, BK>(sI[buf], sJ[buf], klane, rbase + idx, wc * 2 * MB + idx, c00, c01, c10, c11);
         if (more) {
             XT_STORE(0, buf ^ 1)
             XT_STORE(1, buf ^ 1)
@@ -101,7 +115,8 @@ __global__ void __launch_bounds__(256, 2) k_xty(XtyArgs a)
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) {
-            const int bi = I0 + wr * 2 * MB + x * MB, bj = J0 + wc * 2 * MB + y * MB;
+            if (x == 1 && !full) continue;
+            const int bi = I0 + rbase + x * MB, bj = J0 + wc * 2 * MB + y * MB;
             const typename M::acc_t &cc = x == 0 ? (y == 0 ? c00 : c01) : (y == 0 ? c10 : c11);
 #pragma unroll
             for (int r = 0; r < M::NACC; ++r) {
@@ -118,7 +133,7 @@ __global__ void __launch_bounds__(256, 2) k_xty(XtyArgs a)
 
 void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32)
 {
-    const int grid = batch * a.tiles_i * a.tiles_j;
+    const int grid = batch * (a.tiles_i + a.n_split) * a.tiles_j;
     if (grid <= 0) return;
     if (f32) k_xty<float, 16><<<grid, 256, 0, e->stream>>>(a);
     else k_xty<double, 32><<<grid, 256, 0, e->stream>>>(a);

@@ -187,14 +187,19 @@ static Pyr pyr_of(const EkfEngine *e)
     return p;
 }
 
-void launch_ncc_pyramid(EkfEngine *e, const uint8_t *d_raw, int stride, int channels)
+void launch_ncc_pyramid_on(EkfEngine *e, hipStream_t stream, uint8_t *const px[3], const uint8_t *d_raw, int stride, int channels)
 {
     const int w = e->img.w[0], h = e->img.h[0];
-    k_ncc_gray<<<dim3((w + 255) / 256, h), 256, 0, e->stream>>>(d_raw, w, h, stride, channels, e->img.px[0]);
+    k_ncc_gray<<<dim3((w + 255) / 256, h), 256, 0, stream>>>(d_raw, w, h, stride, channels, px[0]);
     for (int l = 1; l < 3; ++l)
         if (e->img.w[l] > 0 && e->img.h[l] > 0)
-            k_ncc_down<<<dim3((e->img.w[l] + 255) / 256, e->img.h[l]), 256, 0, e->stream>>>(
-                e->img.px[l - 1], e->img.w[l - 1], e->img.px[l], e->img.w[l], e->img.h[l]);
+            k_ncc_down<<<dim3((e->img.w[l] + 255) / 256, e->img.h[l]), 256, 0, stream>>>(px[l - 1], e->img.w[l - 1], px[l],
+                                                                                         e->img.w[l], e->img.h[l]);
+}
+
+void launch_ncc_pyramid(EkfEngine *e, const uint8_t *d_raw, int stride, int channels)
+{
+    launch_ncc_pyramid_on(e, e->stream, e->img.px, d_raw, stride, channels);
 }
 
 void launch_ncc_capture(EkfEngine *e, const int *d_idx, const double *d_uv, int count)

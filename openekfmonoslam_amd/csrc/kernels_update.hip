@@ -526,6 +526,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         g.M = m_pad; g.N = n_pad; g.K = m_pad;
         g.row0_first = 0; g.row0_stride = 0; g.m_lim = m_pad;
         g.tri = 2; g.tiles_i = (m_pad + TM - 1) / TM; g.tiles_j = (n_pad + TM - 1) / TM; g.alpha = 1.0;
+        g.n_split = g.tiles_i / 2; // k-depth of row tile i is ~(i+1) TM: halve the units of the longer half
         launch_xty(e, g, 1, e->f32);
     }
     {
