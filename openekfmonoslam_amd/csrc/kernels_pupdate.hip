@@ -122,11 +122,25 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
     //    instead of scattered 4-byte stores).
     //  - AVG (first update after an arbitrary upload): P(i,j) <- 0.5 (P(i,j) + P(j,i)) - acc on i <= j, mirrored.
     T *sT = smem + wv * MB * (MB + 1);
+    // the P values of BOTH blocks of a block row are requested before the first one is needed: the epilogue of a tile
+    // is a 64 KB read-modify-write whose latency was exposed once per MFMA block
+    typename M::acc_t pv[2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) {
             if (x == 1 && !full) continue;
+            if (!AVG && y == 0) {
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy) {
+                    const int pbi = I0 + rbase + x * MB, pbj = J0 + wc * 2 * MB + yy * MB;
+#pragma unroll
+                    for (int r = 0; r < M::NACC; ++r) {
+                        const int gi = pbi + M::row(r, lane), gj = pbj + M::col(lane);
+                        pv[yy][r] = (gi < ilim && gj < n) ? P[(size_t)(gi + p_off) * ldp + gj] : (T)0;
+                    }
+                }
+            }
             const int bi = I0 + rbase + x * MB, bj = J0 + wc * 2 * MB + y * MB;
             const typename M::acc_t &cc = x == 0 ? (y == 0 ? c00 : c01) : (y == 0 ? c10 : c11);
             if (AVG) {
@@ -149,9 +163,8 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
                 const int gi = bi + li, gj = bj + lj;
                 T v = (T)0;
                 if (gi < ilim && gj < n) {
-                    T *pu = P + (size_t)(gi + p_off) * ldp + gj;
-                    v = *pu - cc[r];
-                    *pu = v;
+                    v = pv[y][r] - cc[r];
+                    P[(size_t)(gi + p_off) * ldp + gj] = v;
                 }
                 if (!diag) sT[li * (MB + 1) + lj] = v;
             }

@@ -1205,6 +1205,7 @@ static double ncc_key(int l, const uint8_t *t, int cx, int cy)
 /* One prediction.  Returns 1 and the level-0 pixel + key when matched. */
 static int ncc_match_one(const OrcFilter *f, const EkfPrediction *p, int *mx, int *my, double *mkey)
 {
+    (void)f;
     float axes[2];
     double angle;
     orc_ellipse(p->covarianceMatrix, axes, &angle);
