@@ -299,22 +299,38 @@ k_triinv_level(const double *S, int ldS, int m, int m_pad, double *V, double *W,
     const int lane = tid & 63, wv = tid >> 6;
     const int bi = wv >> 1, bj = wv & 1, lr = lane & 15, lk = lane >> 4;
     acc4 acc = {0, 0, 0, 0};
-    for (int kk = 0; kk < s; kk += NB) {
-        for (int i = tid; i < NB * NB; i += 256) {
+    // k-chunks that can be non-zero: X11 and X22 are lower triangular.
+    //   mode 0: X11[kk + r][tc*32 + c] = 0 when kk + 31 < tc*32      -> start at chunk tc
+    //   mode 1: X22[tr*32 + r][kk + c] = 0 when kk > tr*32 + 31      -> stop after chunk tr
+    const int kk_lo = mode == 0 ? tc * NB : 0;
+    const int kk_hi = mode == 0 ? s : (tr + 1) * NB;
+    // this thread's 4 + 4 elements of a chunk, fetched one chunk ahead of the MFMAs
+    double pa[4], pb[4];
+    auto fetch = [&](int kk) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * 256;
             const int r = i / NB, c = i % NB;
-            double av, bv;
             if (mode == 0) {
                 const int gr = r0 + s + tr * NB + r, gc = r0 + kk + c; // L21 (rows m..m_pad of L are zero)
-                av = (gr < m) ? S[(size_t)gr * ldS + gc] : 0.0;
-                bv = V[(size_t)(r0 + kk + r) * ldw + r0 + tc * NB + c]; // X11[kk + r][tc*32 + c]
+                pa[q] = (gr < m) ? S[(size_t)gr * ldS + gc] : 0.0;
+                pb[q] = V[(size_t)(r0 + kk + r) * ldw + r0 + tc * NB + c]; // X11[kk + r][tc*32 + c]
             } else {
-                av = V[(size_t)(r0 + s + tr * NB + r) * ldw + r0 + s + kk + c]; // X22[tr*32 + r][kk + c]
-                bv = Tbuf[(size_t)(r0 + s + kk + r) * ldw + tc * NB + c];       // T[kk + r][tc*32 + c]
+                pa[q] = V[(size_t)(r0 + s + tr * NB + r) * ldw + r0 + s + kk + c]; // X22[tr*32 + r][kk + c]
+                pb[q] = Tbuf[(size_t)(r0 + s + kk + r) * ldw + tc * NB + c];       // T[kk + r][tc*32 + c]
             }
-            sA[r][c] = av;
-            sB[r][c] = bv;
+        }
+    };
+    fetch(kk_lo);
+    for (int kk = kk_lo; kk < kk_hi; kk += NB) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * 256;
+            sA[i / NB][i % NB] = pa[q];
+            sB[i / NB][i % NB] = pb[q];
         }
         __syncthreads();
+        if (kk + NB < kk_hi) fetch(kk + NB);
 #pragma unroll
         for (int k4 = 0; k4 < NB; k4 += 4)
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[16 * bi + lr][k4 + lk], sB[k4 + lk][16 * bj + lr], acc, 0, 0, 0);
@@ -491,30 +507,11 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     // inv(L) by doubling: 32 -> 64 -> ... until one block covers all rows
     for (int sz = NB; sz < m_pad; sz *= 2) {
         const int npairs = (m_pad - sz + 2 * sz - 1) / (2 * sz); // pairs whose second half has rows
-        if (sz < 256) {
+        {   // 32x32 output tiles on the fp64 MFMA at every level: these products are small (m^3/3 flop in total) and
+            // need many workgroups with short k-loops rather than big tiles (64x64 tiles left 3/4 of the CUs idle)
             const int tiles = (sz / NB) * (sz / NB);
             k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.LL, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 0);
             k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.LL, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 1);
-        } else {
-            const long long dS = 2LL * sz * (ldS + 1), dW = 2LL * sz * (ldw + 1), dT = 2LL * sz * ldw;
-            XtyArgs t1{};   // T1 = L21 X11 : X = L' (upper triangle of LL), Y = X11 (lower triangular)
-            t1.X = e->d.LL + sz;             t1.ldx = ldS; t1.xb = dS;
-            t1.Y = V;                        t1.ldy = ldw; t1.yb = dW;
-            t1.C = e->d.Tbuf + (size_t)sz * ldw; t1.ldc = ldw; t1.cb = dT;
-            t1.M = sz; t1.N = sz; t1.K = sz;
-            t1.row0_first = sz; t1.row0_stride = 2 * sz; t1.m_lim = m_pad;
-            t1.tri = 1; t1.tiles_i = sz / 64; t1.tiles_j = sz / 64; t1.alpha = 1.0;
-            launch_xty(e, t1, npairs, false);
-            XtyArgs x2{};   // X21 = -X22 T1 : X = W22 = X22' (upper triangular), Y = T1
-            x2.X = W + (size_t)sz * (ldw + 1);   x2.ldx = ldw; x2.xb = dW;
-            x2.Y = e->d.Tbuf + (size_t)sz * ldw; x2.ldy = ldw; x2.yb = dT;
-            x2.C = V + (size_t)sz * ldw;         x2.ldc = ldw; x2.cb = dW;
-            x2.Ct = W + sz;                      x2.ldct = ldw; x2.ctb = dW;
-            x2.Ctf = Wf ? Wf + sz : nullptr;
-            x2.M = sz; x2.N = sz; x2.K = sz;
-            x2.row0_first = sz; x2.row0_stride = 2 * sz; x2.m_lim = m_pad;
-            x2.tri = 2; x2.tiles_i = sz / 64; x2.tiles_j = sz / 64; x2.alpha = -1.0;
-            launch_xty(e, x2, npairs, false);
         }
     }
     {   // B = inv(L) G = W' G : one GEMM, k <= row (W upper triangular)
