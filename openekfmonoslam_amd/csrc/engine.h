@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -160,6 +161,7 @@ struct EkfEngine {
     int cells_cap = 0;        // detector cell buffers allocated for this many cells
     int n_kp = 0;
     int pu_tilemap_nt = -1;
+    std::map<int, std::pair<void *, int>> pu_tables; // built work lists of the downdate: key -> (device list, units per XCD)
     int pu_per_xcd = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // image-only work of the next frame, overlapped with the update
