@@ -46,10 +46,14 @@ def cpu_baseline(seq, workload):
     N = seq.n_features
     o = ol.Oracle(seq.cam, seq.par, N + 8)
     o.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
-    kps, desc = seq.frames[0]
-    t0 = time.perf_counter()
-    info = o.step(kps, desc, ol.ALGORITHMIC)
-    t_alg = time.perf_counter() - t0
+    # bounded sample: whole frames of the same sequence until ~10 s of CPU work (at most 4 frames)
+    t_alg, n_done, info = 0.0, 0, None
+    while n_done < min(4, len(seq.frames)) and t_alg < 10.0:
+        kps, desc = seq.frames[n_done]
+        t0 = time.perf_counter()
+        info = o.step(kps, desc, ol.ALGORITHMIC)
+        t_alg += time.perf_counter() - t0
+        n_done += 1
     n, m = seq.state_dim, 2 * max(info.n_inliers, info.n_rescued, 1)
     rows = 16 if n > 3000 else 64
     rng = np.random.default_rng(1)
@@ -61,14 +65,14 @@ def cpu_baseline(seq, workload):
     gflops = (2.0 * rows * m * n + 2.0 * rows * n * n) / t_rows / 1e9
     lit_flops = 2.0 * n * n * m * 2 + 4.0 * n * m * m + (8.0 / 3.0) * m**3 + 2.0 * n**3
     return {
-        "value": 1.0 / t_alg,
+        "value": n_done / t_alg,
         "unit": "EKF updates/s",
         "cores": 1,
         "host_cores_available": os.cpu_count(),
         "kind": "port",
-        "sample": f"frame 1 of the same {workload} sequence (M={info.n_matches} matches, {info.n_inliers} LI inliers, "
-                  f"{info.n_rescued} rescued), oracle 'algorithmic' update (block-sparse H, Cholesky, P -= B'B), "
-                  f"1 thread, {t_alg:.1f} s",
+        "sample": f"first {n_done} frame(s) of the same {workload} sequence (last: M={info.n_matches} matches, "
+                  f"{info.n_inliers} LI inliers, {info.n_rescued} rescued), oracle 'algorithmic' update (block-sparse H, "
+                  f"Cholesky, P -= B'B), 1 thread, {t_alg:.1f} s",
         "literal_reference_algorithm_estimate_s_per_update": lit_flops / (gflops * 1e9),
         "literal_sample": f"dense i-k-j products K H and (I-KH) P restricted to {rows} of {n} rows: {t_rows:.2f} s, "
                           f"{gflops:.2f} GFLOP/s; literal flop model of Update.cpp:92-109,214-218 at m={m}",
