@@ -215,3 +215,44 @@ def test_image_pipeline_init_track_and_grow(eng_mod, oracle_lib):
     e.capture_templates(np.arange(n0, n0 + len(uvn)), uvn)
     assert e.N == o.N == n0 + len(uvn)
     assert_state_close(e, o, 1e-8, "after map management")
+
+
+def test_real_frames_engine_equals_oracle(eng_mod, oracle_lib):
+    """tests/golden/s3_frames: eight frames of the reference's sample sequence (reduced to 320x240 gray by
+    tests/golden/make_s3_frames.py).  Same calls on engine and oracle: init on frame 0 (detect, add, templates), then
+    image steps with the device map management in the reference's order.  Picks, matches and counts identical; state and
+    covariance within 1e-8 after seven frames of real imagery."""
+    import os
+
+    from PIL import Image
+
+    from openekfmonoslam_amd.ekftypes import s3_camera, s3_params
+
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "s3_frames")
+    frames = [np.asarray(Image.open(os.path.join(d, f"{k:05d}.png"))) for k in range(8)]
+    assert frames[0].shape == (240, 320)
+    cam, par = s3_camera(320, 240), s3_params()
+    e = eng_mod.EkfEngine(cam, par, 96)
+    o = oracle_lib.Oracle(cam, par, 96)
+    e.reset()
+    o.reset()
+    e.upload_image(frames[0])
+    o.set_image(frames[0])
+    none = np.zeros(0, dtype=oracle_lib.PREDICTION_DTYPE)
+    uv = e.detect_new_features(40, min_response=1e10)
+    np.testing.assert_array_equal(uv, o.detect_new_features(none, 40, min_response=1e10))
+    assert len(uv) == 40
+    e.add_features(uv)
+    for p in uv:
+        o.add_feature(p)
+    e.capture_templates(np.arange(40), uv)
+    o.capture_templates(np.arange(40), uv)
+    for t in range(1, 8):
+        gi = e.step_image(frames[t])
+        oi = o.step_image(frames[t], ALGORITHMIC)
+        for f in ("n_predicted", "n_matches", "n_hypotheses", "n_inliers", "n_outliers", "n_rescued", "status"):
+            assert getattr(gi, f) == getattr(oi, f), (t, f, getattr(gi, f), getattr(oi, f))
+        assert gi.n_matches >= 30
+    assert_state_close(e, o, 1e-8, "seven real frames")
+    x, _, _ = e.get_state(want_P=False)
+    assert x[0] < -0.005  # the camera of this sequence slides sideways
