@@ -185,7 +185,7 @@ inline bool readPng(const std::string &path, Image &img, std::string *err = 0)
         else if (type == "IEND") break;
         pos += 12 + len;
     }
-    if (!w || !h || interlace || (depth != 8 && depth != 16)) { if (err) *err = path + ": unsupported PNG variant"; return false; }
+    if (!w || !h || w > 16384 || h > 16384 || interlace || (depth != 8 && depth != 16)) { if (err) *err = path + ": unsupported PNG variant"; return false; }
     const int spp = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!spp) { if (err) *err = path + ": bad colour type"; return false; }
     const size_t bpp = (size_t)spp * depth / 8, stride = bpp * w;
