@@ -158,3 +158,51 @@ def test_fp32_covariance_drift_over_90_frames(eng_mod, oracle_lib):
     for name in ("r", "q", "v", "features"):
         assert be[name] <= F32_TOL, (name, be[name])
     assert be["w"] <= F32_TOL_OMEGA
+
+
+def test_abi_error_paths(eng_mod, seq12):
+    """capacity and argument errors come back as status codes (EkfError), the engine stays usable afterwards"""
+    e = eng_mod.EkfEngine(seq12.cam, seq12.par, 12, max_keypoints=16)
+    with pytest.raises(eng_mod.EkfError) as ei:   # more features than the engine was created for
+        big = SyntheticSequence(13, 1)
+        e.set_state(big.x13, big.feature_pos, big.feature_type, big.feature_desc, big.P0)
+    assert ei.value.code == 2
+    e.set_state(seq12.x13, seq12.feature_pos, seq12.feature_type, seq12.feature_desc, seq12.P0)
+    with pytest.raises(eng_mod.EkfError) as ei:   # more keypoints than max_keypoints
+        e.step(*seq12.frames[0])
+    assert ei.value.code == 2
+    with pytest.raises(eng_mod.EkfError) as ei:   # map is full
+        e.add_features(np.array([[100.0, 100.0]]))
+    assert ei.value.code == 2
+    with pytest.raises(eng_mod.EkfError) as ei:   # feature index out of range in a match
+        m = np.zeros(1, dtype=MATCH_DTYPE)
+        m["featureIndex"] = 99
+        e.predict()
+        e.predict_measurements()
+        e.update(m)
+    assert ei.value.code == 1
+    with pytest.raises(eng_mod.EkfError):          # removing a feature that does not exist
+        e.remove_features([40])
+    # still healthy: a normal prediction + update on a subset of the keypoints
+    kps, desc = seq12.frames[0]
+    info = e.step(kps[:16], desc[:16])
+    assert info.status == 0
+
+
+def test_remove_every_feature_then_regrow(eng_mod, oracle_lib, seq12):
+    e, o = make_pair(eng_mod, oracle_lib, seq12)
+    idx = np.arange(12, dtype=np.int32)
+    e.remove_features(idx)
+    o.remove_features(idx)
+    assert e.N == 0 and e.n == 13
+    assert_state_close(e, o, 1e-12, "all features removed")
+    uv = np.array([[100.5, 80.25], [400.0, 300.0], [320.0, 240.0]])
+    e.add_features(uv)
+    for p in uv:
+        o.add_feature(p)
+    assert e.N == 3 and e.n == 31
+    assert_state_close(e, o, F64_TOL, "regrown map")
+    gi = e.step(*seq12.frames[0])
+    oi = o.step(*seq12.frames[0], ALGORITHMIC)
+    _same_info(gi, oi, "step on the regrown map")
+    assert_state_close(e, o, F64_TOL, "step on the regrown map")
