@@ -20,6 +20,8 @@
 #ifndef EKF_ENGINE_H
 #define EKF_ENGINE_H
 
+#include <stddef.h>
+
 #include "ekf_types.h"
 
 #ifdef __cplusplus

@@ -65,3 +65,13 @@ def test_synthetic_sequence_is_deterministic_and_in_frame():
     assert a.P0.shape == (133, 133) and np.allclose(a.P0, a.P0.T, rtol=1e-12, atol=1e-18)
     kps = a.frames[0][0]
     assert len(kps) == 40 and kps["x"].min() > 0 and kps["x"].max() < 640
+
+
+def test_abi_headers_are_plain_c99(tmp_path):
+    """the boundary is a C ABI: include/*.h must compile as C99 on their own (no C++-isms, no missing includes)"""
+    import subprocess
+
+    src = tmp_path / "c99.c"
+    src.write_text('#include "ekf_engine.h"\nint main(void) { EkfEngineConfig c; (void)c; return EKF_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only",
+                           "-I", os.path.join(ROOT, "include"), str(src)])
