@@ -36,7 +36,7 @@ WORKLOADS = {
 PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}  # f32: MI355X_MICROARCH.md; f64: AMD datasheet figure (not in the guide)
 
 
-def cpu_baseline(seq, workload):
+def cpu_baseline(seq, workload, eng=None):
     """The oracle (CPU restatement of the reference algorithm) timed on this box's host cores, rank 0 only.
     (a) one full frame of the SAME workload with the algorithmic update variant; (b) a row sample of the
     reference's literal dense (I - K H) P products, to estimate what the literal algorithm would cost."""
@@ -54,6 +54,30 @@ def cpu_baseline(seq, workload):
         info = o.step(kps, desc, ol.ALGORITHMIC)
         t_alg += time.perf_counter() - t0
         n_done += 1
+    parity = None
+    if eng is not None:  # parity gates next to every number -- the engine on the same frames, same start
+        eng.timing(False)
+        eng.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+        o2 = ol.Oracle(seq.cam, seq.par, N + 8)
+        o2.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+        same = True
+        for t in range(n_done):
+            gi = eng.step_frame(t)
+            oi = o2.step(*seq.frames[t], ol.ALGORITHMIC)
+            same &= all(getattr(gi, f) == getattr(oi, f) for f in
+                        ("n_predicted", "n_matches", "n_hypotheses", "n_inliers", "n_outliers", "n_rescued", "status"))
+        x, fp, P = eng.get_state()
+        xo, fpo, Po = o2.x13(), o2.feature_pos(), o2.P()
+        a, b = np.concatenate([x, fp.reshape(-1)]), np.concatenate([xo, fpo.reshape(-1)])
+        parity = {
+            "frames": n_done,
+            "decisions_identical": bool(same),
+            "P_max_rel": float(np.abs(P - Po).max() / np.abs(Po).max()),
+            "P_fro_rel": float(np.linalg.norm(P - Po) / np.linalg.norm(Po)),
+            "state_max_rel": float((np.abs(a - b) / np.maximum(np.abs(b), 1e-4)).max()),
+            "note": "HIP engine vs the fp64 CPU oracle after the sampled frames; tolerance 1e-5 (fp32 covariance) / "
+                    "1e-9 (fp64); state components below 1e-4 are measured against 1e-4",
+        }
     n, m = seq.state_dim, 2 * max(info.n_inliers, info.n_rescued, 1)
     rows = 16 if n > 3000 else 64
     rng = np.random.default_rng(1)
@@ -76,6 +100,7 @@ def cpu_baseline(seq, workload):
         "literal_reference_algorithm_estimate_s_per_update": lit_flops / (gflops * 1e9),
         "literal_sample": f"dense i-k-j products K H and (I-KH) P restricted to {rows} of {n} rows: {t_rows:.2f} s, "
                           f"{gflops:.2f} GFLOP/s; literal flop model of Update.cpp:92-109,214-218 at m={m}",
+        "parity_vs_oracle": parity,
     }
 
 
@@ -272,7 +297,7 @@ def main():
         "stage_ms_per_step": stages,
     }
     if world == 1 and not group and not ncc and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(seq, args.workload)
+        out["cpu_baseline"] = cpu_baseline(seq, args.workload, eng)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

@@ -246,7 +246,7 @@ void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool sta
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, const int *feat_covpos,
-          const double *Hs_tab, const double *Hf_tab, T *HP, double *S_tab, RowMap rm)
+          const double *Hs_tab, const double *Hf_tab, T *HP, double *S_tab, RowMap rm, double *HPc)
 {
     __shared__ double sH[26];     // Hs (2x7) then Hf (2x6)
     __shared__ double sHP[2][13]; // fp64 H P at columns 0..6 and pos..pos+d-1
@@ -279,6 +279,10 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
         a1 += b1;
         o0[j] = (T)a0;
         o1[j] = (T)a1;
+        if (j < 13) { // fp64 copy of the camera columns: the camera part of B = inv(L) (H P) is solved in fp64 (k_bcam)
+            HPc[(size_t)(2 * fi) * 16 + j] = a0;
+            HPc[(size_t)(2 * fi + 1) * 16 + j] = a1;
+        }
         if (j < 7) {
             sHP[0][j] = a0;
             sHP[1][j] = a1;
@@ -303,11 +307,11 @@ void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list)
     if (e->f32)
         k_hp_rows<float><<<n_list, 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
                                                         e->d.feat_covpos, e->d.Hs, e->d.Hf, (float *)e->d.HP,
-                                                        e->d.pred_S, e->rm);
+                                                        e->d.pred_S, e->rm, e->d.HPc);
     else
         k_hp_rows<double><<<n_list, 256, 0, e->stream>>>((const double *)e->d.P, e->ldP, e->n, d_list,
                                                          e->d.feat_type, e->d.feat_covpos, e->d.Hs, e->d.Hf,
-                                                         (double *)e->d.HP, e->d.pred_S, e->rm);
+                                                         (double *)e->d.HP, e->d.pred_S, e->rm, e->d.HPc);
 }
 
 // predictMeasurementState on the current state into an EkfPrediction array (device), all features.

@@ -23,7 +23,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
          const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
-         double *mHs, double *mHf, int *mpos, int *mdim)
+         double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc)
 {
     const int row = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -32,6 +32,7 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
         const int i = row >> 1, r = row & 1;
         const int fi = matches[i].featureIndex;
         if (j < n_pad) A[(size_t)row * ld + j] = HP[(size_t)(2 * fi + r) * ld + j];
+        if (j < 16) Gc[(size_t)row * 16 + j] = j < 13 ? HPc[(size_t)(2 * fi + r) * 16 + j] : 0.0;
         if (blockIdx.x == 0 && r == 0) {
             const int t = threadIdx.x;
             if (t < 14) mHs[14 * i + t] = Hs_tab[14 * fi + t];
@@ -46,6 +47,7 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
         }
     } else if (row < m_pad) {
         if (j < n_pad) A[(size_t)row * ld + j] = (T)0;
+        if (j < 16) Gc[(size_t)row * 16 + j] = 0.0;
         if (blockIdx.x == 0 && threadIdx.x == 0) nu[row] = 0.0;
     }
 }
@@ -350,19 +352,112 @@ k_triinv_level(const double *S, int ldS, int m, int m_pad, double *V, double *W,
     }
 }
 
+// ------------------------------------------------------------------------------------- camera columns of B in fp64
+// Bc = inv(L) Gc for the 13 camera columns (Gc = fp64 camera columns of the gathered H P rows, V = inv(L) row-major):
+// m^2/2 x 13 fp64 FMAs.  The camera part of dx = B'z and the camera rows / columns of the downdate are formed from
+// Bc, so the camera state does not inherit the rounding of the fp32 GEMM B = W'G (whose entries are small differences
+// of large partial sums in these columns).  16 rows x 16 columns (13 used) per workgroup.
+__global__ void __launch_bounds__(256) k_bcam(const double *V, int ldw, const double *Gc, int m_pad, double *Bc)
+{
+    __shared__ double sg[64][16];
+    const int a = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + r;
+    const int i_max = min(m_pad, blockIdx.x * 16 + 16); // rows of this workgroup need k < i_max
+    double acc = 0.0;
+    for (int k0 = 0; k0 < i_max; k0 += 64) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < 64 * 16; q += 256) sg[q >> 4][q & 15] = (k0 + (q >> 4) < m_pad) ? Gc[(size_t)(k0 + (q >> 4)) * 16 + (q & 15)] : 0.0;
+        __syncthreads();
+        if (i < m_pad) {
+            const int ke = min(64, i + 1 - k0);
+            const double *vr = V + (size_t)i * ldw + k0;
+            for (int k = 0; k < ke; ++k) acc += vr[k] * sg[k][a];
+        }
+    }
+    if (i < m_pad) Bc[(size_t)i * 16 + a] = acc;
+}
+
 // ------------------------------------------------------------------------------------------------- dx = B' z
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, int ldpart)
+k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, int ldpart, double *sq_part, double *cam_part,
+             const double *Bc)
 {
+    __shared__ double sc[64][13]; // camera columns of a chunk of rows of B
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int ks = blockIdx.y;
-    if (j >= n) return;
     const int per = (m + DX_SPLIT - 1) / DX_SPLIT;
     const int kb = ks * per, ke = min(m, kb + per);
-    double s = 0.0;
-    for (int k = kb; k < ke; ++k) s += (double)B[(size_t)k * ld + j] * z[k];
+    double s = 0.0, q = 0.0;
+    double c[13];
+#pragma unroll
+    for (int a = 0; a < 13; ++a) c[a] = 0.0;
+    for (int k0 = kb; k0 < ke; k0 += 64) {
+        const int cnt = min(64, ke - k0);
+        if (Bc) { // fp64 camera columns of B (fp32 covariance only)
+            __syncthreads();
+            for (int i = threadIdx.x; i < cnt * 13; i += 256) sc[i / 13][i % 13] = Bc[(size_t)(k0 + i / 13) * 16 + i % 13];
+            __syncthreads();
+        }
+        if (j < n)
+            for (int k = 0; k < cnt; ++k) {
+                const double b = (Bc && j < 13) ? sc[k][j] : (double)B[(size_t)(k0 + k) * ld + j];
+                s += b * z[k0 + k];
+                q += b * b; // (B'B)_jj in fp64, same pass over B: see k_diag_fix
+                if (cam_part) {
+#pragma unroll
+                    for (int a = 0; a < 13; ++a) c[a] += sc[k][a] * b; // (B'B)_aj, camera rows
+                }
+            }
+    }
+    if (j >= n) return;
     part[(size_t)ks * ldpart + j] = s;
+    if (sq_part) sq_part[(size_t)ks * ldpart + j] = q;
+    if (cam_part) {
+#pragma unroll
+        for (int a = 0; a < 13; ++a) cam_part[((size_t)ks * 13 + a) * ldpart + j] = c[a];
+    }
+}
+
+// fp32 covariance only.  The variances are where the downdate subtracts the most (an inverse-depth variance goes from
+// 1 to 0.07 in one update) and an fp32 MFMA accumulation over ~1000 terms leaves an absolute error of ~3e-6 there, 30x
+// the error of any off-diagonal element (measured at N = 1000).  The diagonal of B'B is therefore accumulated in fp64
+// (k_dx_partial, no extra pass over B) and P_jj = P_jj(old) - (B'B)_jj is rounded to fp32 once.  The 13 camera rows
+// and columns get the same treatment: the camera state -- above all the angular velocity, which is observed only
+// through these cross-covariances -- inherits their error (measured: w block 2e-4 -> see DESIGN.md section 6).
+//   phase 0 (before the downdate): keep P_jj(old);  phase 1 (after): overwrite the diagonal.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_diag_fix(T *P, int ld, int n, RowMap rm, double *dsave, const double *sq_part, double *csave, const double *cam_part,
+           int ldpart, int phase, int avg)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const bool mine = owns_row(rm, j);
+    T *prow = P + (size_t)local_row(rm, j) * ld;
+    if (phase == 0) {
+        if (mine) dsave[j] = (double)prow[j];
+#pragma unroll
+        for (int a = 0; a < 13; ++a) // avg: the first downdate after an arbitrary upload works on 0.5 (P(a,j) + P(j,a))
+            csave[(size_t)a * ldpart + j] = avg ? (double)((T)0.5 * P[(size_t)a * ld + j] + (T)0.5 * prow[a]) : (double)P[(size_t)a * ld + j];
+        return;
+    }
+    if (mine && j >= 13) {
+        double q = 0.0;
+#pragma unroll
+        for (int ks = 0; ks < DX_SPLIT; ++ks) q += sq_part[(size_t)ks * ldpart + j];
+        prow[j] = (T)(dsave[j] - q);
+    }
+    // camera rows (replicated on every rank) and, for owned rows, their mirror: one value, written to both places
+#pragma unroll
+    for (int a = 0; a < 13; ++a) {
+        double q = 0.0;
+#pragma unroll
+        for (int ks = 0; ks < DX_SPLIT; ++ks) q += cam_part[((size_t)ks * 13 + a) * ldpart + j];
+        const T v = (T)(csave[(size_t)a * ldpart + j] - q);
+        P[(size_t)a * ld + j] = v;
+        if (mine) prow[a] = v;
+    }
 }
 
 // stateUpdate (Update.cpp:147-204): x += dx with the DELTA dead-band on every component; R(q) recomputed from
@@ -488,7 +583,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         dim3 grid((n_pad + 255) / 256, m_pad);
         k_gather<T><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const T *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
-                                         e->d.mHf, e->d.mpos, e->d.mdim);
+                                         e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc);
     }
     {
         dim3 grid((M + 15) / 16, (M + 15) / 16);
@@ -528,13 +623,24 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     }
     {
         dim3 grid((n + 255) / 256, DX_SPLIT);
-        k_dx_partial<T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.nu, e->d.dx_part, ld);
+        const double *Bc = nullptr;
+        if (sizeof(T) == 4) {
+            k_bcam<<<(m_pad + 15) / 16, 256, 0, s>>>(V, ldw, e->d.Gc, m_pad, e->d.Bc);
+            Bc = e->d.Bc;
+        }
+        k_dx_partial<T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.nu, e->d.dx_part, ld,
+                                             (update_cov && sizeof(T) == 4) ? e->d.sq_part : nullptr,
+                                             (update_cov && sizeof(T) == 4) ? e->d.cam_part : nullptr, Bc);
         const int nt = max(e->N * 6, 1);
         k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
                                                        e->N, e->d.dx_part, ld);
     }
     if (!update_cov) return;
+    const bool fix_diag = sizeof(T) == 4;
+    const int avg = e->p_exact_sym ? 0 : 1; // an AVG downdate only exists on an unsharded engine: every row is local
+    if (fix_diag) k_diag_fix<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save, e->d.cam_part, ld, 0, avg);
     launch_p_update(e, m_pad);
+    if (fix_diag) k_diag_fix<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save, e->d.cam_part, ld, 1, avg);
     k_quat_norm<<<1, 64, 0, s>>>(e->d.state);
     const int nb = 1 + (n > 7 ? (n - 7 + 255) / 256 : 0);
     k_normalize_cov<T><<<nb, 256, 0, s>>>((T *)e->d.P, ld, n, e->d.state, e->rm);
