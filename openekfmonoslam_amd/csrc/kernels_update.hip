@@ -359,20 +359,39 @@ k_triinv_level(const double *S, int ldS, int m, int m_pad, double *V, double *W,
 // of large partial sums in these columns).  16 rows x 16 columns (13 used) per workgroup.
 __global__ void __launch_bounds__(256) k_bcam(const double *V, int ldw, const double *Gc, int m_pad, double *Bc)
 {
-    __shared__ double sg[64][16];
-    const int a = threadIdx.x & 15, r = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + r;
-    const int i_max = min(m_pad, blockIdx.x * 16 + 16); // rows of this workgroup need k < i_max
+    __shared__ double sv[16][65]; // V[i0 + r][k0 + k]
+    __shared__ double sg[64][17]; // Gc[k0 + k][a]
+    const int tid = threadIdx.x;
+    const int a = tid & 15, r = tid >> 4;
+    const int i0 = blockIdx.x * 16, i = i0 + r;
+    const int i_max = min(m_pad, i0 + 16); // rows of this workgroup need k < i_max (V lower triangular)
+    // both operand tiles of a 64-deep chunk are fetched (coalesced) one chunk ahead of the FMAs that consume them
+    double pv[4], pg[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;                // 1024 elements per tile
+            const int vr = e >> 6, vk = e & 63;         // V tile: 16 rows x 64 k
+            pv[q] = (i0 + vr < m_pad && k0 + vk < m_pad) ? V[(size_t)(i0 + vr) * ldw + k0 + vk] : 0.0;
+            const int gk = e >> 4, ga = e & 15;         // Gc tile: 64 k x 16 columns
+            pg[q] = (k0 + gk < m_pad) ? Gc[(size_t)(k0 + gk) * 16 + ga] : 0.0;
+        }
+    };
     double acc = 0.0;
+    fetch(0);
     for (int k0 = 0; k0 < i_max; k0 += 64) {
         __syncthreads();
-        for (int q = threadIdx.x; q < 64 * 16; q += 256) sg[q >> 4][q & 15] = (k0 + (q >> 4) < m_pad) ? Gc[(size_t)(k0 + (q >> 4)) * 16 + (q & 15)] : 0.0;
-        __syncthreads();
-        if (i < m_pad) {
-            const int ke = min(64, i + 1 - k0);
-            const double *vr = V + (size_t)i * ldw + k0;
-            for (int k = 0; k < ke; ++k) acc += vr[k] * sg[k][a];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            sv[e >> 6][e & 63] = pv[q];
+            sg[e >> 4][e & 15] = pg[q];
         }
+        __syncthreads();
+        if (k0 + 64 < i_max) fetch(k0 + 64);
+        // entries of V above the diagonal are zero, so the full chunk can be summed
+#pragma unroll 16
+        for (int k = 0; k < 64; ++k) acc += sv[r][k] * sg[k][a];
     }
     if (i < m_pad) Bc[(size_t)i * 16 + a] = acc;
 }
