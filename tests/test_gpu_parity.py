@@ -11,10 +11,10 @@ pytestmark = pytest.mark.gpu
 
 F64_TOL = 1e-9   # fp64 engine vs fp64 oracle (different summation orders / FMA only)
 F32_TOL = 1e-5   # the north-star tolerance for the fp32-covariance configuration
-# fp32 covariance: the angular-velocity block (|w| ~ 2e-3 rad/frame in the synthetic sequences, updated only through
-# fp32-stored cross-covariances) carries an absolute error of a few 1e-8 rad/frame, i.e. up to ~3e-5 of its own
-# magnitude; every other block and P itself meet 1e-5.  Stated separately ("fp32 accuracy").
-F32_TOL_OMEGA = 1e-4
+# The angular-velocity block used to be the exception of the fp32 configuration (up to 3e-5 of its own magnitude: it is
+# observed only through cross-covariances).  Since the camera columns of B and the camera rows / diagonal of the downdate
+# are accumulated in fp64 (k_bcam, k_dx_partial, k_diag_fix) it meets the same 1e-5 as every other block.
+F32_TOL_OMEGA = F32_TOL
 
 
 def rel_max(a, b):
