@@ -135,7 +135,7 @@ k_chol_diag0(const double *S, int ldS, int kb, double *V, double *W, float *Wf, 
 //   nu block: z_k = Linv_k nu_k, then nu_i -= L_ik z_k = S_ik (Linv_k' z_k) for all rows below.
 __global__ void __launch_bounds__(256)
 k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, double *nu, int n_stiles, double *V,
-            double *W, float *Wf, int ldw, int *counts)
+            double *W, float *Wf, int ldw, int *counts, double *Gc)
 {
     __shared__ double sA[NB][NB + 1];
     __shared__ double sB[NB][NB + 1];
@@ -251,28 +251,57 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
         }
         return;
     }
-    // nu block
-    __shared__ double sz[NB], sw[NB];
-    if (tid < NB) sz[tid] = tid < kb ? nu[k0 + tid] : 0.0;
-    __syncthreads();
-    double zk = 0.0;
-    if (tid < NB) {
-        for (int c = 0; c <= tid; ++c) zk += sLi[tid][c] * sz[c];
-        if (tid < kb) nu[k0 + tid] = zk;
+    // right-hand-side blocks: [ nu | Gc ] (Gc = fp64 camera columns of the gathered H P rows, fp32 configuration only) are
+    // carried through the sweep like extra columns of S:  Z_k = Linv_k R_k (final rows of z and of Bc = inv(L) Gc), then
+    // R_i -= L_ik Z_k = S_ik (Linv_k' Z_k) for the rows below.  Block nb handles rows k1 + 256 nb ...; every block forms
+    // the 32 x 14 matrices itself (a 32^2 x 14 product), block 0 stores Z_k.
+    constexpr int NR = 14; // nu + 13 camera columns
+    __shared__ double sR[NB][NR + 1], sZ[NB][NR + 1], sW[NB][NR + 1];
+    const int nb = b - n_stiles;
+    const int nrhs = Gc ? NR : 1;
+    for (int i = tid; i < NB * NR; i += 256) {
+        const int r = i / NR, c = i % NR;
+        double v = 0.0;
+        if (r < kb && c < nrhs) v = c == 0 ? nu[k0 + r] : Gc[(size_t)(k0 + r) * 16 + c - 1];
+        sR[r][c] = v;
     }
     __syncthreads();
-    if (tid < NB) sz[tid] = tid < kb ? zk : 0.0;
+    for (int i = tid; i < NB * NR; i += 256) { // Z = Linv_k R_k
+        const int r = i / NR, c = i % NR;
+        double z = 0.0;
+        if (c < nrhs)
+            for (int q = 0; q <= r; ++q) z += sLi[r][q] * sR[q][c];
+        sZ[r][c] = r < kb ? z : 0.0;
+    }
     __syncthreads();
-    if (tid < NB) { // w = Linv_k' z_k
+    for (int i = tid; i < NB * NR; i += 256) { // W = Linv_k' Z
+        const int r = i / NR, c = i % NR;
         double w = 0.0;
-        for (int r = tid; r < NB; ++r) w += sLi[r][tid] * sz[r];
-        sw[tid] = w;
+        if (c < nrhs)
+            for (int q = r; q < NB; ++q) w += sLi[q][r] * sZ[q][c];
+        sW[r][c] = w;
+        if (nb == 0 && r < kb && c < nrhs) {
+            if (c == 0) nu[k0 + r] = sZ[r][0];
+            else Gc[(size_t)(k0 + r) * 16 + c - 1] = sZ[r][c];
+        }
     }
     __syncthreads();
-    for (int i = k1 + tid; i < m; i += 256) {
-        double s = 0.0;
-        for (int c = 0; c < kb; ++c) s += S[(size_t)i * ldS + k0 + c] * sw[c];
-        nu[i] -= s;
+    const int i = k1 + nb * 256 + tid;
+    if (i < m) {
+        double acc[NR];
+#pragma unroll
+        for (int c = 0; c < NR; ++c) acc[c] = 0.0;
+        const double *srow = S + (size_t)i * ldS + k0;
+        for (int q = 0; q < kb; ++q) {
+            const double sv = srow[q];
+#pragma unroll
+            for (int c = 0; c < NR; ++c) acc[c] += sv * sW[q][c];
+        }
+        nu[i] -= acc[0];
+        if (Gc) {
+#pragma unroll
+            for (int c = 1; c < NR; ++c) Gc[(size_t)i * 16 + c - 1] -= acc[c];
+        }
     }
 }
 
@@ -350,50 +379,6 @@ k_triinv_level(const double *S, int ldS, int m, int m_pad, double *V, double *W,
             if (Wf) Wf[(size_t)(r0 + gj) * ldw + gi] = (float)(-acc[q]);
         }
     }
-}
-
-// ------------------------------------------------------------------------------------- camera columns of B in fp64
-// Bc = inv(L) Gc for the 13 camera columns (Gc = fp64 camera columns of the gathered H P rows, V = inv(L) row-major):
-// m^2/2 x 13 fp64 FMAs.  The camera part of dx = B'z and the camera rows / columns of the downdate are formed from
-// Bc, so the camera state does not inherit the rounding of the fp32 GEMM B = W'G (whose entries are small differences
-// of large partial sums in these columns).  16 rows x 16 columns (13 used) per workgroup.
-__global__ void __launch_bounds__(256) k_bcam(const double *V, int ldw, const double *Gc, int m_pad, double *Bc)
-{
-    __shared__ double sv[16][65]; // V[i0 + r][k0 + k]
-    __shared__ double sg[64][17]; // Gc[k0 + k][a]
-    const int tid = threadIdx.x;
-    const int a = tid & 15, r = tid >> 4;
-    const int i0 = blockIdx.x * 16, i = i0 + r;
-    const int i_max = min(m_pad, i0 + 16); // rows of this workgroup need k < i_max (V lower triangular)
-    // both operand tiles of a 64-deep chunk are fetched (coalesced) one chunk ahead of the FMAs that consume them
-    double pv[4], pg[4];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256;                // 1024 elements per tile
-            const int vr = e >> 6, vk = e & 63;         // V tile: 16 rows x 64 k
-            pv[q] = (i0 + vr < m_pad && k0 + vk < m_pad) ? V[(size_t)(i0 + vr) * ldw + k0 + vk] : 0.0;
-            const int gk = e >> 4, ga = e & 15;         // Gc tile: 64 k x 16 columns
-            pg[q] = (k0 + gk < m_pad) ? Gc[(size_t)(k0 + gk) * 16 + ga] : 0.0;
-        }
-    };
-    double acc = 0.0;
-    fetch(0);
-    for (int k0 = 0; k0 < i_max; k0 += 64) {
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256;
-            sv[e >> 6][e & 63] = pv[q];
-            sg[e >> 4][e & 15] = pg[q];
-        }
-        __syncthreads();
-        if (k0 + 64 < i_max) fetch(k0 + 64);
-        // entries of V above the diagonal are zero, so the full chunk can be summed
-#pragma unroll 16
-        for (int k = 0; k < 64; ++k) acc += sv[r][k] * sg[k][a];
-    }
-    if (i < m_pad) Bc[(size_t)i * 16 + a] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------- dx = B' z
@@ -615,8 +600,9 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const int k1 = k0 + kb;
         const int nrb = (m - k1 + NB - 1) / NB; // row blocks below the panel
         const int n_stiles = nrb * (nrb + 1) / 2;
-        k_chol_step<<<n_stiles + 1, 256, 0, s>>>(e->d.S, e->d.LL, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles, V, W, Wf, ldw,
-                                                 e->d.counts);
+        const int n_rhs_blocks = max(1, (m - k1 + 255) / 256); // right-hand-side blocks, 256 rows each
+        k_chol_step<<<n_stiles + n_rhs_blocks, 256, 0, s>>>(e->d.S, e->d.LL, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles, V, W, Wf,
+                                                            ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr);
     }
     // inv(L) by doubling: 32 -> 64 -> ... until one block covers all rows
     for (int sz = NB; sz < m_pad; sz *= 2) {
@@ -643,10 +629,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     {
         dim3 grid((n + 255) / 256, DX_SPLIT);
         const double *Bc = nullptr;
-        if (sizeof(T) == 4) {
-            k_bcam<<<(m_pad + 15) / 16, 256, 0, s>>>(V, ldw, e->d.Gc, m_pad, e->d.Bc);
-            Bc = e->d.Bc;
-        }
+        if (sizeof(T) == 4) Bc = e->d.Gc; // the sweep turned Gc into Bc = inv(L) Gc (right-hand-side blocks of k_chol_step)
         k_dx_partial<T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.nu, e->d.dx_part, ld,
                                              (update_cov && sizeof(T) == 4) ? e->d.sq_part : nullptr,
                                              (update_cov && sizeof(T) == 4) ? e->d.cam_part : nullptr, Bc);
