@@ -13,7 +13,6 @@
 namespace ekf {
 
 constexpr int NB = 32;          // Cholesky panel width
-constexpr int TB = 256;         // row block of the triangular solve B = inv(L) A
 constexpr int LD_ALIGN = 128;   // leading dimensions are multiples of this many elements
 constexpr int DX_SPLIT = 16;    // k-splits of the dx = B' z reduction
 

@@ -1,10 +1,12 @@
 // kernels_update.hip -- A7, the Kalman update (EKF/Update.cpp:92-319), in the algebraically equivalent
 // "square-root downdate" form that never materialises the reference's dense n x n temporaries:
 //
-//     A  = H P            (m x n; rows gathered from the cached H_f P pairs, HBM-bound copy)
-//     S  = A H' + R       (m x m fp64, lower triangle; block-sparse H => 13-term dot products)
-//     S  = L L'           (blocked right-looking Cholesky, fp64)
-//     B  = inv(L) A,  z = inv(L) nu      (fused into the same panel sweep)
+//     G  = H P            (m x n; rows gathered from the cached H_f P pairs, HBM-bound copy)
+//     S  = G H' + R       (m x m fp64, lower triangle; block-sparse H => 13-term dot products)
+//     S  = L L'           (blocked right-looking Cholesky, fp64, one launch per 32-wide panel; z = inv(L) nu and, in the
+//                          fp32 configuration, the fp64 camera columns of B ride along as right-hand sides)
+//     inv(L)              (doubling levels on the fp64 MFMA)
+//     B  = inv(L) G       (ONE GEMM against the inverted factor, kernels_gemm.hip)
 //     dx = B' z           (= K nu,  K = P H' inv(S))
 //     P <- sym(P) - B' B  (= 0.5 ((I-KH)P + ((I-KH)P)'), kernels_pupdate.hip -- the MFMA kernel)
 //     q normalisation and its Jacobian on the rows/columns 3..6 of P (Update.cpp:45-85, 303-317)
