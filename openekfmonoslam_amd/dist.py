@@ -19,7 +19,11 @@ class Ranks:
             import torch
             import torch.distributed as dist
 
-            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            # EKF_DIST_BACKEND=gloo lets several ranks share one GPU (functional checks on a 1-GPU box; RCCL refuses that)
+            backend = backend or os.environ.get("EKF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            if torch.cuda.is_available():
+                torch.cuda.set_device(self.local_rank)
+                self.device = torch.device("cuda", self.local_rank)
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
                 self.device = torch.device("cuda", self.local_rank)

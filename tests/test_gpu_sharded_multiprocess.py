@@ -88,3 +88,31 @@ def test_two_processes_one_filter(tmp_path, precision):
     for rank, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o[-3000:]
         assert f"rank {rank} ok" in o
+
+
+def test_bench_sharded_mode_two_ranks_one_gpu(tmp_path):
+    """bench.py --mode sharded end to end with two ranks on cuda:0 (gloo transport): one JSON line from rank 0,
+    scaling "strong", the same decisions as the unsharded run"""
+    import json
+
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), EKF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "sharded",
+                                       "--workload", "n200_f64", "--steps", "4", "--warmup", "2", "--no-roofline-pass"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert "row-sharded" in d["config"]["parallelism"]
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]  # only rank 0 prints
+    ref = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "n200_f64", "--steps", "4",
+                          "--warmup", "2", "--no-roofline-pass", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    r = json.loads([ln for ln in ref.stdout.splitlines() if ln.startswith("{")][-1])
+    for k in ("mean_matches", "mean_li_inliers", "mean_rescued"):
+        assert d["config"][k] == r["config"][k]
