@@ -70,7 +70,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
                     d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.Tbuf, d.W, d.Wf, d.G, d.LL, d.gates, d.cell_resp, d.cell_xy,
-                    d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.sq_part, d.diag_save, d.cam_part, d.cam_save, d.HPc, d.Gc,
+                    d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.sq_part, d.diag_save, d.cam_part, d.cam_save, d.HPc, d.Gc, d.Bc, d.zvec,
                     e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -206,6 +206,8 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     ALLOC(d.cam_save, (size_t)13 * e->ldP);
     ALLOC(d.HPc, (size_t)mcap * 16);
     ALLOC(d.Gc, mw * 16);
+    ALLOC(d.Bc, mw * 16);
+    ALLOC(d.zvec, mw);
     ALLOC(d.mask, mcap);
     ALLOC(d.preds_out, cap);
 #undef ALLOC

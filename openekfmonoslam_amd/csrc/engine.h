@@ -116,7 +116,9 @@ struct DeviceArrays {
     double *cam_part = nullptr;  // DX_SPLIT x 13 x ldP: partial sums of the camera rows of B'B (fp64)
     double *cam_save = nullptr;  // 13 x ldP: camera rows of P before a downdate
     double *HPc = nullptr;       // [2 cap x 16]: fp64 camera columns of the H P rows
-    double *Gc = nullptr;        // [(mcap + slack) x 16]: those of the gathered rows; the sweep turns it into inv(L) Gc
+    double *Gc = nullptr;        // [(mcap + slack) x 16]: those of the gathered rows (working right-hand sides of the sweep)
+    double *Bc = nullptr;        // [(mcap + slack) x 16]: inv(L) Gc, the fp64 camera columns of B
+    double *zvec = nullptr;      // [mcap + slack]: z = inv(L) nu (nu itself is the sweep's working vector)
     uint8_t *mask = nullptr;   // generic byte mask output (rescue)
     void *pu_tilemap = nullptr; // int2 (ti, tj) per upper-triangle tile, XCD-friendly order
 };

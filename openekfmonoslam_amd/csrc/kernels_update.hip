@@ -137,7 +137,7 @@ k_chol_diag0(const double *S, int ldS, int kb, double *V, double *W, float *Wf, 
 //   nu block: z_k = Linv_k nu_k, then nu_i -= L_ik z_k = S_ik (Linv_k' z_k) for all rows below.
 __global__ void __launch_bounds__(256)
 k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, double *nu, int n_stiles, double *V,
-            double *W, float *Wf, int ldw, int *counts, double *Gc)
+            double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc)
 {
     __shared__ double sA[NB][NB + 1];
     __shared__ double sB[NB][NB + 1];
@@ -256,7 +256,9 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
     // right-hand-side blocks: [ nu | Gc ] (Gc = fp64 camera columns of the gathered H P rows, fp32 configuration only) are
     // carried through the sweep like extra columns of S:  Z_k = Linv_k R_k (final rows of z and of Bc = inv(L) Gc), then
     // R_i -= L_ik Z_k = S_ik (Linv_k' Z_k) for the rows below.  Block nb handles rows k1 + 256 nb ...; every block forms
-    // the 32 x 14 matrices itself (a 32^2 x 14 product), block 0 stores Z_k.
+    // the 32 x 14 matrices itself (a 32^2 x 14 product) from the rows k0.. of the WORKING arrays nu / Gc, which nobody
+    // writes in this launch; block 0 stores Z_k into the RESULT arrays zout / Bc (writing it back in place would race
+    // with the other blocks' reads of those rows).
     constexpr int NR = 14; // nu + 13 camera columns
     __shared__ double sR[NB][NR + 1], sZ[NB][NR + 1], sW[NB][NR + 1];
     const int nb = b - n_stiles;
@@ -283,8 +285,8 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
             for (int q = r; q < NB; ++q) w += sLi[q][r] * sZ[q][c];
         sW[r][c] = w;
         if (nb == 0 && r < kb && c < nrhs) {
-            if (c == 0) nu[k0 + r] = sZ[r][0];
-            else Gc[(size_t)(k0 + r) * 16 + c - 1] = sZ[r][c];
+            if (c == 0) zout[k0 + r] = sZ[r][0];
+            else Bc[(size_t)(k0 + r) * 16 + c - 1] = sZ[r][c];
         }
     }
     __syncthreads();
@@ -625,7 +627,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const int n_stiles = nrb * (nrb + 1) / 2;
         const int n_rhs_blocks = max(1, (m - k1 + 255) / 256); // right-hand-side blocks, 256 rows each
         k_chol_step<<<n_stiles + n_rhs_blocks, 256, 0, s>>>(e->d.S, e->d.LL, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles, V, W, Wf,
-                                                            ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr);
+                                                            ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr, e->d.zvec, e->d.Bc);
     }
     // inv(L) by doubling: 32 -> 64 -> ... until one block covers all rows
     for (int sz = NB; sz < m_pad; sz *= 2) {
@@ -654,8 +656,8 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const bool fix = update_cov && sizeof(T) == 4;
         const int avg = e->p_exact_sym ? 0 : 1; // an AVG downdate only exists on an unsharded engine: every row is local
         const double *Bc = nullptr;
-        if (sizeof(T) == 4) Bc = e->d.Gc; // the sweep turned Gc into Bc = inv(L) Gc (right-hand-side blocks of k_chol_step)
-        k_dx_partial<T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.nu, e->d.dx_part, ld,
+        if (sizeof(T) == 4) Bc = e->d.Bc; // inv(L) Gc, produced by the right-hand-side blocks of k_chol_step
+        k_dx_partial<T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld,
                                              fix ? e->d.sq_part : nullptr, fix ? e->d.cam_part : nullptr, Bc, (const T *)e->d.P,
                                              e->rm, e->d.diag_save, fix ? e->d.cam_save : nullptr, avg);
         const int nt = max(e->N * 6, 1);

@@ -206,3 +206,33 @@ def test_remove_every_feature_then_regrow(eng_mod, oracle_lib, seq12):
     oi = o.step(*seq12.frames[0], ALGORITHMIC)
     _same_info(gi, oi, "step on the regrown map")
     assert_state_close(e, o, F64_TOL, "step on the regrown map")
+
+
+def test_concurrent_engines_give_the_sequential_result(eng_mod):
+    """Two filters stepped from two threads at once (their kernels interleave on the GPU) must each reproduce, bit for
+    bit, what the same filter computes alone.  Guards the in-launch data flow of the sweep: the right-hand-side blocks
+    of k_chol_step once overwrote rows other blocks of the same launch were still reading, which only showed under
+    contention (N = 300: m - k1 > 256, i.e. several right-hand-side blocks per launch)."""
+    import threading
+
+    seq = SyntheticSequence(300, 4)
+
+    def run(out, k):
+        e = eng_mod.EkfEngine(seq.cam, seq.par, 300, max_keypoints=700, precision=1)
+        e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+        for t in range(4):
+            e.step(*seq.frames[t])
+        out[k] = e.get_state()
+
+    ref = [None]
+    run(ref, 0)
+    for _ in range(3):
+        res = [None, None, None]
+        th = [threading.Thread(target=run, args=(res, k)) for k in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for k in range(3):
+            np.testing.assert_array_equal(res[k][0], ref[0][0])
+            np.testing.assert_array_equal(res[k][2], ref[0][2])
