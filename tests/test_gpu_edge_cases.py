@@ -212,13 +212,13 @@ def test_concurrent_engines_give_the_sequential_result(eng_mod):
     """Two filters stepped from two threads at once (their kernels interleave on the GPU) must each reproduce, bit for
     bit, what the same filter computes alone.  Guards the in-launch data flow of the sweep: the right-hand-side blocks
     of k_chol_step once overwrote rows other blocks of the same launch were still reading, which only showed under
-    contention (N = 300: m - k1 > 256, i.e. several right-hand-side blocks per launch)."""
+    contention (N = 1000: up to four right-hand-side blocks per launch; with the defect this test fails)."""
     import threading
 
-    seq = SyntheticSequence(300, 4)
+    seq = SyntheticSequence(1000, 4)
 
     def run(out, k):
-        e = eng_mod.EkfEngine(seq.cam, seq.par, 300, max_keypoints=700, precision=1)
+        e = eng_mod.EkfEngine(seq.cam, seq.par, 1000, max_keypoints=2100, precision=1)
         e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
         for t in range(4):
             e.step(*seq.frames[t])
@@ -226,7 +226,7 @@ def test_concurrent_engines_give_the_sequential_result(eng_mod):
 
     ref = [None]
     run(ref, 0)
-    for _ in range(3):
+    for _ in range(2):
         res = [None, None, None]
         th = [threading.Thread(target=run, args=(res, k)) for k in range(3)]
         for t in th:
