@@ -392,66 +392,48 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
              const double *Bc, const T *P, RowMap rm, double *dsave, double *csave, int avg)
 {
     __shared__ double sc[64][13]; // fp64 camera columns of a chunk of rows of B
-    // two columns per thread (j0, j0 + 256): every broadcast read of sc feeds two FMAs
-    const int j0 = blockIdx.x * 512 + threadIdx.x, j1 = j0 + 256;
-    const bool v0 = j0 < n, v1 = j1 < n;
+    const int j = blockIdx.x * 256 + threadIdx.x;
     const int ks = blockIdx.y;
-    if (ks == 0 && csave) {
+    if (ks == 0 && csave && j < n) {
         // phase 0 of k_diag_fix: keep the diagonal and the camera rows of P as they are before the downdate
         // (avg: the first downdate after an arbitrary upload works on 0.5 (P(a,j) + P(j,a)))
+        const bool mine = owns_row(rm, j);
+        const T *prow = P + (size_t)local_row(rm, j) * ld;
+        if (mine) dsave[j] = (double)prow[j];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int j = h ? j1 : j0;
-            if (j >= n) continue;
-            const bool mine = owns_row(rm, j);
-            const T *prow = P + (size_t)local_row(rm, j) * ld;
-            if (mine) dsave[j] = (double)prow[j];
-#pragma unroll
-            for (int a = 0; a < 13; ++a)
-                csave[(size_t)a * ldpart + j] = avg ? (double)((T)0.5 * P[(size_t)a * ld + j] + (T)0.5 * prow[a]) : (double)P[(size_t)a * ld + j];
-        }
+        for (int a = 0; a < 13; ++a)
+            csave[(size_t)a * ldpart + j] = avg ? (double)((T)0.5 * P[(size_t)a * ld + j] + (T)0.5 * prow[a]) : (double)P[(size_t)a * ld + j];
     }
     const int per = (m + DX_SPLIT - 1) / DX_SPLIT;
     const int kb = ks * per, ke = min(m, kb + per);
-    double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
-    double c0[13], c1[13];
+    double s = 0.0, q = 0.0;
+    double c[13];
 #pragma unroll
-    for (int a = 0; a < 13; ++a) c0[a] = c1[a] = 0.0;
+    for (int a = 0; a < 13; ++a) c[a] = 0.0;
     for (int k0 = kb; k0 < ke; k0 += 64) {
         const int cnt = min(64, ke - k0);
-        if (Bc) {
+        if (Bc) { // fp64 camera columns of B (fp32 covariance only)
             __syncthreads();
             for (int i = threadIdx.x; i < cnt * 13; i += 256) sc[i / 13][i % 13] = Bc[(size_t)(k0 + i / 13) * 16 + i % 13];
             __syncthreads();
         }
-        for (int k = 0; k < cnt; ++k) {
-            const double zk = z[k0 + k];
-            const double b0 = !v0 ? 0.0 : ((Bc && j0 < 13) ? sc[k][j0] : (double)B[(size_t)(k0 + k) * ld + j0]);
-            const double b1 = !v1 ? 0.0 : (double)B[(size_t)(k0 + k) * ld + j1];
-            s0 += b0 * zk;
-            s1 += b1 * zk;
-            q0 += b0 * b0; // (B'B)_jj in fp64, same pass over B: see k_diag_fix
-            q1 += b1 * b1;
-            if (cam_part) {
+        if (j < n)
+            for (int k = 0; k < cnt; ++k) {
+                const double b = (Bc && j < 13) ? sc[k][j] : (double)B[(size_t)(k0 + k) * ld + j];
+                s += b * z[k0 + k];
+                q += b * b; // (B'B)_jj in fp64, same pass over B: see k_diag_fix
+                if (cam_part) {
 #pragma unroll
-                for (int a = 0; a < 13; ++a) { // (B'B)_aj, camera rows
-                    const double ca = sc[k][a];
-                    c0[a] += ca * b0;
-                    c1[a] += ca * b1;
+                    for (int a = 0; a < 13; ++a) c[a] += sc[k][a] * b; // (B'B)_aj, camera rows
                 }
             }
-        }
     }
+    if (j >= n) return;
+    part[(size_t)ks * ldpart + j] = s;
+    if (sq_part) sq_part[(size_t)ks * ldpart + j] = q;
+    if (cam_part) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int j = h ? j1 : j0;
-        if (j >= n) continue;
-        part[(size_t)ks * ldpart + j] = h ? s1 : s0;
-        if (sq_part) sq_part[(size_t)ks * ldpart + j] = h ? q1 : q0;
-        if (cam_part) {
-#pragma unroll
-            for (int a = 0; a < 13; ++a) cam_part[((size_t)ks * 13 + a) * ldpart + j] = h ? c1[a] : c0[a];
-        }
+        for (int a = 0; a < 13; ++a) cam_part[((size_t)ks * 13 + a) * ldpart + j] = c[a];
     }
 }
 
@@ -652,7 +634,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         launch_xty(e, g, 1, e->f32);
     }
     {
-        dim3 grid((n + 511) / 512, DX_SPLIT);
+        dim3 grid((n + 255) / 256, DX_SPLIT);
         const bool fix = update_cov && sizeof(T) == 4;
         const int avg = e->p_exact_sym ? 0 : 1; // an AVG downdate only exists on an unsharded engine: every row is local
         const double *Bc = nullptr;
