@@ -261,34 +261,60 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
     __syncthreads();
     T *o0 = HP + (size_t)(2 * fi) * ld;
     T *o1 = o0 + ld;
-    for (int j = tid; j < n; j += 256) {
-        double a0 = 0.0, a1 = 0.0;
-        for (int a = 0; a < d; ++a) {
-            const double p = (double)Pf[(size_t)a * ld + j];
-            a0 += sH[14 + a] * p;
-            a1 += sH[20 + a] * p;
-        }
-        double b0 = 0.0, b1 = 0.0;
+    // 16 bytes per lane and row: a wavefront reads 1 KB (fp32) / 1 KB (fp64, two columns) of CONTIGUOUS row per load
+    // instead of 256 B, which the HBM-bound pass over P needs (rows are ld elements apart; ld is a multiple of 128, so
+    // reading up to the padded row end is in bounds; columns >= n are never stored)
+    constexpr int VW = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VW)));
+    for (int jb = tid * VW; jb < n; jb += 256 * VW) {
+        vec_t pf[6], pc[7];
 #pragma unroll
-        for (int a = 0; a < 7; ++a) {
-            const double p = (double)P[(size_t)a * ld + j];
-            b0 += sH[a] * p;
-            b1 += sH[7 + a] * p;
+        for (int a = 0; a < 6; ++a)
+            if (a < d) pf[a] = *(const vec_t *)(Pf + (size_t)a * ld + jb);
+#pragma unroll
+        for (int a = 0; a < 7; ++a) pc[a] = *(const vec_t *)(P + (size_t)a * ld + jb);
+        vec_t r0, r1;
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+            const int j = jb + v;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+                if (a < d) {
+                    const double p = (double)pf[a][v];
+                    a0 += sH[14 + a] * p;
+                    a1 += sH[20 + a] * p;
+                }
+            double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 7; ++a) {
+                const double p = (double)pc[a][v];
+                b0 += sH[a] * p;
+                b1 += sH[7 + a] * p;
+            }
+            a0 += b0;
+            a1 += b1;
+            r0[v] = (T)a0;
+            r1[v] = (T)a1;
+            if (j < 13) { // fp64 copy of the camera columns: the camera part of B = inv(L) (H P) is solved in fp64
+                HPc[(size_t)(2 * fi) * 16 + j] = a0;
+                HPc[(size_t)(2 * fi + 1) * 16 + j] = a1;
+            }
+            if (j < 7) {
+                sHP[0][j] = a0;
+                sHP[1][j] = a1;
+            } else if (j >= pos && j < pos + d) {
+                sHP[0][7 + j - pos] = a0;
+                sHP[1][7 + j - pos] = a1;
+            }
         }
-        a0 += b0;
-        a1 += b1;
-        o0[j] = (T)a0;
-        o1[j] = (T)a1;
-        if (j < 13) { // fp64 copy of the camera columns: the camera part of B = inv(L) (H P) is solved in fp64 (k_bcam)
-            HPc[(size_t)(2 * fi) * 16 + j] = a0;
-            HPc[(size_t)(2 * fi + 1) * 16 + j] = a1;
-        }
-        if (j < 7) {
-            sHP[0][j] = a0;
-            sHP[1][j] = a1;
-        } else if (j >= pos && j < pos + d) {
-            sHP[0][7 + j - pos] = a0;
-            sHP[1][7 + j - pos] = a1;
+        if (jb + VW <= n) {
+            *(vec_t *)(o0 + jb) = r0;
+            *(vec_t *)(o1 + jb) = r1;
+        } else {
+#pragma unroll
+            for (int v = 0; v < VW; ++v)
+                if (jb + v < n) { o0[jb + v] = r0[v]; o1[jb + v] = r1[v]; }
         }
     }
     __syncthreads();
