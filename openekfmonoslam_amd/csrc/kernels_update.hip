@@ -28,13 +28,16 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
          double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc)
 {
     const int row = blockIdx.y;
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    // 16 bytes per thread: the copy is pure HBM traffic (n_pad and ld are multiples of 128 elements)
+    constexpr int VW = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VW)));
+    const int j = (blockIdx.x * 256 + threadIdx.x) * VW;
     const int m = 2 * M;
     if (row < m) {
         const int i = row >> 1, r = row & 1;
         const int fi = matches[i].featureIndex;
-        if (j < n_pad) A[(size_t)row * ld + j] = HP[(size_t)(2 * fi + r) * ld + j];
-        if (j < 16) Gc[(size_t)row * 16 + j] = j < 13 ? HPc[(size_t)(2 * fi + r) * 16 + j] : 0.0;
+        if (j < n_pad) *(vec_t *)(A + (size_t)row * ld + j) = *(const vec_t *)(HP + (size_t)(2 * fi + r) * ld + j);
+        if (blockIdx.x == 0 && threadIdx.x < 16) Gc[(size_t)row * 16 + threadIdx.x] = threadIdx.x < 13 ? HPc[(size_t)(2 * fi + r) * 16 + threadIdx.x] : 0.0;
         if (blockIdx.x == 0 && r == 0) {
             const int t = threadIdx.x;
             if (t < 14) mHs[14 * i + t] = Hs_tab[14 * fi + t];
@@ -48,8 +51,13 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
             }
         }
     } else if (row < m_pad) {
-        if (j < n_pad) A[(size_t)row * ld + j] = (T)0;
-        if (j < 16) Gc[(size_t)row * 16 + j] = 0.0;
+        if (j < n_pad) {
+            vec_t zero;
+#pragma unroll
+            for (int v = 0; v < VW; ++v) zero[v] = (T)0;
+            *(vec_t *)(A + (size_t)row * ld + j) = zero;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < 16) Gc[(size_t)row * 16 + threadIdx.x] = 0.0;
         if (blockIdx.x == 0 && threadIdx.x == 0) nu[row] = 0.0;
     }
 }
@@ -591,7 +599,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     double *V = e->d.Dinv, *W = e->d.W;
     float *Wf = e->f32 ? e->d.Wf : nullptr;
     {
-        dim3 grid((n_pad + 255) / 256, m_pad);
+        dim3 grid((n_pad / (int)(16 / sizeof(T)) + 255) / 256, m_pad);
         k_gather<T><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const T *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
                                          e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc);
