@@ -30,7 +30,7 @@ namespace ekf {
 // Swapping the operands of an MFMA product changes no bit, so P[i][j] here equals P[j][i] on the rank that owns j.
 template <typename T, bool AVG, bool RECT>
 __global__ void __launch_bounds__(256, PU_MIN_WAVES)
-k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, const int4 *units, RowMap rm)
+k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, const int4 *units, RowMap rm, int stagger)
 {
     using M = Mma<T>;
     constexpr int MB = M::MB, TM = 4 * MB, KI = 64 / MB, VEC = M::VEC;
@@ -48,6 +48,17 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
     // spreads over all CUs instead of leaving most of them idle for a whole tile time.
     const int4 unit = units[(size_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)];
     if (unit.x < 0) return;
+    if (stagger > 0) {
+        // Short k-loops (m < 512): a tile is mostly its 64 KB read-modify-write of P, and the three workgroups resident on a
+        // CU would hit that HBM-bound phase together.  The second and third workgroup of the first round start a fraction
+        // of a tile time late (s_sleep costs no MFMA slots; the others keep the pipe busy): 0.146 -> 0.125 ms at m = 320.
+        // For long k-loops the half-units-first order does the de-phasing and this is off (it costs 3 % there).
+        const int slot = (blockIdx.x >> 3) / 32; // 32 CUs per XCD: the position this workgroup takes on its CU
+        if (slot == 1 || slot == 2) {
+            const int n_sleep = slot * m_pad / stagger;
+            for (int i = 0; i < n_sleep; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
     const int ti = unit.x, tj = unit.y;
     const bool full = unit.z < 0;
     const bool diag = RECT || (ti == tj);
@@ -249,11 +260,11 @@ static void launch_p_update_t(EkfEngine *e, int m_pad, int grid, const int4 *tm,
     T *P = (T *)e->d.P;
     const T *B = (const T *)e->d.A;
     if (rect)
-        k_p_update<T, false, true><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm);
+        k_p_update<T, false, true><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, (m_pad < 512 && grid >= 768) ? 80 : 0);
     else if (avg)
-        k_p_update<T, true, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm);
+        k_p_update<T, true, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, (m_pad < 512 && grid >= 768) ? 80 : 0);
     else
-        k_p_update<T, false, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm);
+        k_p_update<T, false, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, (m_pad < 512 && grid >= 768) ? 80 : 0);
 }
 
 void launch_p_update(EkfEngine *e, int m_pad)
