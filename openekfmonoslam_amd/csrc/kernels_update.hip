@@ -62,40 +62,67 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
     }
 }
 
+// inv(L_kk) goes to V (row-major inv(L)), its transpose to W (and to the fp32 copy of W, when present)
+__device__ __forceinline__ void store_linv(double *V, double *W, float *Wf, int ldw, int k0, const double (*x)[NB + 1])
+{
+    for (int i = threadIdx.x; i < NB * NB; i += 256) {
+        const int r = i / NB, c = i % NB;
+        V[(size_t)(k0 + r) * ldw + k0 + c] = x[r][c];
+        const double t = x[c][r]; // W[k0 + r][k0 + c] = inv(L)[k0 + c][k0 + r]
+        W[(size_t)(k0 + r) * ldw + k0 + c] = t;
+        if (Wf) Wf[(size_t)(k0 + r) * ldw + k0 + c] = (float)t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ S = A H' + R
 // One thread per 2x2 block (a, b), b <= a, of the lower triangle.
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, const int *mpos, const int *mdim,
-             double pixel_err, double *S, int ldS)
+             double pixel_err, double *S, int ldS, double *V, double *W, float *Wf, int ldw, int *counts)
 {
     const int b = blockIdx.x * 16 + (threadIdx.x & 15);
     const int a = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (a >= M || b > a) return;
-    const int pos = mpos[b], d = mdim[b];
-    const double *hs = mHs + 14 * b, *hf = mHf + 12 * b;
+    if (a < M && b <= a) {
+        const int pos = mpos[b], d = mdim[b];
+        const double *hs = mHs + 14 * b, *hf = mHf + 12 * b;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const T *ar = A + (size_t)(2 * a + r) * ld;
-        double s0 = 0.0, s1 = 0.0;
+        for (int r = 0; r < 2; ++r) {
+            const T *ar = A + (size_t)(2 * a + r) * ld;
+            double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const double v = (double)ar[k];
-            s0 += v * hs[k];
-            s1 += v * hs[7 + k];
+            for (int k = 0; k < 7; ++k) {
+                const double v = (double)ar[k];
+                s0 += v * hs[k];
+                s1 += v * hs[7 + k];
+            }
+            for (int k = 0; k < d; ++k) {
+                const double v = (double)ar[pos + k];
+                s0 += v * hf[k];
+                s1 += v * hf[6 + k];
+            }
+            if (a == b) {
+                if (r == 0) s0 += pixel_err;
+                else s1 += pixel_err;
+            }
+            S[(size_t)(2 * a + r) * ldS + 2 * b] = s0;
+            S[(size_t)(2 * a + r) * ldS + 2 * b + 1] = s1;
         }
-        for (int k = 0; k < d; ++k) {
-            const double v = (double)ar[pos + k];
-            s0 += v * hf[k];
-            s1 += v * hf[6 + k];
-        }
-        if (a == b) {
-            if (r == 0) s0 += pixel_err;
-            else s1 += pixel_err;
-        }
-        S[(size_t)(2 * a + r) * ldS + 2 * b] = s0;
-        S[(size_t)(2 * a + r) * ldS + 2 * b + 1] = s1;
     }
+    if (blockIdx.x != 0 || blockIdx.y != 0) return;
+    // Block (0, 0) has just written the first 32 x 32 diagonal block of S: factorise it here (what the sweep's
+    // look-ahead does for every later block), which saves the separate launch that used to start the sweep.
+    __shared__ double sa[NB][NB + 1], sx[NB][NB + 1];
+    __threadfence_block();
+    __syncthreads();
+    const int kb = min(NB, 2 * M);
+    for (int i = threadIdx.x; i < NB * NB; i += 256) {
+        const int r = i / NB, c = i % NB;
+        sa[r][c] = (r < kb && c <= r) ? S[(size_t)r * ldS + c] : ((r == c) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (!block_chol_inv32_mf(sa, sx) && threadIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
+    store_linv(V, W, Wf, ldw, 0, sx);
 }
 
 // -------------------------------------------------------------------------------------- blocked Cholesky sweep
@@ -109,31 +136,7 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 // B = inv(L) A is NOT part of the sweep: it is independent per column of A and runs afterwards as one launch
 // (k_xty, kernels_gemm.hip) on the MFMA pipe, against the explicitly inverted factor.
 
-// inv(L_kk) goes to V (row-major inv(L)), its transpose to W (and to the fp32 copy of W, when present)
-__device__ __forceinline__ void store_linv(double *V, double *W, float *Wf, int ldw, int k0, const double (*x)[NB + 1])
-{
-    for (int i = threadIdx.x; i < NB * NB; i += 256) {
-        const int r = i / NB, c = i % NB;
-        V[(size_t)(k0 + r) * ldw + k0 + c] = x[r][c];
-        const double t = x[c][r]; // W[k0 + r][k0 + c] = inv(L)[k0 + c][k0 + r]
-        W[(size_t)(k0 + r) * ldw + k0 + c] = t;
-        if (Wf) Wf[(size_t)(k0 + r) * ldw + k0 + c] = (float)t;
-    }
-}
 
-// first panel only: factorise block 0
-__global__ void __launch_bounds__(256)
-k_chol_diag0(const double *S, int ldS, int kb, double *V, double *W, float *Wf, int ldw, int *counts)
-{
-    __shared__ double sa[NB][NB + 1], sx[NB][NB + 1];
-    for (int i = threadIdx.x; i < NB * NB; i += 256) {
-        const int r = i / NB, c = i % NB;
-        sa[r][c] = (r < kb && c <= r) ? S[(size_t)r * ldS + c] : ((r == c) ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    if (!block_chol_inv32_mf(sa, sx) && threadIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
-    store_linv(V, W, Wf, ldw, 0, sx);
-}
 
 // One launch per panel k (width NB = 32), Linv_k = inv(L_kk) already in V (look-ahead of the previous launch):
 //   grid.x : [0, n_stiles) lower-triangular 32x32 tiles (i >= j > k) of the trailing matrix, then one block for nu.
@@ -607,9 +610,8 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     {
         dim3 grid((M + 15) / 16, (M + 15) / 16);
         k_assemble_S<T><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
-                                             e->cfg.cam.pixelErrorX, e->d.S, ldS);
+                                             e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts);
     }
-    k_chol_diag0<<<1, 256, 0, s>>>(e->d.S, ldS, min(NB, m), V, W, Wf, ldw, e->d.counts);
     for (int k0 = 0; k0 < m; k0 += NB) {
         const int kb = min(NB, m - k0);
         const int k1 = k0 + kb;
