@@ -13,7 +13,7 @@ using namespace ekf;
 
 namespace ekf {
 void launch_partition(EkfEngine *e, const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0,
-                      int *cnt1);
+                      int *cnt1, bool map_update = false, const uint8_t *d_kdesc = nullptr);
 void launch_outlier_idx(EkfEngine *e, const EkfMatch *src, int M, int *idx);
 } // namespace ekf
 
@@ -685,13 +685,13 @@ int ekf_predict(EkfEngine *e)
 }
 
 // device-side core of predictCameraMeasurements; leaves the count in h_counts
-static int predict_measurements_dev(EkfEngine *e, const int *d_idx, int count, int *n_out)
+static int predict_measurements_dev(EkfEngine *e, const int *d_idx, int count, int *n_out, bool count_predicted = false)
 {
     launch_predict_features(e, d_idx, d_idx ? count : e->N, false);
     int rc = read_counts(e);
     if (rc) return rc;
     const int np = e->h_counts[d_idx ? CNT_NPRED_SUB : CNT_NPRED];
-    launch_hp_rows(e, d_idx ? e->d.plist_sub : e->d.plist, np);
+    launch_hp_rows(e, d_idx ? e->d.plist_sub : e->d.plist, np, count_predicted);
     if (!d_idx) e->n_pred = np;
     *n_out = np;
     if (e->shard_world > 1 && np > 0) {
@@ -1000,9 +1000,8 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
     // 1-2. prediction (:273-284)
     launch_predict(e);
     int np = 0;
-    if ((rc = predict_measurements_dev(e, nullptr, e->N, &np))) return rc;
+    if ((rc = predict_measurements_dev(e, nullptr, e->N, &np, true))) return rc; // + timesPredicted++ (EKF.cpp:572)
     li.n_predicted = np;
-    launch_count_predicted(e, np); // updateMapFeatures, EKF.cpp:572 / MapManagement.cpp:81-86
     tm.mark();
     // 4. matching (:337)
     int M = 0;
@@ -1016,8 +1015,8 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
         li.n_hypotheses = e->h_counts[CNT_RS_NEXT];
         ni = e->h_counts[CNT_RS_BEST];
         no = M - ni;
-        launch_partition(e, e->d.matches, M, e->d.best_flags, e->d.msel, e->d.mout, nullptr);
-        launch_map_update(e, e->d.msel, ni, d_desc); // MapManagement.cpp:88-113 for the low-innovation inliers
+        // + updateMapFeatures for the low-innovation inliers (MapManagement.cpp:88-113), same launch
+        launch_partition(e, e->d.matches, M, e->d.best_flags, e->d.msel, e->d.mout, nullptr, true, d_desc);
     }
     li.n_inliers = ni;
     li.n_outliers = no;
@@ -1037,10 +1036,9 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
             e->d.matches = e->d.mout;
             launch_rescue(e, no);
             e->d.matches = save;
-            launch_partition(e, e->d.mout, no, e->d.mask, e->d.msel, nullptr, e->d.counts + CNT_NRESC);
+            launch_partition(e, e->d.mout, no, e->d.mask, e->d.msel, nullptr, e->d.counts + CNT_NRESC, true, d_desc); // rescued matches join the inliers (EKF.cpp:552-556)
             if ((rc = read_counts(e))) return rc;
             nr = e->h_counts[CNT_NRESC];
-            launch_map_update(e, e->d.msel, nr, d_desc); // rescued matches join the inliers (EKF.cpp:552-556)
         }
     }
     li.n_rescued = nr;

@@ -214,7 +214,7 @@ void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32);
 void launch_predict(EkfEngine *e);
 // full (idx == nullptr) or subset prediction; fills tables, compacted list and CNT_NPRED / CNT_NPRED_SUB
 void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool tables_only_state);
-void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list);
+void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_predicted = false);
 void launch_match(EkfEngine *e, int n_pred, int n_kp);
 void launch_match_index(EkfEngine *e, int M);
 void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch);
@@ -222,7 +222,6 @@ void launch_ransac_init(EkfEngine *e, int M);
 void launch_update(EkfEngine *e, int M, bool update_cov);
 void launch_rescue(EkfEngine *e, int M);
 void launch_state_only_predict(EkfEngine *e, EkfPrediction *d_out); // predictMeasurementState on current state
-void launch_count_predicted(EkfEngine *e, int n_pred);
 void launch_add_features(EkfEngine *e, const double *d_uv, int count, double *d_Jpo, double *d_Jhr);
 void launch_compact_P(EkfEngine *e, int n_new, const int *d_new2old);
 void launch_linearity(EkfEngine *e, double *d_out);

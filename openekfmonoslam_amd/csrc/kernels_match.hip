@@ -169,7 +169,8 @@ void launch_match_index(EkfEngine *e, int M)
 // Stable partition of src[0..M) by flags: dst1 receives the flagged matches, dst0 (optional) the others, both in
 // the original order (1PointRansac.cpp:213-227, EKF.cpp:110-117).
 __global__ void __launch_bounds__(1024)
-k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0, int *cnt1)
+k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0, int *cnt1, const uint8_t *kdesc,
+            uint8_t *feat_desc, unsigned *times_matched)
 {
     __shared__ int part[1024];
     const int tid = threadIdx.x;
@@ -192,26 +193,37 @@ k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, Ek
         else if (dst0) dst0[p0++] = src[i];
     }
     if (tid == 1023 && cnt1) *cnt1 = part[1023];
+    if (!times_matched) return;
+    // updateMapFeatures for the selected matches (MapManagement.cpp:88-113), fused: timesMatched++ and the map descriptor
+    // replaced by the matched keypoint's (matcher mode B has no keypoint: keypointIndex < 0)
+    __syncthreads();
+    const int count = part[1023];
+    for (int i = tid; i < count; i += 1024) {
+        const int fi = dst1[i].featureIndex, kp = dst1[i].keypointIndex;
+        times_matched[fi]++;
+        if (kp >= 0 && kdesc) {
+            const uint32_t *sd = (const uint32_t *)(kdesc + (size_t)kp * EKF_DESC_BYTES);
+            uint32_t *dd = (uint32_t *)(feat_desc + (size_t)fi * EKF_DESC_BYTES);
+#pragma unroll
+            for (int w = 0; w < 8; ++w) dd[w] = sd[w];
+        }
+    }
 }
 
 void launch_partition(EkfEngine *e, const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0,
-                      int *cnt1)
+                      int *cnt1, bool map_update, const uint8_t *d_kdesc)
 {
     if (M <= 0) {
         if (cnt1) (void)hipMemsetAsync(cnt1, 0, sizeof(int), e->stream);
         return;
     }
-    k_partition<<<1, 1024, 0, e->stream>>>(src, M, flags, dst1, dst0, cnt1);
+    k_partition<<<1, 1024, 0, e->stream>>>(src, M, flags, dst1, dst0, cnt1, d_kdesc, e->d.feat_desc,
+                                           map_update ? e->d.feat_times_matched : nullptr);
 }
 
 // updateMapFeatures (EKF/MapManagement.cpp:77-113), run by EKF::step every frame (EKF.cpp:572): every predicted
-// feature's timesPredicted++, every inlier / rescued match's timesMatched++ and its map descriptor replaced by the
-// matched keypoint's descriptor.
-__global__ void __launch_bounds__(256) k_count_predicted(const int *plist, int n_pred, unsigned *times_predicted)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n_pred) times_predicted[plist[i]]++;
-}
+// feature's timesPredicted++ (done by k_hp_rows during a step), every inlier / rescued match's timesMatched++ and its
+// map descriptor replaced by the matched keypoint's descriptor.
 
 __global__ void __launch_bounds__(256)
 k_map_update(const EkfMatch *sel, int count, const uint8_t *kdesc, uint8_t *feat_desc, unsigned *times_matched)
@@ -224,11 +236,6 @@ k_map_update(const EkfMatch *sel, int count, const uint8_t *kdesc, uint8_t *feat
         ((uint32_t *)(feat_desc + (size_t)fi * EKF_DESC_BYTES))[w] = ((const uint32_t *)(kdesc + (size_t)kp * EKF_DESC_BYTES))[w];
 }
 
-void launch_count_predicted(EkfEngine *e, int n_pred)
-{
-    if (n_pred > 0)
-        k_count_predicted<<<(n_pred + 255) / 256, 256, 0, e->stream>>>(e->d.plist, n_pred, e->d.feat_times_predicted);
-}
 
 void launch_map_update(EkfEngine *e, const EkfMatch *d_sel, int count, const uint8_t *d_kdesc)
 {

@@ -246,7 +246,7 @@ void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool sta
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, const int *feat_covpos,
-          const double *Hs_tab, const double *Hf_tab, T *HP, double *S_tab, RowMap rm, double *HPc)
+          const double *Hs_tab, const double *Hf_tab, T *HP, double *S_tab, RowMap rm, double *HPc, unsigned *times_predicted)
 {
     __shared__ double sH[26];     // Hs (2x7) then Hf (2x6)
     __shared__ double sHP[2][13]; // fp64 H P at columns 0..6 and pos..pos+d-1
@@ -254,6 +254,9 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
     const int tid = threadIdx.x;
     const int d = feat_dim(feat_type[fi]);
     const int pos = feat_covpos[fi];
+    // updateMapFeatures' timesPredicted++ (MapManagement.cpp:81-86) rides along when a step asks for it (every rank counts
+    // every feature: the map is replicated)
+    if (times_predicted && tid == 0) times_predicted[fi]++;
     if (!owns_row(rm, pos)) return; // sharded: the owner of the feature's rows computes them, the exchange delivers them
     const T *Pf = P + (size_t)local_row(rm, pos) * ld;
     if (tid < 14) sH[tid] = Hs_tab[14 * fi + tid];
@@ -327,17 +330,18 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
     }
 }
 
-void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list)
+void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_predicted)
 {
+    unsigned *tp = count_predicted ? e->d.feat_times_predicted : nullptr;
     if (n_list <= 0) return;
     if (e->f32)
         k_hp_rows<float><<<n_list, 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
                                                         e->d.feat_covpos, e->d.Hs, e->d.Hf, (float *)e->d.HP,
-                                                        e->d.pred_S, e->rm, e->d.HPc);
+                                                        e->d.pred_S, e->rm, e->d.HPc, tp);
     else
         k_hp_rows<double><<<n_list, 256, 0, e->stream>>>((const double *)e->d.P, e->ldP, e->n, d_list,
                                                          e->d.feat_type, e->d.feat_covpos, e->d.Hs, e->d.Hf,
-                                                         (double *)e->d.HP, e->d.pred_S, e->rm, e->d.HPc);
+                                                         (double *)e->d.HP, e->d.pred_S, e->rm, e->d.HPc, tp);
 }
 
 // predictMeasurementState on the current state into an EkfPrediction array (device), all features.

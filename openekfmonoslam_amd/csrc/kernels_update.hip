@@ -482,36 +482,9 @@ k_diag_fix(T *P, int ld, int n, RowMap rm, const double *dsave, const double *sq
     }
 }
 
-// stateUpdate (Update.cpp:147-204): x += dx with the DELTA dead-band on every component; R(q) recomputed from
-// the un-normalised q (:168).
-__global__ void __launch_bounds__(256)
-k_state_apply(double *st, double *feat_pos, const int *feat_type, const int *feat_covpos, int N, const double *part,
-              int ldpart)
+// quaternion normalisation and its Jacobian (Update.cpp:45-62, 303-312), one thread
+__device__ inline void quat_norm_dev(double *st)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t == 0) {
-        double *x = st + ST_X;
-        for (int i = 0; i < 13; ++i) {
-            double s = 0.0;
-            for (int ks = 0; ks < DX_SPLIT; ++ks) s += part[(size_t)ks * ldpart + i];
-            if (fabs(s) > EKF_DELTA) x[i] += s;
-        }
-        quat_to_rot(x + 3, st + ST_R);
-    }
-    if (t >= N * 6) return;
-    const int f = t / 6, a = t % 6;
-    if (a >= feat_dim(feat_type[f])) return;
-    const int j = feat_covpos[f] + a;
-    double s = 0.0;
-    for (int ks = 0; ks < DX_SPLIT; ++ks) s += part[(size_t)ks * ldpart + j];
-    if (fabs(s) > EKF_DELTA) feat_pos[6 * f + a] += s;
-}
-
-// ------------------------------------------------------------------------------ quaternion normalisation tail
-// normalizeQuaternionJacobian from the un-normalised q (Update.cpp:45-60, 305), then q /= |q| (:308-313).
-__global__ void k_quat_norm(double *st)
-{
-    if (threadIdx.x != 0) return;
     double *q = st + ST_X + 3;
     const double r = q[0], x = q[1], y = q[2], z = q[3];
     const double nrm = sqrt(r * r + x * x + y * y + z * z);
@@ -525,6 +498,37 @@ __global__ void k_quat_norm(double *st)
     q[0] = r / nrm; q[1] = x / nrm; q[2] = y / nrm; q[3] = z / nrm;
     quat_to_rot(q, st + ST_R);
 }
+
+// stateUpdate (Update.cpp:147-204): x += dx with the DELTA dead-band on every component; R(q) recomputed from
+// the un-normalised q (:168).
+__global__ void __launch_bounds__(256)
+k_state_apply(double *st, double *feat_pos, const int *feat_type, const int *feat_covpos, int N, const double *part,
+              int ldpart, int normalise)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) {
+        double *x = st + ST_X;
+        for (int i = 0; i < 13; ++i) {
+            double s = 0.0;
+            for (int ks = 0; ks < DX_SPLIT; ++ks) s += part[(size_t)ks * ldpart + i];
+            if (fabs(s) > EKF_DELTA) x[i] += s;
+        }
+        // the covariance downdate that sits between the state update and the normalisation in the reference
+        // (Update.cpp:299-312) does not read the state, so the normalisation is done here (not for updateOnlyState)
+        if (normalise) quat_norm_dev(st);
+        else quat_to_rot(x + 3, st + ST_R);
+    }
+    if (t >= N * 6) return;
+    const int f = t / 6, a = t % 6;
+    if (a >= feat_dim(feat_type[f])) return;
+    const int j = feat_covpos[f] + a;
+    double s = 0.0;
+    for (int ks = 0; ks < DX_SPLIT; ++ks) s += part[(size_t)ks * ldpart + j];
+    if (fabs(s) > EKF_DELTA) feat_pos[6 * f + a] += s;
+}
+
+// ------------------------------------------------------------------------------ quaternion normalisation tail
+// normalizeQuaternionJacobian from the un-normalised q (Update.cpp:45-60, 305), then q /= |q| (:308-313).
 
 // normalizeCovariance (Update.cpp:64-85): P <- D P D', D = diag(I3, J, I).  Five disjoint blocks; block 0 owns
 // the 7x7 corner pieces, every other thread owns column j of the row strip 3..6 and row j of the column strip.
@@ -654,13 +658,12 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
                                              e->rm, e->d.diag_save, fix ? e->d.cam_save : nullptr, avg);
         const int nt = max(e->N * 6, 1);
         k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
-                                                       e->N, e->d.dx_part, ld);
+                                                       e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
     }
     if (!update_cov) return;
     const bool fix_diag = sizeof(T) == 4;
     launch_p_update(e, m_pad);
     if (fix_diag) k_diag_fix<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save, e->d.cam_part, ld);
-    k_quat_norm<<<1, 64, 0, s>>>(e->d.state);
     const int nb = 1 + (n > 7 ? (n - 7 + 255) / 256 : 0);
     k_normalize_cov<T><<<nb, 256, 0, s>>>((T *)e->d.P, ld, n, e->d.state, e->rm);
 }
