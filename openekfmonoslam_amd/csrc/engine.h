@@ -233,6 +233,5 @@ void launch_match_ncc(EkfEngine *e, int n_pred);
 void launch_gate_snapshot(EkfEngine *e, int n_pred);
 void launch_detect_cells(EkfEngine *e, int n_gates, int cells_x, int cells_y, long long *d_resp, int *d_xy);
 void launch_publish_counts(EkfEngine *e, int *d_mirror, int seq);
-void launch_map_update(EkfEngine *e, const EkfMatch *d_sel, int count, const uint8_t *d_kdesc);
 
 } // namespace ekf

@@ -221,27 +221,9 @@ void launch_partition(EkfEngine *e, const EkfMatch *src, int M, const uint8_t *f
                                            map_update ? e->d.feat_times_matched : nullptr);
 }
 
-// updateMapFeatures (EKF/MapManagement.cpp:77-113), run by EKF::step every frame (EKF.cpp:572): every predicted
-// feature's timesPredicted++ (done by k_hp_rows during a step), every inlier / rescued match's timesMatched++ and its
-// map descriptor replaced by the matched keypoint's descriptor.
-
-__global__ void __launch_bounds__(256)
-k_map_update(const EkfMatch *sel, int count, const uint8_t *kdesc, uint8_t *feat_desc, unsigned *times_matched)
-{
-    const int i = blockIdx.x * 32 + (threadIdx.x >> 3), w = threadIdx.x & 7; // 8 lanes x 4 bytes per descriptor
-    if (i >= count) return;
-    const int fi = sel[i].featureIndex, kp = sel[i].keypointIndex;
-    if (w == 0) times_matched[fi]++;
-    if (kp >= 0)
-        ((uint32_t *)(feat_desc + (size_t)fi * EKF_DESC_BYTES))[w] = ((const uint32_t *)(kdesc + (size_t)kp * EKF_DESC_BYTES))[w];
-}
 
 
-void launch_map_update(EkfEngine *e, const EkfMatch *d_sel, int count, const uint8_t *d_kdesc)
-{
-    if (count > 0)
-        k_map_update<<<(count + 31) / 32, 256, 0, e->stream>>>(d_sel, count, d_kdesc, e->d.feat_desc, e->d.feat_times_matched);
-}
+
 
 __global__ void __launch_bounds__(256) k_outlier_idx(const EkfMatch *src, int M, int *idx)
 {
