@@ -78,6 +78,29 @@ int main(int argc, char **argv)
             ekf.syncToHost();
             report("class", ekf.state, ekf.stateCovarianceMatrix, &info);
         }
+        // (3) class EKF: the map-management methods (EKF.cpp:574-612) after one step, then another step on the new map
+        {
+            EKF ekf(cam, par, N + 8);
+            ekf.init(seed, P0);
+            ekf.step(frames[0]);
+            std::vector<int32_t> drop;
+            drop.push_back(1);
+            drop.push_back(3);
+            ekf.removeFeaturesFromStateAndCovariance(drop);                                   // MapManagement.cpp:212
+            std::vector<double> uv;
+            uv.push_back(100.5); uv.push_back(80.25);
+            uv.push_back(400.0); uv.push_back(300.0);
+            std::vector<uint8_t> nd(2 * EKF_DESC_BYTES);
+            for (size_t i = 0; i < nd.size(); ++i) nd[i] = (uint8_t)(37 * i + 11);
+            ekf.addFeaturesToStateAndCovariance(uv, nd);                                      // AddMapFeature.cpp:354
+            const int conv = ekf.convertMapFeaturesInverseDepthToDepth();                     // MapManagement.cpp:494
+            const int bad = ekf.removeBadMapFeatures();                                       // :279
+            EkfStepInfo info = ekf.step(frames[1]);
+            ekf.syncToHost();
+            std::printf("mapmgmt_aux conv %d bad %d features %d dim %d\n", conv, bad, (int)ekf.state.mapFeatures.size(),
+                        ekf_state_dim(ekf.engine()));
+            report("mapmgmt", ekf.state, ekf.stateCovarianceMatrix, &info);
+        }
         // (2) the reference's stage functions, frame 0, in EKF::step order
         ekf_compat::Context::instance().configure(cam, par, N + 8);
         State state(seed);

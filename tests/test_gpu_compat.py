@@ -60,8 +60,9 @@ def test_compat_class_and_functions_match_ctypes_and_oracle(tmp_path, oracle_lib
     scen = os.path.join(str(tmp_path), "scenario.bin")
     write_scenario(scen, seq)
     out = subprocess.run([exe, scen], check=True, capture_output=True, text=True).stdout.strip().splitlines()
-    res = {ln.split()[0]: parse(ln) for ln in out if ln.startswith(("class", "functions"))}
-    assert set(res) == {"class", "functions"}
+    res = {ln.split()[0]: parse(ln) for ln in out if ln.startswith(("class", "functions", "mapmgmt "))}
+    assert set(res) == {"class", "functions", "mapmgmt"}
+    aux = [ln for ln in out if ln.startswith("mapmgmt_aux")][0].split()
 
     e = engine.EkfEngine(seq.cam, seq.par, 32, max_keypoints=256)
     o = oracle_lib.Oracle(seq.cam, seq.par, 32)
@@ -81,6 +82,22 @@ def test_compat_class_and_functions_match_ctypes_and_oracle(tmp_path, oracle_lib
     assert tr == float(np.trace(P)) or abs(tr - np.trace(P)) <= 1e-15 * abs(tr)
     li = infos[-1]
     assert counts == [li.n_predicted, li.n_matches, li.n_hypotheses, li.n_inliers, li.n_rescued]
+    # class EKF map management == the same calls through ctypes (bitwise: same library, same order)
+    e2 = engine.EkfEngine(seq.cam, seq.par, 32, max_keypoints=256)
+    e2.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    e2.step(*seq.frames[0])
+    e2.remove_features([1, 3])
+    nd = ((37 * np.arange(64) + 11) % 256).astype(np.uint8).reshape(2, 32)
+    e2.add_features(np.array([[100.5, 80.25], [400.0, 300.0]]), nd)
+    conv = e2.convert_inverse_depth_to_depth()
+    bad = e2.remove_bad_features()
+    i2 = e2.step(*seq.frames[1])
+    x2, _, P2 = e2.get_state()
+    assert [int(aux[2]), int(aux[4]), int(aux[6]), int(aux[8])] == [conv, bad, e2.N, e2.n]
+    xm, trm, from_, cm = res["mapmgmt"]
+    np.testing.assert_array_equal(xm, x2)
+    assert abs(trm - np.trace(P2)) <= 1e-15 * abs(trm) and abs(from_ - np.linalg.norm(P2)) <= 1e-14 * from_
+    assert cm == [i2.n_predicted, i2.n_matches, i2.n_hypotheses, i2.n_inliers, i2.n_rescued]
     # stage functions, frame 0: equal to the resident path and within 1e-8 of the oracle
     xf, trf, frof, cf = res["functions"]
     np.testing.assert_allclose(xf, x0, rtol=1e-12, atol=1e-15)
