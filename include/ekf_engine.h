@@ -122,6 +122,11 @@ int ekf_get_camera_covariance(EkfEngine *e, double P13[169]);
 int ekf_get_unseen_features(EkfEngine *e, int32_t *feat_idx, int *count);
 /* MapFeature::featureType / covarianceMatrixPos of every feature (EKF/MapFeature.h:60-68) */
 int ekf_get_feature_layout(EkfEngine *e, int32_t *type, int32_t *covpos);
+/* predictedDistortedFeatures of the step's predictCameraMeasurements as they were BEFORE the updates -- what
+ * drawPrediction receives for the per-frame prediction image (EKF/EKF.cpp:294-305, Gui/Draw.cpp:266-310).  Off by
+ * default (one extra small launch per frame when on); preds may be NULL to get the count only. */
+int ekf_keep_step_predictions(EkfEngine *e, int on);
+int ekf_get_step_predictions(EkfEngine *e, EkfPrediction *preds, int *n_preds);
 
 /* -- stages ---------------------------------------------------------------------------------------------- */
 /* stateAndCovariancePrediction(State&, Matd&)            EKF/StateAndCovariancePrediction.h:41 (.cpp:244-253) */
@@ -151,6 +156,8 @@ int ekf_match(EkfEngine *e, const EkfKeypoint *kps, const uint8_t *desc32, int n
  * inlier_mask[i] = 1 for matches kept as low-innovation inliers.  n_hypotheses (optional) = hypotheses the
  * sequential reference loop would have evaluated. */
 int ekf_ransac(EkfEngine *e, const EkfMatch *matches, int M, uint8_t *inlier_mask, int *n_hypotheses);
+/* ekf_ransac / ekf_update / ekf_update_only_state / ekf_rescue: at most ONE match per featureIndex (what
+ * matchPredictedFeatures produces); a list with a repeated featureIndex returns EKF_ERR_INVALID_ARG. */
 
 /* update(state, P, matches, preds, jacobians)            EKF/Update.h:48 (.cpp:282-319) */
 int ekf_update(EkfEngine *e, const EkfMatch *matches, int M);

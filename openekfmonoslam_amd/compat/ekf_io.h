@@ -179,7 +179,7 @@ inline bool readPng(const std::string &path, Image &img, std::string *err = 0)
         const std::string type((const char *)&buf[pos + 4], 4);
         const uint8_t *d = &buf[pos + 8];
         if (pos + 12 + len > buf.size()) break;
-        if (type == "IHDR") { w = be32(d); h = be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12]; }
+        if (type == "IHDR" && len >= 13) { w = be32(d); h = be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12]; }
         else if (type == "PLTE") palette.assign(d, d + len);
         else if (type == "IDAT") idat.insert(idat.end(), d, d + len);
         else if (type == "IEND") break;
@@ -232,7 +232,7 @@ inline bool readPng(const std::string &path, Image &img, std::string *err = 0)
     return true;
 }
 
-// gray or BGR image -> 8-bit PNG (filter 0); for tools and tests
+// gray or BGR image -> 8-bit PNG (filter 0): cv::imwrite of the per-frame prediction image (EKF.cpp:300-302), tools, tests
 inline bool writePng(const std::string &path, const Image &img)
 {
     const int ch = img.channels;
@@ -297,6 +297,147 @@ private:
     std::string path_, prefix_, ext_;
     int index_, end_;
 };
+
+// ------------------------------------------------------------------------------------------- prediction image
+// drawPrediction (Gui/Draw.cpp:266-310): the frame with, per predicted feature, a 5-pixel cross (drawPoint :66-70), the
+// outline of its uncertainty ellipse (drawUncertaintyEllipse2D :42-64: centre and semi-axes truncated to int) and its
+// map index; inverse-depth features red, depth features green (BGR).  The reference renders the index with
+// cv::putText (Hershey plain, scale 1.3); this build draws it with its own 3x5 digit glyphs -- the one stated deviation.
+struct Bgr { uint8_t b, g, r; };
+
+inline void putPixel(Image &im, int x, int y, Bgr c)
+{
+    if (x < 0 || y < 0 || x >= im.width || y >= im.height) return;
+    uint8_t *p = &im.data[((size_t)y * im.width + x) * 3];
+    p[0] = c.b; p[1] = c.g; p[2] = c.r;
+}
+
+inline void drawLine(Image &im, int x0, int y0, int x1, int y1, Bgr c)
+{   // Bresenham, 8-connected (cv::line with the default line type)
+    const int dx = std::abs(x1 - x0), sx = x0 < x1 ? 1 : -1, dy = -std::abs(y1 - y0), sy = y0 < y1 ? 1 : -1;
+    int e = dx + dy;
+    for (;;) {
+        putPixel(im, x0, y0, c);
+        if (x0 == x1 && y0 == y1) break;
+        const int e2 = 2 * e;
+        if (e2 >= dy) { e += dy; x0 += sx; }
+        if (e2 <= dx) { e += dx; y0 += sy; }
+    }
+}
+
+// matrix2x2ToUncertaintyEllipse2D (Core/EKFMath.cpp:271-298): cv::eigen of the symmetric 2x2 (cyclic Jacobi,
+// eigenvalues descending, eigenvectors as rows), semi-axes 2 sqrt(lambda chi2_95) as float, angle atan(V10 / V00)
+inline void covarianceToEllipse(const double S[4], float axes[2], double *angle)
+{
+    double A01 = S[1], W0 = S[0], W1 = S[3];
+    double V[4] = {1, 0, 0, 1};
+    for (int it = 0; it < 120; ++it) {
+        const double p = A01;
+        if (std::fabs(p) <= 2.220446049250313e-16) break;
+        const double y = (W1 - W0) * 0.5;
+        double t = std::fabs(y) + std::hypot(p, y);
+        double s = std::hypot(p, t);
+        const double c = t / s;
+        s = p / s;
+        t = (p / t) * p;
+        if (y < 0) { s = -s; t = -t; }
+        A01 = 0;
+        W0 -= t;
+        W1 += t;
+        for (int i = 0; i < 2; ++i) {
+            const double a0 = V[i], b0 = V[2 + i];
+            V[i] = a0 * c - b0 * s;
+            V[2 + i] = a0 * s + b0 * c;
+        }
+    }
+    if (W0 < W1) {
+        std::swap(W0, W1);
+        for (int i = 0; i < 2; ++i) std::swap(V[i], V[2 + i]);
+    }
+    axes[0] = (float)(2.0 * std::sqrt(W0 * EKF_CHISQ_95_2));
+    axes[1] = (float)(2.0 * std::sqrt(W1 * EKF_CHISQ_95_2));
+    *angle = std::atan(V[2] / V[0]);
+}
+
+inline void drawEllipseOutline(Image &im, int cx, int cy, int aw, int ah, double angleRad, Bgr c)
+{   // cv::ellipse outline: the polygon of ellipse2Poly (5-degree steps), closed
+    const double ca = std::cos(angleRad), sa = std::sin(angleRad);
+    int px = 0, py = 0;
+    for (int k = 0; k <= 72; ++k) {
+        const double t = k * (3.14159265358979323846 / 36.0);
+        const double ex = aw * std::cos(t), ey = ah * std::sin(t);
+        const int x = (int)std::lrint(cx + ex * ca - ey * sa), y = (int)std::lrint(cy + ex * sa + ey * ca);
+        if (k > 0) drawLine(im, px, py, x, y, c);
+        px = x; py = y;
+    }
+}
+
+inline void drawNumber(Image &im, int x, int y, int value, Bgr c)
+{   // 3x5 glyphs, 2x magnified, baseline at y (the text origin of putText is the bottom-left corner)
+    static const uint16_t glyph[10] = {075557, 022222, 071747, 071717, 055711, 074717, 074757, 071111, 075757, 075717};
+    char buf[16];
+    std::snprintf(buf, sizeof(buf), "%d", value);
+    for (int i = 0; buf[i]; ++i) {
+        const uint16_t g = glyph[buf[i] - '0'];
+        for (int r = 0; r < 5; ++r)
+            for (int q = 0; q < 3; ++q)
+                if (g >> (14 - 3 * r - q) & 1)
+                    for (int a = 0; a < 2; ++a)
+                        for (int b = 0; b < 2; ++b) putPixel(im, x + 8 * i + 2 * q + a, y - 10 + 2 * r + b, c);
+    }
+}
+
+inline void drawPrediction(const Image &image, const EkfPrediction *preds, int nPreds, const int32_t *featureType, Image &result)
+{
+    result.width = image.width; result.height = image.height; result.channels = 3;
+    result.data.resize((size_t)image.width * image.height * 3);
+    for (size_t i = 0; i < (size_t)image.width * image.height; ++i)
+        for (int ch = 0; ch < 3; ++ch) result.data[3 * i + ch] = image.channels == 3 ? image.data[3 * i + ch] : image.data[i];
+    const Bgr green = {0, 255, 0}, red = {0, 0, 255}, text = {0, 255, 255}, shadow = {150, 150, 150};
+    for (int i = 0; i < nPreds; ++i) {
+        const EkfPrediction &p = preds[i];
+        const bool inv = featureType[p.featureIndex] == EKF_FEATURE_INVERSE_DEPTH;
+        const Bgr col = inv ? red : green;
+        const int x = (int)p.imagePos[0], y = (int)p.imagePos[1];
+        drawLine(result, x, y - 2, x, y + 2, col);
+        drawLine(result, x + 2, y, x - 2, y, col);
+        float axes[2];
+        double angle;
+        covarianceToEllipse(p.covarianceMatrix, axes, &angle);
+        // centre: cv::Point(Point2f) truncates the FLOAT copy of the position; axes: cv::Size(int, int) from floats
+        drawEllipseOutline(result, (int)(float)p.imagePos[0], (int)(float)p.imagePos[1], (int)std::min(axes[0], 9999999.f),
+                           (int)std::min(axes[1], 9999999.f), angle, col);
+        drawNumber(result, (int)std::lrint(p.imagePos[0] + 1), (int)std::lrint(p.imagePos[1] + 1), p.featureIndex, shadow);
+        drawNumber(result, (int)std::lrint(p.imagePos[0]), (int)std::lrint(p.imagePos[1]), p.featureIndex, text);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- log.txt
+// State::showDetailed (State.cpp:229-258) = operator<<(State) (:371-400) + one line per map feature
+// (operator<<(MapFeature), MapFeature.cpp:130-145), default ostream formatting (6 significant digits) as in the
+// reference.
+inline void showDetailed(std::ostream &os, const double x[13], int N, const double *featurePos, const int32_t *featureType,
+                         const uint32_t *timesPredicted, const uint32_t *timesMatched)
+{
+    const double q0 = x[3], q1 = x[4], q2 = x[5], q3 = x[6];
+    const double ang[3] = {std::atan2(2 * (q0 * q1 + q2 * q3), 1 - 2 * (q1 * q1 + q2 * q2)), // quaterionToAngles, EKFMath.cpp:355-365
+                           std::asin(2 * (q0 * q2 - q3 * q1)),
+                           std::atan2(2 * (q0 * q3 + q1 * q2), 1 - 2 * (q2 * q2 + q3 * q3))};
+    os << "Posicion de la camara: " << x[0] << ", " << x[1] << ", " << x[2] << std::endl;
+    os << "Orientacion(cuaternions): " << x[3] << ", " << x[4] << ", " << x[5] << ", " << x[6] << std::endl;
+    os << "Orientacion en angulos eulerianos: " << ang[0] << ", " << ang[1] << ", " << ang[2] << std::endl;
+    os << "Velocidad lineal (con respecto al mundo): " << x[7] << ", " << x[8] << ", " << x[9] << std::endl;
+    os << "Velocidad angular (con respecto a la camara): " << x[10] << ", " << x[11] << ", " << x[12] << std::endl;
+    os << "Cantidad de features en el mapa: " << N << std::endl;
+    os << std::endl;
+    os << "Map Features (" << N << "):" << std::endl;
+    for (int i = 0; i < N; ++i) {
+        const int d = featureType[i] == EKF_FEATURE_INVERSE_DEPTH ? 6 : 3;
+        os << i << ": " << featurePos[6 * (size_t)i];
+        for (int k = 1; k < d; ++k) os << ", " << featurePos[6 * (size_t)i + k];
+        os << " (" << timesMatched[i] << "/" << timesPredicted[i] << ")" << std::endl;
+    }
+}
 
 // --------------------------------------------------------------------------------------------- output.yml
 // cv::FileStorage YAML 1.0 as OpenCV 2.4 writes it: "%YAML:1.0" header, 3-space indentation, reals as "%.16e" (or
@@ -380,29 +521,43 @@ public:
         cfg.precision = precision; cfg.device = -1;
         const int rc = ekf_engine_create(&cfg, &e_);
         if (rc != EKF_OK) throw std::runtime_error("ekf_engine_create failed (no MI355X visible?)");
-        if (!outputPath_.empty()) {
+        if (!outputPath_.empty()) { // EKF.cpp:129-137: output.yml + log.txt (+ a video this build does not write)
             if (!out_.open(outputPath_ + "output.yml")) throw std::runtime_error("cannot write " + outputPath_ + "output.yml");
+            log_.open((outputPath_ + "log.txt").c_str(), std::ios_base::out);
             ekf_timing_enable(e_, 1);
+            ekf_keep_step_predictions(e_, 1);
         }
     }
     ~ImageEKF()
     {
         out_.release();
+        if (log_.is_open()) log_.close();
         if (e_) ekf_engine_destroy(e_);
     }
     // EKF::init(image)  EKF.cpp:170-237
     void init(const Image &image)
     {
+        if (log_.is_open()) { // EKF.cpp:172-180; the new-feature selection of this build draws no random numbers: seed 0
+            log_ << "Random Seed: " << 0 << std::endl << std::endl;
+            log_ << "~~~~~~~~~~~~ STEP " << steps_ << " ~~~~~~~~~~~~" << std::endl;
+        }
         chk(ekf_reset(e_), "ekf_reset");
         chk(ekf_image_upload(e_, image.data.data(), image.width, image.height, image.width * image.channels, image.channels), "ekf_image_upload");
         addNewFeatures(run_.minMatchesPerImage);
+        logState();
     }
     // EKF::step(image)  EKF.cpp:242-666
     EkfStepInfo step(const Image &image)
     {
+        ++steps_; // EKF.cpp:244: the first step is "Frame 1", map management runs on steps f, 2f, ...
+        if (log_.is_open()) {
+            log_ << std::endl << std::endl;
+            log_ << "~~~~~~~~~~~~ STEP " << steps_ << " ~~~~~~~~~~~~" << std::endl;
+        }
         EkfStepInfo info;
         if (out_.isOpened()) ekf_timing_reset(e_);
         chk(ekf_step_image(e_, image.data.data(), image.width, image.height, image.width * image.channels, image.channels, &info), "ekf_step_image");
+        if (!outputPath_.empty()) writePredictionImage(image); // EKF.cpp:294-305
         const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
         const int inliers = info.n_inliers + info.n_rescued;
         // EKF.cpp:574-612 (updateMapFeatures already ran inside the step)
@@ -416,9 +571,13 @@ public:
                 for (int i = 0; i < N; ++i)
                     if ((float)tm[i] / (float)tp[i] < par_.goodFeatureMatchingPercent) drop[i] = 1;
             }
-            int kept = 0;
-            for (int i = 0; i < N; ++i) kept += !drop[i];
-            const int rows = ekf_state_dim(e_);
+            // the conditions below are evaluated AFTER removeBadMapFeatures in the reference (EKF.cpp:580-586):
+            // map size and covariance rows of the features that are kept
+            std::vector<int32_t> type(N + 1);
+            chk(ekf_get_feature_layout(e_, type.data(), 0), "ekf_get_feature_layout");
+            int kept = 0, rows = 13;
+            for (int i = 0; i < N; ++i)
+                if (!drop[i]) { ++kept; rows += type[i] == EKF_FEATURE_INVERSE_DEPTH ? 6 : 3; }
             if (needed > 0 && (run_.alwaysRemoveUnseenMapFeatures || (run_.maxMapFeaturesCount > 0 && kept + needed > run_.maxMapFeaturesCount) ||
                                (run_.maxMapSize > 0 && rows + needed * 6 > run_.maxMapSize))) {
                 std::vector<int32_t> unseen(N + 1);
@@ -438,7 +597,7 @@ public:
             const double mapUs = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
             writeFrame(info, mapUs);
         }
-        ++steps_;
+        logState();
         return info;
     }
     EkfEngine *engine() { return e_; }
@@ -468,6 +627,33 @@ private:
         std::vector<int32_t> idx(got);
         for (int i = 0; i < got; ++i) idx[i] = N0 + i;
         chk(ekf_capture_templates(e_, idx.data(), uv.data(), got), "ekf_capture_templates");
+    }
+    void logState()
+    {   // state.showDetailed(_logFile)  EKF.cpp:233-236, 662-665
+        if (!log_.is_open()) return;
+        const int N = ekf_num_features(e_);
+        double x[13];
+        std::vector<double> fp(6 * (size_t)N + 6);
+        std::vector<int32_t> type(N + 1);
+        std::vector<uint32_t> tp(N + 1), tm(N + 1);
+        chk(ekf_get_state(e_, x, fp.data(), 0), "ekf_get_state");
+        chk(ekf_get_feature_layout(e_, type.data(), 0), "ekf_get_feature_layout");
+        chk(ekf_get_map_features(e_, 0, tp.data(), tm.data()), "ekf_get_map_features");
+        showDetailed(log_, x, N, fp.data(), type.data(), tp.data(), tm.data());
+    }
+    void writePredictionImage(const Image &image)
+    {
+        int np = 0;
+        chk(ekf_get_step_predictions(e_, 0, &np), "ekf_get_step_predictions");
+        std::vector<EkfPrediction> preds(np + 1);
+        chk(ekf_get_step_predictions(e_, preds.data(), &np), "ekf_get_step_predictions");
+        std::vector<int32_t> type(ekf_num_features(e_) + 1);
+        chk(ekf_get_feature_layout(e_, type.data(), 0), "ekf_get_feature_layout");
+        Image drawn;
+        drawPrediction(image, preds.data(), np, type.data(), drawn);
+        char name[32];
+        std::snprintf(name, sizeof(name), "%05d.png", steps_);
+        if (!writePng(outputPath_ + name, drawn)) throw std::runtime_error("cannot write " + outputPath_ + name); // cv::imwrite, EKF.cpp:302
     }
     void writeFrame(const EkfStepInfo &info, double mapManagementUs)
     {
@@ -510,6 +696,7 @@ private:
     EkfParams par_;
     RunParameters run_;
     OutputWriter out_;
+    std::ofstream log_;
 };
 
 } // namespace ekf_compat

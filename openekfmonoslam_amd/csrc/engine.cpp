@@ -65,12 +65,12 @@ void ekf_engine_destroy(EkfEngine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     DeviceArrays &d = e->d;
-    void *ptrs[] = {d.state,     d.feat_pos,  d.feat_type, d.feat_covpos, d.feat_desc, d.feat_times_predicted, d.feat_times_matched, d.P, d.P2, d.mm_scratch, d.mm_index,        d.pred_vis,
+    void *ptrs[] = {d.state,     d.feat_pos,  d.feat_type, d.feat_covpos, d.feat_desc, d.feat_times_predicted, d.feat_times_matched, d.P, d.P2, d.mm_scratch, d.mm_index,        d.pred_vis, d.pred_vis_full, d.step_preds,
                     d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,
                     d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
                     d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.Tbuf, d.W, d.Wf, d.G, d.LL, d.gates, d.cell_resp, d.cell_xy,
-                    d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.sq_part, d.diag_save, d.cam_part, d.cam_save, d.HPc, d.Gc, d.Bc, d.zvec,
+                    d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.sq_part, d.diag_save, d.cam_part, d.cam_save, d.HPc, d.Gc, d.Bc, d.zvec, d.yvec,
                     e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -159,6 +159,8 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     ALLOC(d.mm_scratch, (size_t)60 * cap + 4 * (size_t)e->ldP + 64);
     ALLOC(d.mm_index, (size_t)e->ncap + 8);
     ALLOC(d.pred_vis, cap);
+    ALLOC(d.pred_vis_full, cap);
+    ALLOC(d.step_preds, cap);
     ALLOC(d.pred_uv, 2 * cap);
     ALLOC(d.pred_vis2, cap);
     ALLOC(d.pred_uv2, 2 * cap);
@@ -208,6 +210,7 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     ALLOC(d.Gc, mw * 16);
     ALLOC(d.Bc, mw * 16);
     ALLOC(d.zvec, mw);
+    ALLOC(d.yvec, mw);
     ALLOC(d.mask, mcap);
     ALLOC(d.preds_out, cap);
 #undef ALLOC
@@ -390,6 +393,8 @@ int ekf_set_state(EkfEngine *e, const double x13[13], int n_features, const doub
         e->p_exact_sym = sharded;
     }
     HIPCHK(hipMemset(e->d.pred_vis, 0, (size_t)e->cap * sizeof(int)));
+    HIPCHK(hipMemset(e->d.pred_vis_full, 0, (size_t)e->cap * sizeof(int)));
+    e->n_step_preds = 0;
     HIPCHK(hipMemset(e->d.feat_times_predicted, 0, (size_t)e->cap * sizeof(unsigned)));
     HIPCHK(hipMemset(e->d.feat_times_matched, 0, (size_t)e->cap * sizeof(unsigned)));
     return EKF_OK;
@@ -469,7 +474,7 @@ int ekf_get_unseen_features(EkfEngine *e, int32_t *feat_idx, int *count)
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     std::vector<int> vis(e->N);
-    HIPCHK(hipMemcpy(vis.data(), e->d.pred_vis, (size_t)e->N * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(vis.data(), e->d.pred_vis_full, (size_t)e->N * sizeof(int), hipMemcpyDeviceToHost));
     int k = 0;
     for (int i = 0; i < e->N; ++i)
         if (!vis[i]) {
@@ -477,6 +482,25 @@ int ekf_get_unseen_features(EkfEngine *e, int32_t *feat_idx, int *count)
             ++k;
         }
     *count = k;
+    return EKF_OK;
+}
+
+int ekf_keep_step_predictions(EkfEngine *e, int on)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    e->keep_step_preds = on != 0;
+    if (!on) e->n_step_preds = 0;
+    return EKF_OK;
+}
+
+int ekf_get_step_predictions(EkfEngine *e, EkfPrediction *preds, int *n_preds)
+{
+    if (!e || !n_preds) return EKF_ERR_INVALID_ARG;
+    *n_preds = e->n_step_preds;
+    if (!preds || e->n_step_preds == 0) return EKF_OK;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(preds, e->d.step_preds, (size_t)e->n_step_preds * sizeof(EkfPrediction), hipMemcpyDeviceToHost));
     return EKF_OK;
 }
 
@@ -717,6 +741,10 @@ static int predict_measurements_dev(EkfEngine *e, const int *d_idx, int count, i
             return EKF_ERR_COMM;
         }
     }
+    if (!d_idx && e->keep_step_preds) { // EKF.cpp:294-305 draws the step's predictions as they were BEFORE the updates
+        launch_pack_predictions(e, e->d.plist, np, e->d.step_preds);
+        e->n_step_preds = np;
+    }
     if (!d_idx && e->img.valid) { // image mode: keep the gates of this prediction for detectNewImageFeatures' mask
         launch_gate_snapshot(e, np);
         e->n_gates = np;
@@ -844,11 +872,17 @@ static int ransac_dev(EkfEngine *e, int M)
     return check_async(e);
 }
 
+// The device code keys predictions, Jacobians and H.P rows by featureIndex: one match per feature (what the matcher
+// produces, Matching.cpp:217-262).  A list with a repeated featureIndex is rejected instead of being half-processed.
 static int validate_matches(const EkfEngine *e, const EkfMatch *m, int M)
 {
     if (M < 0 || M > e->cap || (M > 0 && !m)) return EKF_ERR_INVALID_ARG;
-    for (int i = 0; i < M; ++i)
-        if (m[i].featureIndex < 0 || m[i].featureIndex >= e->N) return EKF_ERR_INVALID_ARG;
+    std::vector<uint8_t> seen((size_t)e->N, 0);
+    for (int i = 0; i < M; ++i) {
+        const int f = m[i].featureIndex;
+        if (f < 0 || f >= e->N || seen[f]) return EKF_ERR_INVALID_ARG;
+        seen[f] = 1;
+    }
     return EKF_OK;
 }
 
@@ -959,6 +993,10 @@ struct StageTimer {
     EkfEngine *e;
     std::vector<hipEvent_t> evs;
     explicit StageTimer(EkfEngine *eng) : e(eng) {}
+    ~StageTimer() // early returns of step_dev skip finish(): the events recorded so far are released here
+    {
+        for (auto ev : evs) (void)hipEventDestroy(ev);
+    }
     void mark()
     {
         if (!e->timing) return;
@@ -969,10 +1007,7 @@ struct StageTimer {
     }
     void finish()
     {
-        if (!e->timing || evs.size() < 7) {
-            for (auto ev : evs) (void)hipEventDestroy(ev);
-            return;
-        }
+        if (!e->timing || evs.size() < 7) return;
         (void)hipStreamSynchronize(e->stream);
         double *dst[6] = {&e->times.prediction_ms, &e->times.matching_ms, &e->times.ransac_ms,
                           &e->times.update_li_ms,  &e->times.rescue_ms,   &e->times.update_hi_ms};
@@ -981,6 +1016,7 @@ struct StageTimer {
             if (hipEventElapsedTime(&ms, evs[i], evs[i + 1]) == hipSuccess) *dst[i] += ms;
         }
         for (auto ev : evs) (void)hipEventDestroy(ev);
+        evs.clear();
         e->times.steps += 1;
         harvest_pu_events(e);
     }

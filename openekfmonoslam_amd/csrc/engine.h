@@ -61,7 +61,9 @@ struct DeviceArrays {
     double *mm_scratch = nullptr; // map management scratch: Jpo/Jhr of a batch, 3 x ldP conversion rows, N linearity values
     int *mm_index = nullptr;      // new2old row map (ncap ints)
     // prediction tables, keyed by feature index
-    int *pred_vis = nullptr;
+    int *pred_vis = nullptr;      // visibility per feature, latest prediction (full or subset)
+    int *pred_vis_full = nullptr; // visibility per feature, last FULL prediction (the step's unseenFeatures)
+    EkfPrediction *step_preds = nullptr; // snapshot of the last full prediction (ekf_keep_step_predictions)
     double *pred_uv = nullptr; // 2 per feature
     int *pred_vis2 = nullptr;    // scratch copies for state-only predictions
     double *pred_uv2 = nullptr;
@@ -119,6 +121,7 @@ struct DeviceArrays {
     double *Gc = nullptr;        // [(mcap + slack) x 16]: those of the gathered rows (working right-hand sides of the sweep)
     double *Bc = nullptr;        // [(mcap + slack) x 16]: inv(L) Gc, the fp64 camera columns of B
     double *zvec = nullptr;      // [mcap + slack]: z = inv(L) nu (nu itself is the sweep's working vector)
+    double *yvec = nullptr;      // [mcap + slack]: y = inv(L)' z = inv(S) nu (fp32 configuration: dx = (H P)' y)
     uint8_t *mask = nullptr;   // generic byte mask output (rescue)
     void *pu_tilemap = nullptr; // int2 (ti, tj) per upper-triangle tile, XCD-friendly order
 };
@@ -165,6 +168,8 @@ struct EkfEngine {
     bool p_exact_sym = false; // P known to be bitwise symmetric (engine-maintained invariant)
     int n_pred = 0;           // predictions of the last full prediction
     int n_gates = 0;          // gates snapshotted for the new-feature detector
+    bool keep_step_preds = false; // snapshot every full prediction for ekf_get_step_predictions
+    int n_step_preds = 0;
     int cells_cap = 0;        // detector cell buffers allocated for this many cells
     int n_kp = 0;
     int pu_tilemap_nt = -1;
@@ -233,5 +238,6 @@ void launch_match_ncc(EkfEngine *e, int n_pred);
 void launch_gate_snapshot(EkfEngine *e, int n_pred);
 void launch_detect_cells(EkfEngine *e, int n_gates, int cells_x, int cells_y, long long *d_resp, int *d_xy);
 void launch_publish_counts(EkfEngine *e, int *d_mirror, int seq);
+void launch_pack_predictions(EkfEngine *e, const int *d_list, int n, EkfPrediction *d_out);
 
 } // namespace ekf

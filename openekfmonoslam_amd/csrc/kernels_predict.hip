@@ -167,7 +167,7 @@ void launch_predict(EkfEngine *e)
 // One thread per work item: pixel prediction, visibility, and (when predicted) the Jacobian blocks.
 __global__ void __launch_bounds__(256)
 k_predict_features(const double *st, CamD cam, const double *feat_pos, const int *feat_type, const int *idx,
-                   int count, int *flag, int *vis, double *uv_tab, double *Hs_tab, double *Hf_tab)
+                   int count, int *flag, int *vis, double *uv_tab, double *Hs_tab, double *Hf_tab, int *vis_full)
 {
     const int w = blockIdx.x * 256 + threadIdx.x;
     if (w >= count) return;
@@ -185,6 +185,9 @@ k_predict_features(const double *st, CamD cam, const double *feat_pos, const int
     const bool ok = predict_pixel(cam, x, Rt, Rinv, fp, type, uv);
     flag[w] = ok ? 1 : 0;
     vis[fi] = ok ? 1 : 0;
+    // the list of unseen features the map management consumes is the one of the step's FULL prediction (EKF.cpp:277-284);
+    // the outlier re-prediction after the first update must not disturb it (its own "unseen" list is discarded, :472-476)
+    if (vis_full) vis_full[fi] = ok ? 1 : 0;
     if (ok) {
         uv_tab[2 * fi] = uv[0];
         uv_tab[2 * fi + 1] = uv[1];
@@ -234,7 +237,8 @@ void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool sta
     k_predict_features<<<nb, 256, 0, e->stream>>>(e->d.state, e->cam, e->d.feat_pos, e->d.feat_type, d_idx, count,
                                                   e->d.work_flag, state_only ? e->d.pred_vis2 : e->d.pred_vis,
                                                   state_only ? e->d.pred_uv2 : e->d.pred_uv,
-                                                  state_only ? nullptr : e->d.Hs, state_only ? nullptr : e->d.Hf);
+                                                  state_only ? nullptr : e->d.Hs, state_only ? nullptr : e->d.Hf,
+                                                  sub ? nullptr : e->d.pred_vis_full);
     k_compact<<<1, 1024, 0, e->stream>>>(e->d.work_flag, d_idx, count, sub ? e->d.plist_sub : e->d.plist,
                                          e->d.counts + (sub ? CNT_NPRED_SUB : CNT_NPRED));
 }
@@ -359,6 +363,26 @@ k_pack_predictions(const int *list, const int *count, const double *uv_tab, cons
     p.imagePos[1] = uv_tab[2 * fi + 1];
     for (int i = 0; i < 4; ++i) p.covarianceMatrix[i] = with_S ? S_tab[4 * fi + i] : 0.0;
     out[k] = p;
+}
+
+__global__ void __launch_bounds__(256)
+k_pack_predictions_n(const int *list, int n, const double *uv_tab, const double *S_tab, EkfPrediction *out)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int fi = list[k];
+    EkfPrediction p;
+    p.featureIndex = fi;
+    p._pad = 0;
+    p.imagePos[0] = uv_tab[2 * fi];
+    p.imagePos[1] = uv_tab[2 * fi + 1];
+    for (int i = 0; i < 4; ++i) p.covarianceMatrix[i] = S_tab[4 * fi + i];
+    out[k] = p;
+}
+
+void launch_pack_predictions(EkfEngine *e, const int *d_list, int n, EkfPrediction *d_out)
+{
+    if (n > 0) k_pack_predictions_n<<<(n + 255) / 256, 256, 0, e->stream>>>(d_list, n, e->d.pred_uv, e->d.pred_S, d_out);
 }
 
 void launch_state_only_predict(EkfEngine *e, EkfPrediction *d_out)

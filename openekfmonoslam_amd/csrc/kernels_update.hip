@@ -397,10 +397,26 @@ k_triinv_level(const double *S, int ldS, int m, int m_pad, double *V, double *W,
 }
 
 // ------------------------------------------------------------------------------------------------- dx = B' z
+// y = inv(L)' z = W z (W upper triangular, fp64): with it dx = (H P)' y = G' inv(S) nu, the gain applied without going
+// through B.  fp32 configuration only: B = inv(L) G comes out of an fp32 MFMA GEMM (accumulation error ~ sqrt(m) eps per
+// element), G is the fp64-accumulated H P rounded once -- measured at N = 1000: the inverse-depth components were
+// 2e-7 ... 1e-6 off (up to 8e-5 of a small rho) through B' z.  One wavefront per row.
+__global__ void __launch_bounds__(256) k_yvec(const double *W, int ldw, int m, const double *z, double *y)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= m) return;
+    const double *w = W + (size_t)i * ldw;
+    double s = 0.0;
+    for (int k = i + lane; k < m; k += 64) s += w[k] * z[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) y[i] = s;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, int ldpart, double *sq_part, double *cam_part,
-             const double *Bc, const T *P, RowMap rm, double *dsave, double *csave, int avg)
+             const double *Bc, const T *P, RowMap rm, double *dsave, double *csave, int avg, const T *G, const double *y)
 {
     __shared__ double sc[64][13]; // fp64 camera columns of a chunk of rows of B
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -431,7 +447,9 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
         if (j < n)
             for (int k = 0; k < cnt; ++k) {
                 const double b = (Bc && j < 13) ? sc[k][j] : (double)B[(size_t)(k0 + k) * ld + j];
-                s += b * z[k0 + k];
+                // feature columns of the fp32 configuration: dx_j = sum_k (H P)_kj y_k (see k_yvec); camera columns: Bc' z (fp64)
+                if (G && j >= 13) s += (double)G[(size_t)(k0 + k) * ld + j] * y[k0 + k];
+                else s += b * z[k0 + k];
                 q += b * b; // (B'B)_jj in fp64, same pass over B: see k_diag_fix
                 if (cam_part) {
 #pragma unroll
@@ -652,10 +670,15 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const bool fix = update_cov && sizeof(T) == 4;
         const int avg = e->p_exact_sym ? 0 : 1; // an AVG downdate only exists on an unsharded engine: every row is local
         const double *Bc = nullptr;
-        if (sizeof(T) == 4) Bc = e->d.Bc; // inv(L) Gc, produced by the right-hand-side blocks of k_chol_step
+        const T *Gy = nullptr;
+        if (sizeof(T) == 4) {
+            Bc = e->d.Bc; // inv(L) Gc, produced by the right-hand-side blocks of k_chol_step
+            k_yvec<<<(m + 3) / 4, 256, 0, s>>>(W, ldw, m, e->d.zvec, e->d.yvec);
+            Gy = G;
+        }
         k_dx_partial<T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld,
                                              fix ? e->d.sq_part : nullptr, fix ? e->d.cam_part : nullptr, Bc, (const T *)e->d.P,
-                                             e->rm, e->d.diag_save, fix ? e->d.cam_save : nullptr, avg);
+                                             e->rm, e->d.diag_save, fix ? e->d.cam_save : nullptr, avg, Gy, e->d.yvec);
         const int nt = max(e->N * 6, 1);
         k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
                                                        e->N, e->d.dx_part, ld, update_cov ? 1 : 0);

@@ -65,6 +65,8 @@ ABI = {
     "ekf_remove_bad_features": (_i, [_vp, C.POINTER(_i)]),
     "ekf_convert_inverse_depth_to_depth": (_i, [_vp, C.POINTER(_i)]),
     "ekf_get_feature_layout": (_i, [_vp, _vp, _vp]),
+    "ekf_keep_step_predictions": (_i, [_vp, _i]),
+    "ekf_get_step_predictions": (_i, [_vp, _vp, C.POINTER(_i)]),
     "ekf_get_camera_covariance": (_i, [_vp, _vp]),
     "ekf_get_unseen_features": (_i, [_vp, _vp, C.POINTER(_i)]),
     "ekf_state_dim": (_i, [_vp]),
@@ -246,6 +248,19 @@ class EkfEngine:
         n = C.c_int(0)
         self._chk(self.L.ekf_get_unseen_features(self.h, _p(idx), C.byref(n)))
         return idx[: n.value].copy()
+
+    def keep_step_predictions(self, on=True):
+        self._chk(self.L.ekf_keep_step_predictions(self.h, 1 if on else 0))
+
+    def step_predictions(self):
+        """predictions of the last step's full prediction, as they were before the updates (drawPrediction's input)"""
+        from .ekftypes import PREDICTION_DTYPE
+
+        n = C.c_int(0)
+        self._chk(self.L.ekf_get_step_predictions(self.h, None, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=PREDICTION_DTYPE)
+        self._chk(self.L.ekf_get_step_predictions(self.h, _p(out), C.byref(n)))
+        return out[: n.value].copy()
 
     # ---- map management
     def reset(self):

@@ -190,7 +190,7 @@ class SyntheticSequence:
 
     def __init__(self, n_features, n_frames, width=640, height=480, seed=None, pixel_sigma=0.5,
                  outlier_fraction=0.05, distractors_per_feature=1.0, max_bit_flips=20,
-                 v=(0.01, 0.0, 0.002), w=(0.0, 0.002, 0.0), depth_range=(2.0, 10.0), margin=12.0):
+                 v=(0.01, 0.0, 0.002), w=(0.0, 0.002, 0.0), depth_range=(2.0, 10.0), margin=12.0, horizon=100):
         self.cam = s3_camera(width, height)
         self.par = s3_params()
         self.n_features = int(n_features)
@@ -201,21 +201,25 @@ class SyntheticSequence:
         v = np.asarray(v, dtype=np.float64)
         w = np.asarray(w, dtype=np.float64)
 
-        # trajectory, integrated exactly like predictState (EKF/StateAndCovariancePrediction.cpp:43-65)
+        # trajectory, integrated exactly like predictState (EKF/StateAndCovariancePrediction.cpp:43-65).
+        # The scene (points, map, and the first k frames) must not depend on how many frames are asked for: the
+        # visibility check below runs over a fixed horizon (a multiple of `horizon` frames that covers the run), so
+        # SyntheticSequence(N, 25).frames == SyntheticSequence(N, 70).frames[:25].
         T = self.n_frames
-        r = np.zeros((T + 1, 3))
-        q = np.zeros((T + 1, 4))
+        TH = horizon * max(1, -(-T // horizon))
+        r = np.zeros((TH + 1, 3))
+        q = np.zeros((TH + 1, 4))
         q[0] = [1, 0, 0, 0]
         dq = angles_to_quat(w)
-        for t in range(T):
+        for t in range(TH):
             r[t + 1] = r[t] + v
             q[t + 1] = quat_mul(q[t], dq)
-        Rs = [quat_to_rot(q[t]) for t in range(T + 1)]
-        self.truth_r, self.truth_q = r, q
+        Rs = [quat_to_rot(q[t]) for t in range(TH + 1)]
+        self.truth_r, self.truth_q = r[: T + 1], q[: T + 1]
 
-        # points: rejection-sample so every point stays inside the frame (with a margin) for the whole run
+        # points: rejection-sample so every point stays inside the frame (with a margin) over the whole horizon
         pts = np.zeros((0, 3))
-        check = sorted(set([0, T // 4, T // 2, (3 * T) // 4, T]))
+        check = sorted(set([0, TH // 4, TH // 2, (3 * TH) // 4, TH]))
         while len(pts) < self.n_features:
             nb = max(256, 2 * (self.n_features - len(pts)))
             uv = np.stack([rng.uniform(margin, width - margin, nb), rng.uniform(margin, height - margin, nb)], -1)

@@ -2,6 +2,8 @@
 //   io_check config <config.yml>                 -> prints the parsed camera / filter / run parameters
 //   io_check png <in.png> <out.png>              -> decodes, prints geometry + byte sum, re-encodes
 //   io_check yaml <out.yml>                      -> writes two frames in the output.yml layout
+//   io_check draw <out.png>                      -> drawPrediction on a synthetic frame (two predictions)
+//   io_check log <out.txt>                       -> State::showDetailed layout
 #include <cstdio>
 #include <string>
 
@@ -48,7 +50,7 @@ int main(int argc, const char *argv[])
         ekf_compat::OutputWriter w;
         if (!w.open(argv[2])) return 1;
         for (int k = 0; k < 2; ++k) {
-            w.beginMap(k == 0 ? "Frame 0" : "Frame 1");
+            w.beginMap(k == 0 ? "Frame 1" : "Frame 2");
             w.comment("");
             w.comment("Running time (microseconds)");
             w.write("Prediction", 123.456 + k);
@@ -63,6 +65,28 @@ int main(int argc, const char *argv[])
             w.endMap();
         }
         w.release();
+        return 0;
+    }
+    if (mode == "draw") {
+        ekf_compat::Image img, out;
+        img.width = 96; img.height = 64; img.channels = 1;
+        img.data.assign((size_t)96 * 64, 40);
+        EkfPrediction p[2];
+        p[0].featureIndex = 0; p[0].imagePos[0] = 30.7; p[0].imagePos[1] = 20.2;
+        p[0].covarianceMatrix[0] = 4.0; p[0].covarianceMatrix[1] = 0.0; p[0].covarianceMatrix[2] = 0.0; p[0].covarianceMatrix[3] = 1.0;
+        p[1].featureIndex = 1; p[1].imagePos[0] = 70.0; p[1].imagePos[1] = 40.0;
+        p[1].covarianceMatrix[0] = 1.0; p[1].covarianceMatrix[1] = 0.0; p[1].covarianceMatrix[2] = 0.0; p[1].covarianceMatrix[3] = 1.0;
+        const int32_t type[2] = {EKF_FEATURE_INVERSE_DEPTH, EKF_FEATURE_DEPTH};
+        ekf_compat::drawPrediction(img, p, 2, type, out);
+        return ekf_compat::writePng(argv[2], out) ? 0 : 1;
+    }
+    if (mode == "log") {
+        std::ofstream f(argv[2]);
+        const double x[13] = {0.5, -0.25, 1.0, 1, 0, 0, 0, 0.01, 0, 0.002, 0, 0.002, 0};
+        const double fp[12] = {0, 0, 0, 0.1, -0.2, 0.5, 1.5, 2.5, 3.5, 0, 0, 0};
+        const int32_t type[2] = {EKF_FEATURE_INVERSE_DEPTH, EKF_FEATURE_DEPTH};
+        const uint32_t tp[2] = {7, 3}, tm[2] = {5, 3};
+        ekf_compat::showDetailed(f, x, 2, fp, type, tp, tm);
         return 0;
     }
     return 2;

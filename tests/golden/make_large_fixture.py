@@ -1,0 +1,67 @@
+"""Mints tests/golden/oracle_n{N}_f{F}_summary.npz: a SUMMARY of the fp64 oracle's state after F frames of the seeded
+synthetic sequence at a map size whose full covariance is too large to commit or to recompute at test time
+(N = 5000: P is 7.2 GB in fp64 and one oracle frame costs ~10 minutes of CPU) -- SURVEY.md 8(c): x13, the feature
+parameters, the 13x13 camera block, trace(P), ||P||_F, max|P|, the diagonal, 64 sampled rows x 64 sampled columns of P, and the
+decision counters of every frame.  Oracle variant: ALGORITHMIC (validated against the LITERAL one at N <= 200 by
+tests/test_oracle_selfcheck.py).  ORACLE-minted (the reference cannot be built in this image).
+
+    python tests/golden/make_large_fixture.py 5000 1
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle_lib as ol  # noqa: E402
+from openekfmonoslam_amd.synth import SyntheticSequence  # noqa: E402
+
+SIZES = {1000: (640, 480), 2000: (1280, 720), 5000: (1920, 1080)}
+
+
+def sample_index(n, count=64, seed=7):
+    rng = np.random.Generator(np.random.PCG64(seed + n))
+    idx = np.sort(rng.choice(np.arange(13, n), size=count - 8, replace=False))
+    return np.concatenate([np.array([0, 3, 6, 7, 9, 10, 11, 12]), idx]).astype(np.int64)
+
+
+def summary(P):
+    n = P.shape[0]
+    idx = sample_index(n)
+    return {"P13": P[:13, :13].copy(), "trace": np.float64(np.trace(P)), "fro": np.float64(np.linalg.norm(P)),
+            "maxabs": np.float64(np.abs(P).max()), "diag": np.diag(P).copy(), "sample_idx": idx,
+            "sample": P[np.ix_(idx, idx)].copy()}
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+    F = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    W, H = SIZES.get(N, (640, 480))
+    seq = SyntheticSequence(N, F, width=W, height=H)
+    o = ol.Oracle(seq.cam, seq.par, N + 8)
+    o.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    out = {"n_features": np.int32(N), "frames": np.int32(F), "width": np.int32(W), "height": np.int32(H),
+           "input_P0_trace": np.float64(np.trace(seq.P0)), "input_P0_fro": np.float64(np.linalg.norm(seq.P0)),
+           "input_kps0_sum": np.float64(seq.frames[0][0]["x"].astype(np.float64).sum())}
+    infos = []
+    for t, (kps, desc) in enumerate(seq.frames):
+        t0 = time.time()
+        i = o.step(kps, desc, ol.ALGORITHMIC)
+        infos.append([i.n_predicted, i.n_matches, i.n_hypotheses, i.n_inliers, i.n_outliers, i.n_rescued, i.status])
+        print(f"frame {t}: {infos[-1]}  {time.time() - t0:.1f} s", flush=True)
+    out["info"] = np.array(infos, dtype=np.int32)
+    out["x13"] = o.x13()
+    out["feature_pos"] = o.feature_pos()
+    for k, v in summary(o.P()).items():
+        out[k] = v
+    path = os.path.join(ROOT, "tests", "golden", f"oracle_n{N}_f{F}_summary.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -9,40 +9,14 @@ from openekfmonoslam_amd.synth import SyntheticSequence
 
 pytestmark = pytest.mark.gpu
 
-F64_TOL = 1e-9   # fp64 engine vs fp64 oracle (different summation orders / FMA only)
-F32_TOL = 1e-5   # the north-star tolerance for the fp32-covariance configuration
+from parity_metric import F32_TOL, F64_TOL  # 1e-5 (fp32 covariance, the north-star tolerance) / 1e-9 (fp64)
 # The angular-velocity block used to be the exception of the fp32 configuration (up to 3e-5 of its own magnitude: it is
 # observed only through cross-covariances).  Since the camera columns of B and the camera rows / diagonal of the downdate
 # are accumulated in fp64 (right-hand sides of k_chol_step, k_dx_partial, k_diag_fix) it meets the same 1e-5 as every other block.
 F32_TOL_OMEGA = F32_TOL
 
 
-def rel_max(a, b):
-    """max |a-b| / max |b| : the norm-wise measure SURVEY.md 8(d) prescribes for P."""
-    b = np.asarray(b)
-    return float(np.abs(np.asarray(a) - b).max() / max(np.abs(b).max(), 1e-300))
-
-
-def rel_fro(a, b):
-    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
-
-
-def state_err(x, fp, xo, fpo):
-    """max relative error over the camera 13-vector and the feature blocks; components smaller than 1e-4 are
-    measured against 1e-4 (an absolute floor of 1e-9 at the 1e-5 tolerance)."""
-    a = np.concatenate([x, fp.reshape(-1)])
-    b = np.concatenate([xo, fpo.reshape(-1)])
-    return float((np.abs(a - b) / np.maximum(np.abs(b), 1e-4)).max())
-
-
-def block_errs(x, fp, xo, fpo):
-    """Block-wise relative errors: camera r, q, v, w (max-norm of the difference over max-norm of the block) and the
-    feature parameters (component-wise, components below 1e-4 measured against 1e-4)."""
-    out = {}
-    for name, sl in (("r", slice(0, 3)), ("q", slice(3, 7)), ("v", slice(7, 10)), ("w", slice(10, 13))):
-        out[name] = float(np.abs(x[sl] - xo[sl]).max() / max(np.abs(xo[sl]).max(), 1e-9))
-    out["features"] = float((np.abs(fp - fpo) / np.maximum(np.abs(fpo), 1e-4)).max())
-    return out
+from parity_metric import block_errs, rel_fro, rel_max, state_err  # noqa: E402,F401
 
 
 @pytest.fixture(scope="module")

@@ -45,11 +45,11 @@ def test_sample_program_runs_a_png_sequence(tmp_path):
         assert feats >= 40 - 5  # map management tops the map up towards MinMatchesPerImage
     text = (outdir / "output.yml").read_text()
     doc = yaml.safe_load(re.sub(r"!!opencv-matrix", "", text.split("\n", 1)[1]))
-    assert sorted(doc) == [f"Frame {k}" for k in range(6)]
+    assert sorted(doc) == [f"Frame {k}" for k in range(1, 7)]  # EKF.cpp:244: the first step is Frame 1
     keys = ["Prediction", "Matching", "Ransac", "totalMatches", "liInliers", "UpdateLI", "RescueOutliers", "hiInliers",
             "UpdateHI", "MapManagement", "StateEstimation", "MapFeaturesInvDepthCount", "MapFeaturesDepthCount",
             "StateCovarianceMatrixEstimation"]
-    last = doc["Frame 5"]
+    last = doc["Frame 6"]
     assert list(last) == keys  # same keys, same order as EKF.cpp:262-628
     assert last["UpdateLI"] > 0 and last["Prediction"] > 0
     x = np.array(last["StateEstimation"]["data"])
@@ -59,3 +59,12 @@ def test_sample_program_runs_a_png_sequence(tmp_path):
     P = np.array(last["StateCovarianceMatrixEstimation"]["data"]).reshape(13, 13)
     np.testing.assert_array_equal(P, P.T)
     assert np.all(np.diag(P) >= 0)
+    # log.txt (EKF.cpp:135, 172-180, 233-236, 246-250, 662-665) and the per-frame prediction images (:294-305)
+    log = (outdir / "log.txt").read_text()
+    assert log.startswith("Random Seed: 0\n\n~~~~~~~~~~~~ STEP 0 ~~~~~~~~~~~~\n")
+    assert log.count("~~~~~~~~~~~~ STEP ") == 7 and log.count("Map Features (") == 7
+    assert "Cantidad de features en el mapa: 40" in log
+    for k in range(1, 7):
+        im = np.asarray(Image.open(str(outdir / f"{k:05d}.png")).convert("RGB")).astype(int)
+        assert im.shape == (seq.cam.pixelsY, seq.cam.pixelsX, 3)
+        assert ((im == [255, 0, 0]).all(axis=2)).sum() > 40 * 9  # a red cross (+ ellipse) per predicted inverse-depth feature

@@ -144,15 +144,55 @@ def test_output_yml_layout(io_check, tmp_path):
     subprocess.check_call([io_check, "yaml", str(path)])
     text = path.read_text()
     assert text.startswith("%YAML:1.0\n")
-    assert '"Frame 0":' in text and "!!opencv-matrix" in text and "# Running time (microseconds)" in text
+    assert '"Frame 1":' in text and "!!opencv-matrix" in text and "# Running time (microseconds)" in text
     body = re.sub(r"!!opencv-matrix", "", text.split("\n", 1)[1])
     doc = yaml.safe_load(body)
-    f1 = doc["Frame 1"]
+    f1 = doc["Frame 2"]
     assert f1["totalMatches"] == 58 and f1["MapFeaturesInvDepthCount"] == 40
     assert f1["Prediction"] == pytest.approx(124.456, abs=1e-12) and f1["UpdateLI"] == 2000.0
     st = f1["StateEstimation"]
     assert (st["rows"], st["cols"], st["dt"]) == (1, 13, "d")
     np.testing.assert_allclose(st["data"], [-(i + 1) / 7.0 for i in range(13)], rtol=1e-15)
-    P = np.array(doc["Frame 0"]["StateCovarianceMatrixEstimation"]["data"]).reshape(13, 13)
+    P = np.array(doc["Frame 1"]["StateCovarianceMatrixEstimation"]["data"]).reshape(13, 13)
     np.testing.assert_allclose(np.diag(P), [1e-6 * (14 * i + 1) for i in range(13)], rtol=1e-15)
     assert all(len(ln) <= 80 for ln in text.splitlines())
+
+
+def test_prediction_image_drawing(io_check, tmp_path):
+    """drawPrediction (Gui/Draw.cpp:266-310): cross + ellipse outline + index per prediction, red for inverse-depth and
+    green for depth features, on a BGR copy of the frame."""
+    from PIL import Image
+
+    path = tmp_path / "pred.png"
+    subprocess.check_call([io_check, "draw", str(path)])
+    im = np.asarray(Image.open(str(path)).convert("RGB")).astype(int)
+    assert im.shape == (64, 96, 3)
+    red, green = np.array([255, 0, 0]), np.array([0, 255, 0])
+    # crosses: centre pixel and arm ends at (int)u, (int)v (the right arm lies under the index label, drawn last)
+    for (x, y), col in (((30, 20), red), ((70, 40), green)):
+        for dx, dy in ((0, 0), (-2, 0), (0, 2), (0, -2)):
+            assert (im[y + dy, x + dx] == col).all(), (x, y, dx, dy)
+    # ellipse of S = diag(4, 1): semi-axes (int)(2 sqrt(4 * 5.9915)) = 9 and (int)(2 sqrt(5.9915)) = 4 around (30, 20)
+    assert (im[20, 30 + 9] == red).all() and (im[20, 30 - 9] == red).all()
+    assert (im[20 + 4, 30] == red).all() and (im[20 - 4, 30] == red).all()
+    assert (im[20, 30 + 11] == 40).all()  # outside the outline: untouched background
+    # circle of S = I: radius 4 around (70, 40), green
+    assert (im[40, 66] == green).all() and (im[44, 70] == green).all()
+    # index labels: yellow text (BGR 0,255,255 = RGB 255,255,0) with a gray shadow
+    assert ((im == [255, 255, 0]).all(axis=2)).sum() > 10 and ((im == [150, 150, 150]).all(axis=2)).sum() > 0
+
+
+def test_log_txt_layout(io_check, tmp_path):
+    """State::showDetailed (State.cpp:229-258, 371-400; MapFeature.cpp:130-145), default ostream formatting."""
+    path = tmp_path / "log.txt"
+    subprocess.check_call([io_check, "log", str(path)])
+    lines = path.read_text().splitlines()
+    assert lines[0] == "Posicion de la camara: 0.5, -0.25, 1"
+    assert lines[1] == "Orientacion(cuaternions): 1, 0, 0, 0"
+    assert lines[2] == "Orientacion en angulos eulerianos: 0, 0, 0"
+    assert lines[3] == "Velocidad lineal (con respecto al mundo): 0.01, 0, 0.002"
+    assert lines[4] == "Velocidad angular (con respecto a la camara): 0, 0.002, 0"
+    assert lines[5] == "Cantidad de features en el mapa: 2"
+    assert lines[6] == "" and lines[7] == "Map Features (2):"
+    assert lines[8] == "0: 0, 0, 0, 0.1, -0.2, 0.5 (5/7)"
+    assert lines[9] == "1: 1.5, 2.5, 3.5 (3/3)"

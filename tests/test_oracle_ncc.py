@@ -109,7 +109,7 @@ def test_step_image_tracks(oracle_lib):
 
 def test_detector_finds_unmasked_corners(oracle_lib):
     """new-feature detection (the build's own corner measure + the reference's zone heuristic)"""
-    seq = SyntheticSequence(40, 2)
+    seq = SyntheticSequence(40, 2, horizon=2)  # points spread over the whole frame: every zone holds structure
     o = _seeded(seq)
     img = seq.render_image(0)
     o.set_image(img)
