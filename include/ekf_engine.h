@@ -44,8 +44,18 @@ typedef struct EkfEngineConfig {
     int32_t precision;     /* EKF_PRECISION_*                                                                */
     int32_t device;        /* HIP device ordinal, or -1 for the current device                               */
     int32_t ransac_batch;  /* hypotheses evaluated per launch (0 = default 32)                               */
-    int32_t flags;         /* reserved, 0                                                                    */
+    int32_t flags;         /* descriptor format, EKF_DESCRIPTOR_* (0 = 32-byte binary / Hamming)                  */
 } EkfEngineConfig;
+
+/* Descriptor format of the map features and keypoints = the two branches of computeDistance
+ * (EKF/Matching.cpp:47-92):
+ *   EKF_DESCRIPTOR_U8_HAMMING      CV_8U, EKF_DESC_BYTES bytes per descriptor, Hamming distance (:76-92; BRIEF-32, the
+ *                                  shipped configuration)
+ *   EKF_DESCRIPTOR_F32_L2(cols)    CV_32F, `cols` floats per descriptor (1..1024), L2 distance (:60-73; SURF / SIFT
+ *                                  style extractors of Cfg/DescriptorExtractorFactory.cpp)
+ * Every `desc32` argument of this ABI is a row-major matrix with ekf_descriptor_bytes(e) bytes per row. */
+#define EKF_DESCRIPTOR_U8_HAMMING 0
+#define EKF_DESCRIPTOR_F32_L2(cols) (1 | ((cols) << 8))
 
 /* Per-step counters; same layout as the oracle's OrcStepInfo. */
 typedef struct EkfStepInfo {
@@ -97,6 +107,7 @@ int ekf_get_state(EkfEngine *e, double x13[13], double *feature_pos, double *P);
  * descriptors (32 bytes each) and MapFeature::timesPredicted / timesMatched.  Any pointer may be NULL. */
 int ekf_get_map_features(EkfEngine *e, uint8_t *desc32, uint32_t *times_predicted, uint32_t *times_matched);
 int ekf_state_dim(const EkfEngine *e);
+int ekf_descriptor_bytes(const EkfEngine *e); /* bytes per descriptor row (32, or 4 * cols for CV_32F) */
 int ekf_num_features(const EkfEngine *e);
 
 /* -- map management: the state dimension changes, P is edited in place on the device ------ */

@@ -109,6 +109,12 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     e->par = ParD{p.linearAccelSD, p.angularAccelSD, p.matchingCompCoefSecondBestVSFirst,
                   p.ransacThresholdPredictDistance, p.ransacAllInliersProbability, p.ransacChi2Threshold};
     e->f32 = cfg->precision == EKF_PRECISION_F32;
+    if ((cfg->flags & 0xff) == 1) { // EKF_DESCRIPTOR_F32_L2(cols)
+        const int cols = (cfg->flags >> 8) & 0xffff;
+        if (cols < 1 || cols > 1024) { delete e; return EKF_ERR_INVALID_ARG; }
+        e->desc_f32 = true;
+        e->desc_bytes = 4 * cols;
+    } else if ((cfg->flags & 0xff) != 0) { delete e; return EKF_ERR_INVALID_ARG; }
     e->shard_rank = rank;
     e->shard_world = world;
     e->cap = cfg->max_features;
@@ -138,7 +144,7 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     ALLOC(d.feat_pos, 6 * cap);
     ALLOC(d.feat_type, cap);
     ALLOC(d.feat_covpos, cap);
-    ALLOC(d.feat_desc, EKF_DESC_BYTES * cap);
+    ALLOC(d.feat_desc, (size_t)e->desc_bytes * cap);
     ALLOC(d.feat_times_predicted, cap);
     ALLOC(d.feat_times_matched, cap);
     {
@@ -173,7 +179,7 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     ALLOC(d.plist_sub, cap);
     ALLOC(d.counts, CNT_COUNT);
     ALLOC(d.kps, (size_t)e->kcap);
-    ALLOC(d.kdesc, (size_t)e->kcap * EKF_DESC_BYTES);
+    ALLOC(d.kdesc, (size_t)e->kcap * e->desc_bytes);
     ALLOC(d.mt_valid, cap);
     ALLOC(d.mt_kp, cap);
     ALLOC(d.mt_dist, cap);
@@ -298,13 +304,14 @@ int ekf_get_map_features(EkfEngine *e, uint8_t *desc32, uint32_t *times_predicte
     HIPCHK(hipStreamSynchronize(e->stream));
     const size_t N = (size_t)e->N;
     if (N == 0) return EKF_OK;
-    if (desc32) HIPCHK(hipMemcpy(desc32, e->d.feat_desc, N * EKF_DESC_BYTES, hipMemcpyDeviceToHost));
+    if (desc32) HIPCHK(hipMemcpy(desc32, e->d.feat_desc, N * e->desc_bytes, hipMemcpyDeviceToHost));
     if (times_predicted) HIPCHK(hipMemcpy(times_predicted, e->d.feat_times_predicted, N * 4, hipMemcpyDeviceToHost));
     if (times_matched) HIPCHK(hipMemcpy(times_matched, e->d.feat_times_matched, N * 4, hipMemcpyDeviceToHost));
     return EKF_OK;
 }
 
 int ekf_state_dim(const EkfEngine *e) { return e ? e->n : 0; }
+int ekf_descriptor_bytes(const EkfEngine *e) { return e ? e->desc_bytes : 0; }
 int ekf_num_features(const EkfEngine *e) { return e ? e->N : 0; }
 
 int ekf_synchronize(EkfEngine *e)
@@ -348,9 +355,9 @@ int ekf_set_state(EkfEngine *e, const double x13[13], int n_features, const doub
         HIPCHK(hipMemcpy(e->d.feat_type, type.data(), (size_t)n_features * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d.feat_covpos, covpos.data(), (size_t)n_features * sizeof(int), hipMemcpyHostToDevice));
         if (desc32)
-            HIPCHK(hipMemcpy(e->d.feat_desc, desc32, (size_t)n_features * EKF_DESC_BYTES, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d.feat_desc, desc32, (size_t)n_features * e->desc_bytes, hipMemcpyHostToDevice));
         else
-            HIPCHK(hipMemset(e->d.feat_desc, 0, (size_t)n_features * EKF_DESC_BYTES));
+            HIPCHK(hipMemset(e->d.feat_desc, 0, (size_t)n_features * e->desc_bytes));
     }
     e->N = n_features;
     e->n = n;
@@ -523,9 +530,9 @@ int ekf_add_features(EkfEngine *e, const double *uv, const uint8_t *desc32, int 
     HIPCHK(hipSetDevice(e->device));
     double *d_uv = e->d.mm_scratch, *d_Jpo = d_uv + 2 * (size_t)e->cap, *d_Jhr = d_Jpo + 42 * (size_t)count;
     HIPCHK(hipMemcpyAsync(d_uv, uv, (size_t)2 * count * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    uint8_t *dd = e->d.feat_desc + (size_t)e->N * EKF_DESC_BYTES;
-    if (desc32) HIPCHK(hipMemcpyAsync(dd, desc32, (size_t)count * EKF_DESC_BYTES, hipMemcpyHostToDevice, e->stream));
-    else HIPCHK(hipMemsetAsync(dd, 0, (size_t)count * EKF_DESC_BYTES, e->stream));
+    uint8_t *dd = e->d.feat_desc + (size_t)e->N * e->desc_bytes;
+    if (desc32) HIPCHK(hipMemcpyAsync(dd, desc32, (size_t)count * e->desc_bytes, hipMemcpyHostToDevice, e->stream));
+    else HIPCHK(hipMemsetAsync(dd, 0, (size_t)count * e->desc_bytes, e->stream));
     HIPCHK(hipMemsetAsync(e->d.feat_times_predicted + e->N, 0, (size_t)count * 4, e->stream));
     HIPCHK(hipMemsetAsync(e->d.feat_times_matched + e->N, 0, (size_t)count * 4, e->stream));
     launch_add_features(e, d_uv, count, d_Jpo, d_Jhr);
@@ -559,7 +566,7 @@ static int compact_map(EkfEngine *e, const std::vector<uint8_t> &drop_feature, c
     launch_compact_P(e, n_new, e->d.mm_index);
     // SoA arrays: small, compacted through the host
     std::vector<double> pos(6 * (size_t)N);
-    std::vector<uint8_t> desc((size_t)N * EKF_DESC_BYTES);
+    std::vector<uint8_t> desc((size_t)N * e->desc_bytes);
     std::vector<unsigned> tp(N), tm(N);
     std::vector<uint8_t> tmpl((size_t)N * 363);
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -573,7 +580,7 @@ static int compact_map(EkfEngine *e, const std::vector<uint8_t> &drop_feature, c
     for (int i = 0; i < N; ++i) {
         if (drop_feature[i]) continue;
         std::memmove(&pos[6 * (size_t)w], &pos[6 * (size_t)i], 6 * sizeof(double));
-        std::memmove(&desc[(size_t)w * EKF_DESC_BYTES], &desc[(size_t)i * EKF_DESC_BYTES], EKF_DESC_BYTES);
+        std::memmove(&desc[(size_t)w * e->desc_bytes], &desc[(size_t)i * e->desc_bytes], e->desc_bytes);
         std::memmove(&tmpl[(size_t)w * 363], &tmpl[(size_t)i * 363], 363);
         tp[w] = tp[i];
         tm[w] = tm[i];
@@ -590,7 +597,7 @@ static int compact_map(EkfEngine *e, const std::vector<uint8_t> &drop_feature, c
     }
     if (w > 0) {
         HIPCHK(hipMemcpy(e->d.feat_pos, pos.data(), (size_t)6 * w * 8, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(e->d.feat_desc, desc.data(), (size_t)w * EKF_DESC_BYTES, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d.feat_desc, desc.data(), (size_t)w * e->desc_bytes, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d.tmpl, tmpl.data(), (size_t)w * 363, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d.feat_times_predicted, tp.data(), (size_t)w * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d.feat_times_matched, tm.data(), (size_t)w * 4, hipMemcpyHostToDevice));
@@ -820,7 +827,7 @@ static int upload_keypoints(EkfEngine *e, const EkfKeypoint *kps, const uint8_t 
     if (n_kp > e->kcap) return EKF_ERR_CAPACITY;
     if (n_kp > 0) {
         HIPCHK(hipMemcpyAsync(e->d.kps, kps, (size_t)n_kp * sizeof(EkfKeypoint), hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipMemcpyAsync(e->d.kdesc, desc32, (size_t)n_kp * EKF_DESC_BYTES, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->d.kdesc, desc32, (size_t)n_kp * e->desc_bytes, hipMemcpyHostToDevice, e->stream));
     }
     e->n_kp = n_kp;
     return EKF_OK;
@@ -1122,9 +1129,9 @@ int ekf_frames_upload(EkfEngine *e, int n_frames, const int32_t *kp_counts, cons
     e->frames.n = n_frames;
     if (total == 0) return EKF_OK;
     HIPCHK(hipMalloc((void **)&e->frames.kps, total * sizeof(EkfKeypoint)));
-    HIPCHK(hipMalloc((void **)&e->frames.desc, total * EKF_DESC_BYTES));
+    HIPCHK(hipMalloc((void **)&e->frames.desc, total * e->desc_bytes));
     HIPCHK(hipMemcpy(e->frames.kps, kps_concat, total * sizeof(EkfKeypoint), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->frames.desc, desc_concat, total * EKF_DESC_BYTES, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->frames.desc, desc_concat, total * e->desc_bytes, hipMemcpyHostToDevice));
     return EKF_OK;
 }
 
@@ -1133,7 +1140,7 @@ int ekf_step_frame(EkfEngine *e, int frame, EkfStepInfo *info)
     if (!e || frame < 0 || frame >= e->frames.n) return EKF_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(e->device));
     const size_t off = (size_t)e->frames.offset[frame];
-    return step_dev(e, e->frames.kps + off, e->frames.desc + off * EKF_DESC_BYTES, e->frames.count[frame], info);
+    return step_dev(e, e->frames.kps + off, e->frames.desc + off * e->desc_bytes, e->frames.count[frame], info);
 }
 
 // ------------------------------------------------------------------------------------- NCC matcher (mode B)

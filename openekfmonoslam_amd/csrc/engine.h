@@ -158,6 +158,8 @@ struct EkfEngine {
     int ldP = 0, ldS = 0, ldW = 0;
     int N = 0, n = 0;
     bool f32 = false;
+    int desc_bytes = EKF_DESC_BYTES; // bytes per descriptor row
+    bool desc_f32 = false;           // CV_32F descriptors / L2 distance (Matching.cpp:60-73) instead of CV_8U / Hamming
     // row sharding: world == 1 means the whole matrix lives here
     int shard_rank = 0, shard_world = 1;
     int p_rows_cap = 0;                  // rows allocated for P

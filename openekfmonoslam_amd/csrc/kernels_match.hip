@@ -1,7 +1,8 @@
 // kernels_match.hip -- A5, the stage of matchPredictedFeatures downstream of the detector
 // (EKF/Matching.cpp:217-262): per prediction, gate the frame's keypoints with the uncertainty ellipse
-// (Core/EKFMath.cpp:271-351), Hamming distance on the 32-byte descriptors (Matching.cpp:74-90) and the reference's
-// 2-element "best" list (Matching.cpp:116-144, 169-175).  Integer/byte work, a few KB per block, all L2-resident:
+// (Core/EKFMath.cpp:271-351), descriptor distance -- both branches of computeDistance: Hamming on 32-byte CV_8U
+// descriptors (Matching.cpp:76-92) or L2 on CV_32F descriptors (:60-73) -- and the reference's 2-element "best" list
+// (Matching.cpp:116-144, 169-175).  Integer/byte work, a few KB per block, all L2-resident:
 // one workgroup per prediction, keypoints strided over the lanes, candidates replayed in keypoint order so the
 // order-dependent list logic gives the reference's answer.
 #include "engine.h"
@@ -12,15 +13,17 @@ namespace ekf {
 __global__ void __launch_bounds__(256)
 k_match(const int *plist, const double *uv_tab, const double *S_tab, const uint8_t *feat_desc,
         const EkfKeypoint *kps, const uint8_t *kdesc, int n_kp, double coef, int *mt_valid, int *mt_kp,
-        float *mt_dist)
+        float *mt_dist, int desc_bytes, int desc_f32)
 {
     __shared__ Gate g;
-    __shared__ uint32_t qd[8];
+    __shared__ uint32_t qd[1024]; // the map feature's descriptor: 8 words (CV_8U) or up to 1024 floats (CV_32F)
     __shared__ int c_idx[256];
-    __shared__ int c_dist[256];
+    __shared__ double c_dist[256]; // computeDistance returns double (an integer value for Hamming)
     __shared__ int wave_cnt[4];
-    // list state (thread 0)
-    __shared__ int s_list_n, s_front, s_dfront, s_dback, s_min;
+    // list state (thread 0); DMatch::distance is a float (Matching.cpp:133)
+    __shared__ int s_list_n, s_front;
+    __shared__ float s_dfront, s_dback;
+    __shared__ double s_min;
 
     const int k = blockIdx.x, tid = threadIdx.x;
     const int fi = plist[k];
@@ -30,25 +33,35 @@ k_match(const int *plist, const double *uv_tab, const double *S_tab, const uint8
         ellipse_from_cov(S_tab + 4 * fi, axes, &angle);
         const int aw = (int)rintf(axes[0]), ah = (int)rintf(axes[1]); // cv::Size(Size2f): round half to even
         gate_from_ellipse((float)uv_tab[2 * fi], (float)uv_tab[2 * fi + 1], aw, ah, angle, &g);
-        s_list_n = 0; s_front = -1; s_dfront = 0; s_dback = 0; s_min = -1;
+        s_list_n = 0; s_front = -1; s_dfront = 0.f; s_dback = 0.f; s_min = -1.0;
     }
-    if (tid < 8) qd[tid] = ((const uint32_t *)(feat_desc + (size_t)fi * EKF_DESC_BYTES))[tid];
+    const int words = desc_bytes / 4;
+    for (int w = tid; w < words; w += 256) qd[w] = ((const uint32_t *)(feat_desc + (size_t)fi * desc_bytes))[w];
     __syncthreads();
 
     const int lane = tid & 63, wv = tid >> 6;
     for (int base = 0; base < n_kp; base += 256) {
         const int j = base + tid;
         bool inside = false;
-        int dist = 0;
+        double dist = 0.0;
         if (j < n_kp) {
             const double px = (double)kps[j].x, py = (double)kps[j].y;
             const double a1x = px - g.f1x, a1y = py - g.f1y, a2x = px - g.f2x, a2y = py - g.f2y;
             const double ns = sqrt(a1x * a1x + a1y * a1y) + sqrt(a2x * a2x + a2y * a2y);
             inside = ns <= g.two_major;
             if (inside) {
-                const uint32_t *cd = (const uint32_t *)(kdesc + (size_t)j * EKF_DESC_BYTES);
-#pragma unroll
-                for (int w = 0; w < 8; ++w) dist += __popc(cd[w] ^ qd[w]);
+                const uint32_t *cd = (const uint32_t *)(kdesc + (size_t)j * desc_bytes);
+                if (desc_f32) { // Matching.cpp:60-73: float difference, float square, double sum in column order, sqrt
+                    for (int w = 0; w < words; ++w) {
+                        const float subs = __uint_as_float(qd[w]) - __uint_as_float(cd[w]);
+                        dist += (double)(subs * subs);
+                    }
+                    dist = sqrt(dist);
+                } else {
+                    int d = 0;
+                    for (int w = 0; w < words; ++w) d += __popc(cd[w] ^ qd[w]);
+                    dist = (double)d;
+                }
             }
         }
         // ordered compaction of this chunk's candidates
@@ -67,12 +80,12 @@ k_match(const int *plist, const double *uv_tab, const double *S_tab, const uint8
             const int nc = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
             // findBestNMatches, nBest = 2: push_front when (dist < min) or fewer than two entries
             for (int c = 0; c < nc; ++c) {
-                const int dc = c_dist[c];
-                if ((s_min >= 0 && dc < s_min) || s_list_n < 2) {
-                    s_min = s_min < 0 ? dc : min(s_min, dc);
+                const double dc = c_dist[c];
+                if (dc < s_min || s_list_n < 2) { // minDistance starts at -1: the first two candidates always enter (:130)
+                    s_min = s_min < 0 ? dc : fmin(s_min, dc);
                     s_dback = s_dfront;
                     s_front = c_idx[c];
-                    s_dfront = dc;
+                    s_dfront = (float)dc;
                     if (s_list_n < 2) ++s_list_n;
                 }
             }
@@ -81,10 +94,10 @@ k_match(const int *plist, const double *uv_tab, const double *S_tab, const uint8
     }
     if (tid == 0) {
         // matchICDescriptors: accept a lone candidate, or front <= back * coef (distances are floats in DMatch)
-        const bool ok = s_list_n == 1 || (s_list_n >= 2 && (double)(float)s_dfront <= (double)(float)s_dback * coef);
+        const bool ok = s_list_n == 1 || (s_list_n >= 2 && (double)s_dfront <= (double)s_dback * coef);
         mt_valid[k] = ok ? 1 : 0;
         mt_kp[k] = ok ? s_front : -1;
-        mt_dist[k] = (float)s_dfront;
+        mt_dist[k] = s_dfront;
     }
 }
 
@@ -132,7 +145,7 @@ void launch_match(EkfEngine *e, int n_pred, int n_kp)
     }
     k_match<<<n_pred, 256, 0, e->stream>>>(e->d.plist, e->d.pred_uv, e->d.pred_S, e->d.feat_desc, e->d.kps,
                                            e->d.kdesc, n_kp, e->cfg.par.matchingCompCoefSecondBestVSFirst,
-                                           e->d.mt_valid, e->d.mt_kp, e->d.mt_dist);
+                                           e->d.mt_valid, e->d.mt_kp, e->d.mt_dist, e->desc_bytes, e->desc_f32 ? 1 : 0);
     k_match_compact<<<1, 1024, 0, e->stream>>>(e->d.plist, n_pred, e->d.mt_valid, e->d.mt_kp, e->d.mt_dist,
                                                e->d.kps, 0, e->d.matches, e->d.counts + CNT_NMATCH);
 }
@@ -170,7 +183,7 @@ void launch_match_index(EkfEngine *e, int M)
 // the original order (1PointRansac.cpp:213-227, EKF.cpp:110-117).
 __global__ void __launch_bounds__(1024)
 k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0, int *cnt1, const uint8_t *kdesc,
-            uint8_t *feat_desc, unsigned *times_matched)
+            uint8_t *feat_desc, unsigned *times_matched, int desc_bytes)
 {
     __shared__ int part[1024];
     const int tid = threadIdx.x;
@@ -200,12 +213,11 @@ k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, Ek
     const int count = part[1023];
     for (int i = tid; i < count; i += 1024) {
         const int fi = dst1[i].featureIndex, kp = dst1[i].keypointIndex;
-        times_matched[fi]++;
+        atomicAdd(&times_matched[fi], 1u); // one match per feature on every engine path; atomic all the same
         if (kp >= 0 && kdesc) {
-            const uint32_t *sd = (const uint32_t *)(kdesc + (size_t)kp * EKF_DESC_BYTES);
-            uint32_t *dd = (uint32_t *)(feat_desc + (size_t)fi * EKF_DESC_BYTES);
-#pragma unroll
-            for (int w = 0; w < 8; ++w) dd[w] = sd[w];
+            const uint32_t *sd = (const uint32_t *)(kdesc + (size_t)kp * desc_bytes);
+            uint32_t *dd = (uint32_t *)(feat_desc + (size_t)fi * desc_bytes);
+            for (int w = 0; w < desc_bytes / 4; ++w) dd[w] = sd[w];
         }
     }
 }
@@ -218,7 +230,7 @@ void launch_partition(EkfEngine *e, const EkfMatch *src, int M, const uint8_t *f
         return;
     }
     k_partition<<<1, 1024, 0, e->stream>>>(src, M, flags, dst1, dst0, cnt1, d_kdesc, e->d.feat_desc,
-                                           map_update ? e->d.feat_times_matched : nullptr);
+                                           map_update ? e->d.feat_times_matched : nullptr, e->desc_bytes);
 }
 
 

@@ -70,6 +70,7 @@ ABI = {
     "ekf_get_camera_covariance": (_i, [_vp, _vp]),
     "ekf_get_unseen_features": (_i, [_vp, _vp, C.POINTER(_i)]),
     "ekf_state_dim": (_i, [_vp]),
+    "ekf_descriptor_bytes": (_i, [_vp]),
     "ekf_num_features": (_i, [_vp]),
     "ekf_predict": (_i, [_vp]),
     "ekf_predict_measurements": (_i, [_vp, _vp, _i, _vp, C.POINTER(_i), _vp, _vp]),
@@ -155,14 +156,16 @@ class EkfEngine:
     """One device-resident filter (state, covariance, map, per-frame tables) on one MI355X."""
 
     def __init__(self, cam, par, max_features, max_keypoints=0, precision=PRECISION_F64, device=-1, ransac_batch=0,
-                 shard=None):
+                 shard=None, descriptor_cols_f32=0):
         """shard = (rank, world) creates one rank of a row-sharded filter; install the exchange with
-        set_exchange before the first prediction."""
+        set_exchange before the first prediction.  descriptor_cols_f32 > 0: CV_32F descriptors of that many floats
+        matched by L2 distance (EKF_DESCRIPTOR_F32_L2) instead of 32-byte binary descriptors / Hamming."""
         self.L = load_library()
         cfg = EkfEngineConfig()
         cfg.cam, cfg.par = cam, par
         cfg.max_features, cfg.max_keypoints = int(max_features), int(max_keypoints)
-        cfg.precision, cfg.device, cfg.ransac_batch, cfg.flags = int(precision), int(device), int(ransac_batch), 0
+        cfg.precision, cfg.device, cfg.ransac_batch = int(precision), int(device), int(ransac_batch)
+        cfg.flags = (1 | (int(descriptor_cols_f32) << 8)) if descriptor_cols_f32 else 0
         h = _vp()
         if shard is None:
             rc = self.L.ekf_engine_create(C.byref(cfg), C.byref(h))
@@ -174,6 +177,15 @@ class EkfEngine:
         self.h = h
         self.cap = int(max_features)
         self.precision = precision
+        self.desc_bytes = self.L.ekf_descriptor_bytes(self.h)
+        self.desc_dtype = np.float32 if descriptor_cols_f32 else np.uint8
+
+    def _desc(self, desc):
+        """descriptor matrix -> contiguous bytes, one row of desc_bytes per descriptor"""
+        if desc is None:
+            return None
+        d = np.ascontiguousarray(desc, dtype=self.desc_dtype)
+        return d.view(np.uint8).reshape(-1, self.desc_bytes)
 
     def set_exchange(self, fn):
         """fn(what, device_base, row_bytes, row_begin[world+1], world, rank) -> 0 on success; called by the engine
@@ -225,7 +237,7 @@ class EkfEngine:
         x13 = np.ascontiguousarray(x13, dtype=np.float64)
         fp = np.ascontiguousarray(feature_pos, dtype=np.float64).reshape(-1, 6)
         ft = None if feature_type is None else np.ascontiguousarray(feature_type, dtype=np.int32)
-        d = None if desc is None else np.ascontiguousarray(desc, dtype=np.uint8)
+        d = self._desc(desc)
         Pm = None if P is None else np.ascontiguousarray(P, dtype=np.float64)
         self._chk(self.L.ekf_set_state(self.h, _p(x13), len(fp), _p(fp), _p(ft), _p(d), _p(Pm)))
 
@@ -268,7 +280,7 @@ class EkfEngine:
 
     def add_features(self, uv, desc=None):
         uv = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
-        d = None if desc is None else np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, DESC_BYTES)
+        d = self._desc(desc)
         self._chk(self.L.ekf_add_features(self.h, _p(uv), _p(d), len(uv)))
 
     def remove_features(self, idx):
@@ -294,11 +306,11 @@ class EkfEngine:
     def get_map_features(self):
         """(descriptors [N,32] u8, timesPredicted [N] u32, timesMatched [N] u32)."""
         N = max(self.N, 1)
-        d = np.zeros((N, DESC_BYTES), dtype=np.uint8)
+        d = np.zeros((N, self.desc_bytes), dtype=np.uint8)
         tp = np.zeros(N, dtype=np.uint32)
         tm = np.zeros(N, dtype=np.uint32)
         self._chk(self.L.ekf_get_map_features(self.h, _p(d), _p(tp), _p(tm)))
-        return d[: self.N], tp[: self.N], tm[: self.N]
+        return d[: self.N].view(self.desc_dtype), tp[: self.N], tm[: self.N]
 
     # ---- stages
     def predict(self):
@@ -323,7 +335,7 @@ class EkfEngine:
 
     def match(self, kps, desc):
         kps = np.ascontiguousarray(kps, dtype=KEYPOINT_DTYPE)
-        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, DESC_BYTES)
+        desc = self._desc(desc)
         out = np.zeros(max(self.N, 1), dtype=MATCH_DTYPE)
         k = _i(0)
         self._chk(self.L.ekf_match(self.h, _p(kps), _p(desc), len(kps), _p(out), C.byref(k)))
@@ -352,7 +364,7 @@ class EkfEngine:
 
     def step(self, kps, desc):
         kps = np.ascontiguousarray(kps, dtype=KEYPOINT_DTYPE)
-        desc = np.ascontiguousarray(desc, dtype=np.uint8)
+        desc = self._desc(desc)
         info = EkfStepInfo()
         self._chk(self.L.ekf_step(self.h, _p(kps), _p(desc), len(kps), C.byref(info)))
         return info
@@ -361,7 +373,7 @@ class EkfEngine:
     def upload_frames(self, frames):
         counts = np.array([len(k) for k, _ in frames], dtype=np.int32)
         kps = np.ascontiguousarray(np.concatenate([k for k, _ in frames]), dtype=KEYPOINT_DTYPE)
-        desc = np.ascontiguousarray(np.concatenate([d for _, d in frames]), dtype=np.uint8)
+        desc = self._desc(np.concatenate([d for _, d in frames]))
         self._chk(self.L.ekf_frames_upload(self.h, len(frames), _p(counts), _p(kps), _p(desc)))
 
     def step_frame(self, i):

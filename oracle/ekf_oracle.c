@@ -34,6 +34,8 @@ struct OrcFilter {
     int32_t *ftype;
     int32_t *fcovpos;
     uint8_t *fdesc;
+    int desc_bytes; /* bytes per descriptor row: 32 (CV_8U, Hamming) or 4 * cols (CV_32F, L2) */
+    int desc_f32;
     uint32_t *ftimes_predicted;
     uint32_t *ftimes_matched;
     double *P;     /* n x n, leading dimension n */
@@ -215,6 +217,8 @@ OrcFilter *orc_create(const EkfCamera *cam, const EkfParams *par, int max_featur
     f->fpos = (double *)calloc((size_t)max_features * 6 + 6, sizeof(double));
     f->ftype = (int32_t *)calloc((size_t)max_features + 1, sizeof(int32_t));
     f->fcovpos = (int32_t *)calloc((size_t)max_features + 1, sizeof(int32_t));
+    f->desc_bytes = EKF_DESC_BYTES;
+    f->desc_f32 = 0;
     f->fdesc = (uint8_t *)calloc((size_t)max_features * EKF_DESC_BYTES + EKF_DESC_BYTES, 1);
     f->ftimes_predicted = (uint32_t *)calloc((size_t)max_features + 1, sizeof(uint32_t));
     f->ftimes_matched = (uint32_t *)calloc((size_t)max_features + 1, sizeof(uint32_t));
@@ -224,6 +228,26 @@ OrcFilter *orc_create(const EkfCamera *cam, const EkfParams *par, int max_featur
     if (!f->fpos || !f->ftype || !f->fcovpos || !f->fdesc || !f->P) { orc_destroy(f); return NULL; }
     orc_reset(f);
     return f;
+}
+
+/* descriptor format = the branch of computeDistance (EKF/Matching.cpp:47-92) the matcher takes; flags as
+ * EkfEngineConfig.flags (EKF_DESCRIPTOR_*).  Call before any descriptor is stored. */
+int orc_set_descriptor_format(OrcFilter *f, int flags)
+{
+    int bytes = EKF_DESC_BYTES, f32 = 0;
+    if ((flags & 0xff) == 1) {
+        int cols = (flags >> 8) & 0xffff;
+        if (cols < 1 || cols > 1024) return EKF_ERR_INVALID_ARG;
+        bytes = 4 * cols;
+        f32 = 1;
+    } else if ((flags & 0xff) != 0) return EKF_ERR_INVALID_ARG;
+    uint8_t *d = (uint8_t *)calloc((size_t)(f->cap + 1) * bytes, 1);
+    if (!d) return EKF_ERR_CAPACITY;
+    free(f->fdesc);
+    f->fdesc = d;
+    f->desc_bytes = bytes;
+    f->desc_f32 = f32;
+    return EKF_OK;
 }
 
 void orc_destroy(OrcFilter *f)
@@ -254,6 +278,7 @@ void orc_reset(OrcFilter *f)
 }
 
 int orc_state_dim(const OrcFilter *f) { return f->n; }
+int orc_descriptor_bytes(const OrcFilter *f) { return f->desc_bytes; }
 int orc_num_features(const OrcFilter *f) { return f->N; }
 double *orc_x13(OrcFilter *f) { return f->x; }
 double *orc_rotation(OrcFilter *f) { return f->R; }
@@ -280,8 +305,8 @@ int orc_set_state(OrcFilter *f, const double x13[13], int n_features, const doub
         memcpy(&f->fpos[6 * i], &feature_pos[6 * i], 6 * sizeof(double));
         pos += feat_dim(t);
     }
-    if (desc32) memcpy(f->fdesc, desc32, (size_t)n_features * EKF_DESC_BYTES);
-    else memset(f->fdesc, 0, (size_t)n_features * EKF_DESC_BYTES);
+    if (desc32) memcpy(f->fdesc, desc32, (size_t)n_features * f->desc_bytes);
+    else memset(f->fdesc, 0, (size_t)n_features * f->desc_bytes);
     memset(f->ftimes_predicted, 0, (size_t)n_features * sizeof(uint32_t));
     memset(f->ftimes_matched, 0, (size_t)n_features * sizeof(uint32_t));
     f->N = n_features;
@@ -408,8 +433,8 @@ int orc_add_feature(OrcFilter *f, const double uv[2], const uint8_t *desc32)
     memcpy(&f->fpos[6 * idx], fp, sizeof(fp));
     f->ftype[idx] = EKF_FEATURE_INVERSE_DEPTH;
     f->fcovpos[idx] = n0;
-    if (desc32) memcpy(&f->fdesc[(size_t)idx * EKF_DESC_BYTES], desc32, EKF_DESC_BYTES);
-    else memset(&f->fdesc[(size_t)idx * EKF_DESC_BYTES], 0, EKF_DESC_BYTES);
+    if (desc32) memcpy(&f->fdesc[(size_t)idx * f->desc_bytes], desc32, (size_t)f->desc_bytes);
+    else memset(&f->fdesc[(size_t)idx * f->desc_bytes], 0, (size_t)f->desc_bytes);
     f->N = idx + 1;
 
     double Jpo[42] = {0}, Jhr[18] = {0};
@@ -484,7 +509,7 @@ int orc_remove_features(OrcFilter *f, const int32_t *idx, int count)
         if (w != i) {
             memcpy(&f->fpos[6 * w], &f->fpos[6 * i], 6 * sizeof(double));
             f->ftype[w] = f->ftype[i];
-            memcpy(&f->fdesc[(size_t)w * EKF_DESC_BYTES], &f->fdesc[(size_t)i * EKF_DESC_BYTES], EKF_DESC_BYTES);
+            memcpy(&f->fdesc[(size_t)w * f->desc_bytes], &f->fdesc[(size_t)i * f->desc_bytes], (size_t)f->desc_bytes);
             f->ftimes_predicted[w] = f->ftimes_predicted[i];
             f->ftimes_matched[w] = f->ftimes_matched[i];
         }
@@ -1053,6 +1078,18 @@ static double hamming32(const uint8_t *a, const uint8_t *b)
     return (double)d;
 }
 
+/* computeDistance, CV_32F branch: EKF/Matching.cpp:60-73 -- float difference, float square, double sum, sqrt */
+static double l2_f32(const uint8_t *a, const uint8_t *b, int cols)
+{
+    const float *x = (const float *)a, *y = (const float *)b;
+    double distance = 0.0f;
+    for (int j = 0; j < cols; ++j) {
+        float subs = x[j] - y[j];
+        distance += subs * subs;
+    }
+    return sqrt(distance);
+}
+
 /* EKF/Matching.cpp:217-262 (gate), :148-177 (matchICDescriptors), :116-144 (findBestNMatches) */
 int orc_match(const OrcFilter *f, const EkfPrediction *preds, int n_pred, const EkfKeypoint *kps,
               const uint8_t *desc32, int n_kp, EkfMatch *out)
@@ -1067,14 +1104,15 @@ int orc_match(const OrcFilter *f, const EkfPrediction *preds, int n_pred, const 
         /* cv::Size(cv::Size2f): saturate_cast<int>(float) = round half to even */
         int aw = (int)lrintf(axes[0]), ah = (int)lrintf(axes[1]);
         float cx = (float)preds[i].imagePos[0], cy = (float)preds[i].imagePos[1]; /* Point2d -> Point2f */
-        const uint8_t *qd = &f->fdesc[(size_t)fi * EKF_DESC_BYTES];
+        const uint8_t *qd = &f->fdesc[(size_t)fi * f->desc_bytes];
         /* findBestNMatches with nBest = 2: a 2-element list, newest in front */
         int list_n = 0, idx_front = -1, idx_back = -1;
         float d_front = 0.f, d_back = 0.f;
         double min_distance = -1.0;
         for (int j = 0; j < n_kp; ++j) {
             if (!orc_point_in_ellipse(kps[j].x, kps[j].y, cx, cy, aw, ah, angle)) continue;
-            double dist = hamming32(qd, &desc32[(size_t)j * EKF_DESC_BYTES]);
+            const uint8_t *cd = &desc32[(size_t)j * f->desc_bytes];
+            double dist = f->desc_f32 ? l2_f32(qd, cd, f->desc_bytes / 4) : hamming32(qd, cd);
             if (dist < min_distance || list_n < 2) {
                 min_distance = min_distance < 0 ? dist : (min_distance < dist ? min_distance : dist);
                 idx_back = idx_front; d_back = d_front; /* push_front, pop_back beyond 2 */
@@ -1832,7 +1870,7 @@ static int orc_step_impl(OrcFilter *f, const EkfKeypoint *kps, const uint8_t *de
     for (int i = 0; i < ni; ++i) {
         int fi = sel[i].featureIndex;
         f->ftimes_matched[fi]++;
-        if (!use_ncc) memcpy(&f->fdesc[(size_t)fi * EKF_DESC_BYTES], &desc32[(size_t)sel[i].keypointIndex * EKF_DESC_BYTES], EKF_DESC_BYTES);
+        if (!use_ncc) memcpy(&f->fdesc[(size_t)fi * f->desc_bytes], &desc32[(size_t)sel[i].keypointIndex * f->desc_bytes], (size_t)f->desc_bytes);
     }
     int st = orc_update(f, sel, preds, Hs, Hf, ni, variant);                 /* :430 */
     if (st != EKF_OK) status = st;
@@ -1864,7 +1902,7 @@ static int orc_step_impl(OrcFilter *f, const EkfKeypoint *kps, const uint8_t *de
     for (int i = 0; i < nr; ++i) { /* rescued matches join the inliers (EKF.cpp:552-556) */
         int fi = sel[i].featureIndex;
         f->ftimes_matched[fi]++;
-        if (!use_ncc) memcpy(&f->fdesc[(size_t)fi * EKF_DESC_BYTES], &desc32[(size_t)sel[i].keypointIndex * EKF_DESC_BYTES], EKF_DESC_BYTES);
+        if (!use_ncc) memcpy(&f->fdesc[(size_t)fi * f->desc_bytes], &desc32[(size_t)sel[i].keypointIndex * f->desc_bytes], (size_t)f->desc_bytes);
     }
     if (nr > 0) {                                                            /* :529-532 */
         st = orc_update(f, sel, preds, Hs, Hf, nr, variant);

@@ -45,6 +45,8 @@ typedef struct OrcStepInfo {
 
 OrcFilter *orc_create(const EkfCamera *cam, const EkfParams *par, int max_features);
 void orc_destroy(OrcFilter *f);
+int orc_set_descriptor_format(OrcFilter *f, int flags); /* EKF_DESCRIPTOR_* of ekf_engine.h; before any descriptor is stored */
+int orc_descriptor_bytes(const OrcFilter *f);
 
 /* initState + initCovariance: EKF/CommonFunctions.cpp:39-80.  Empties the map. */
 void orc_reset(OrcFilter *f);

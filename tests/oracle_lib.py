@@ -30,6 +30,8 @@ def lib():
         L.orc_create.restype = vp
         L.orc_create.argtypes = [C.POINTER(EkfCamera), C.POINTER(EkfParams), i32]
         L.orc_destroy.argtypes = [vp]
+        L.orc_set_descriptor_format.argtypes = [vp, i32]
+        L.orc_descriptor_bytes.argtypes = [vp]
         L.orc_reset.argtypes = [vp]
         L.orc_add_feature.argtypes = [vp, vp, vp]
         L.orc_set_state.argtypes = [vp, vp, i32, vp, vp, vp, vp]
@@ -79,12 +81,21 @@ def _p(a):
 class Oracle:
     """Thin object wrapper; array outputs are numpy copies."""
 
-    def __init__(self, cam, par, max_features):
+    def __init__(self, cam, par, max_features, descriptor_cols_f32=0):
         self.L = lib()
         self.cam, self.par = cam, par
         self.h = self.L.orc_create(C.byref(cam), C.byref(par), int(max_features))
         assert self.h
         self.cap = int(max_features)
+        if descriptor_cols_f32:  # CV_32F descriptors, L2 distance (Matching.cpp:60-73)
+            assert self.L.orc_set_descriptor_format(self.h, 1 | (int(descriptor_cols_f32) << 8)) == 0
+        self.desc_bytes = self.L.orc_descriptor_bytes(self.h)
+        self.desc_dtype = np.float32 if descriptor_cols_f32 else np.uint8
+
+    def _desc(self, desc):
+        if desc is None:
+            return None
+        return np.ascontiguousarray(desc, dtype=self.desc_dtype).view(np.uint8).reshape(-1, self.desc_bytes)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -115,7 +126,7 @@ class Oracle:
 
     def map_features(self):
         N = self.N
-        d = np.ctypeslib.as_array(self.L.orc_feature_desc(self.h), (N * DESC_BYTES,)).copy().reshape(N, DESC_BYTES)
+        d = np.ctypeslib.as_array(self.L.orc_feature_desc(self.h), (N * self.desc_bytes,)).copy().reshape(N, self.desc_bytes).view(self.desc_dtype)
         tp = np.ctypeslib.as_array(self.L.orc_feature_times_predicted(self.h), (N,)).copy()
         tm = np.ctypeslib.as_array(self.L.orc_feature_times_matched(self.h), (N,)).copy()
         return d, tp, tm
@@ -147,14 +158,14 @@ class Oracle:
 
     def add_feature(self, uv, desc=None):
         uv = np.ascontiguousarray(uv, dtype=np.float64)
-        d = None if desc is None else np.ascontiguousarray(desc, dtype=np.uint8)
+        d = self._desc(desc)
         return self.L.orc_add_feature(self.h, _p(uv), _p(d))
 
     def set_state(self, x13, feature_pos, feature_type, desc, P):
         x13 = np.ascontiguousarray(x13, dtype=np.float64)
         fp = np.ascontiguousarray(feature_pos, dtype=np.float64).reshape(-1, 6)
         ft = None if feature_type is None else np.ascontiguousarray(feature_type, dtype=np.int32)
-        d = None if desc is None else np.ascontiguousarray(desc, dtype=np.uint8)
+        d = self._desc(desc)
         Pm = np.ascontiguousarray(P, dtype=np.float64)
         rc = self.L.orc_set_state(self.h, _p(x13), len(fp), _p(fp), _p(ft), _p(d), _p(Pm))
         assert rc == 0, rc
@@ -202,7 +213,7 @@ class Oracle:
     def match(self, preds, kps, desc):
         preds = np.ascontiguousarray(preds, dtype=PREDICTION_DTYPE)
         kps = np.ascontiguousarray(kps, dtype=KEYPOINT_DTYPE)
-        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, DESC_BYTES)
+        desc = self._desc(desc)
         out = np.zeros(max(len(preds), 1), dtype=MATCH_DTYPE)
         k = self.L.orc_match(self.h, _p(preds), len(preds), _p(kps), _p(desc), len(kps), _p(out))
         return out[:k].copy()
@@ -235,7 +246,7 @@ class Oracle:
 
     def step(self, kps, desc, variant=LITERAL):
         kps = np.ascontiguousarray(kps, dtype=KEYPOINT_DTYPE)
-        desc = np.ascontiguousarray(desc, dtype=np.uint8)
+        desc = self._desc(desc)
         info = EkfStepInfo()
         self.L.orc_step(self.h, _p(kps), _p(desc), len(kps), variant, C.byref(info))
         return info
