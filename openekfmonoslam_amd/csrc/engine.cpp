@@ -64,12 +64,13 @@ void ekf_engine_destroy(EkfEngine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->stream_u) (void)hipStreamSynchronize(e->stream_u);
     DeviceArrays &d = e->d;
     void *ptrs[] = {d.state,     d.feat_pos,  d.feat_type, d.feat_covpos, d.feat_desc, d.feat_times_predicted, d.feat_times_matched, d.P, d.P2, d.mm_scratch, d.mm_index,        d.pred_vis, d.pred_vis_full, d.step_preds,
                     d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,
                     d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
-                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.Tbuf, d.W, d.Wf, d.G, d.LL, d.gates, d.cell_resp, d.cell_xy,
+                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.W, d.Wf, d.G, d.LL, d.gates, d.cell_resp, d.cell_xy,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.sq_part, d.diag_save, d.cam_part, d.cam_save, d.HPc, d.Gc, d.Bc, d.zvec, d.yvec,
                     e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq};
     for (void *p : ptrs)
@@ -84,6 +85,11 @@ void ekf_engine_destroy(EkfEngine *e)
     }
     if (e->h_mirror) (void)hipHostFree(e->h_mirror);
     if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
+    if (e->stream_u) { (void)hipStreamSynchronize(e->stream_u); (void)hipStreamDestroy(e->stream_u); }
+    for (auto ev : e->ev_chunks)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->ev_b_done) (void)hipEventDestroy(e->ev_b_done);
+    if (e->ev_dx_done) (void)hipEventDestroy(e->ev_dx_done);
     if (e->ev_main) (void)hipEventDestroy(e->ev_main);
     if (e->ev_prefetch) (void)hipEventDestroy(e->ev_prefetch);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -133,6 +139,9 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     if ((st = hipSetDevice(e->device)) != hipSuccess) return fail(st, "hipSetDevice");
     if ((st = hipStreamCreate(&e->stream)) != hipSuccess) return fail(st, "hipStreamCreate");
     if ((st = hipStreamCreate(&e->stream2)) != hipSuccess) return fail(st, "hipStreamCreate");
+    if ((st = hipStreamCreate(&e->stream_u)) != hipSuccess) return fail(st, "hipStreamCreate");
+    if ((st = hipEventCreateWithFlags(&e->ev_b_done, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
+    if ((st = hipEventCreateWithFlags(&e->ev_dx_done, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
     if ((st = hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
     if ((st = hipEventCreateWithFlags(&e->ev_prefetch, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
     DeviceArrays &d = e->d;
@@ -201,7 +210,6 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     ALLOC(d.nu, mcap);
     ALLOC(d.Dinv, mw * e->ldW);
     ALLOC(d.W, mw * e->ldW);
-    ALLOC(d.Tbuf, mw * e->ldW);
     if (e->f32) ALLOC(d.Wf, mw * e->ldW);
     ALLOC(d.mHs, 14 * cap);
     ALLOC(d.mHf, 12 * cap);

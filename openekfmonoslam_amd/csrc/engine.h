@@ -107,7 +107,6 @@ struct DeviceArrays {
     double *Dinv = nullptr; // V = inv(L), row-major [mw x ldW], built up from 32x32 diagonal blocks by doubling
     double *W = nullptr;    // W = inv(L)' (upper triangular), row-major [mw x ldW]: the k-major operand of B = W' G
     float *Wf = nullptr;    // fp32 copy of W (fp32 configuration)
-    double *Tbuf = nullptr; // [mw x ldW] scratch of the doubling steps (T = L21 X11)
     double *mHs = nullptr;  // per selected match
     double *mHf = nullptr;
     int *mpos = nullptr;
@@ -179,6 +178,18 @@ struct EkfEngine {
     int pu_per_xcd = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // image-only work of the next frame, overlapped with the update
+    hipStream_t stream_u = nullptr;            // update: inverse / B chunks behind the sweep, dx beside the downdate
+    std::vector<hipEvent_t> ev_chunks;         // main -> side stream, one per chunk of the sweep
+    hipEvent_t ev_b_done = nullptr, ev_dx_done = nullptr;
+    hipEvent_t chunk_event(int i)
+    {
+        while ((int)ev_chunks.size() <= i) {
+            hipEvent_t ev = nullptr;
+            (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            ev_chunks.push_back(ev);
+        }
+        return ev_chunks[i];
+    }
     hipEvent_t ev_main = nullptr, ev_prefetch = nullptr;
     ekf::DeviceArrays d;
     ekf::Frames frames;
@@ -211,11 +222,12 @@ struct XtyArgs {
     int M, N, K;                          // output rows / columns / k-depth per batch element
     int row0_first, row0_stride, m_lim;   // rows of element b that exist: min(M, m_lim - (row0_first + b row0_stride))
     int tri;                              // 0: all k; 1: Y[k][j] = 0 for k < j; 2: X[k][i] = 0 for k > i
-    int tiles_i, tiles_j;
+    int tiles_i, tiles_j;                 // row tiles of this launch (from ti_first on) / column tiles
+    int ti_first;                         // first row tile (a launch may cover a row range of the product)
     int n_split;                          // bottom row tiles cut into two half units (tri == 2, batch 1 only)
     double alpha;
 };
-void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32);
+void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32, hipStream_t stream);
 
 // ---- launchers (kernels_*.hip) ; T selected by e->f32 ----------------------------------------------------
 void launch_predict(EkfEngine *e);

@@ -39,6 +39,7 @@ __global__ void __launch_bounds__(256, 3) k_xty(XtyArgs a)
         ti = a.tri == 2 ? a.tiles_i - 1 - a.n_split - t / a.tiles_j : a.n_split + t / a.tiles_j;
         tj = t % a.tiles_j;
     }
+    ti += a.ti_first;
     const int I0 = ti * TM, J0 = tj * TM;
     // rows of this batch element that exist (the last pair of a level may be cut by m_pad)
     const int Mb = min(a.M, a.m_lim - (a.row0_first + b * a.row0_stride));
@@ -131,12 +132,13 @@ __global__ void __launch_bounds__(256, 3) k_xty(XtyArgs a)
         }
 }
 
-void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32)
+void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32, hipStream_t stream)
 {
+    (void)e;
     const int grid = batch * (a.tiles_i + a.n_split) * a.tiles_j;
     if (grid <= 0) return;
-    if (f32) k_xty<float, 16><<<grid, 256, 0, e->stream>>>(a);
-    else k_xty<double, 32><<<grid, 256, 0, e->stream>>>(a);
+    if (f32) k_xty<float, 16><<<grid, 256, 0, stream>>>(a);
+    else k_xty<double, 32><<<grid, 256, 0, stream>>>(a);
 }
 
 } // namespace ekf

@@ -5,8 +5,8 @@
 //     S  = G H' + R       (m x m fp64, lower triangle; block-sparse H => 13-term dot products)
 //     S  = L L'           (blocked right-looking Cholesky, fp64, one launch per 32-wide panel; z = inv(L) nu and, in the
 //                          fp32 configuration, the fp64 camera columns of B ride along as right-hand sides)
-//     inv(L)              (doubling levels on the fp64 MFMA)
-//     B  = inv(L) G       (ONE GEMM against the inverted factor, kernels_gemm.hip)
+//     inv(L)              (by block columns, chunk by chunk behind the sweep on a second stream, fp64 MFMA)
+//     B  = inv(L) G       (GEMM against the inverted factor, kernels_gemm.hip, one row chunk at a time behind the inverse)
 //     dx = B' z           (= K nu,  K = P H' inv(S))
 //     P <- sym(P) - B' B  (= 0.5 ((I-KH)P + ((I-KH)P)'), kernels_pupdate.hip -- the MFMA kernel)
 //     q normalisation and its Jacobian on the rows/columns 3..6 of P (Update.cpp:45-85, 303-317)
@@ -25,7 +25,8 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
          const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
-         double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc)
+         double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, const T *P, int n, RowMap rm,
+         double *dsave, double *csave, int avg)
 {
     const int row = blockIdx.y;
     // 16 bytes per thread: the copy is pure HBM traffic (n_pad and ld are multiples of 128 elements)
@@ -33,6 +34,22 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
     typedef T vec_t __attribute__((ext_vector_type(VW)));
     const int j = (blockIdx.x * 256 + threadIdx.x) * VW;
     const int m = 2 * M;
+    if (row == 0 && csave) {
+        // phase 0 of k_diag_fix (fp32 covariance): keep the diagonal and the camera rows of P as they are before the
+        // downdate (avg: the first downdate after an arbitrary upload works on 0.5 (P(a,j) + P(j,a))).  P is not
+        // touched between here and the downdate.
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+            const int jj = j + v;
+            if (jj >= n) break;
+            const bool mine = owns_row(rm, jj);
+            const T *prow = P + (size_t)local_row(rm, jj) * ld;
+            if (mine) dsave[jj] = (double)prow[jj];
+#pragma unroll
+            for (int a = 0; a < 13; ++a)
+                csave[(size_t)a * ld + jj] = avg ? (double)((T)0.5 * P[(size_t)a * ld + jj] + (T)0.5 * prow[a]) : (double)P[(size_t)a * ld + jj];
+        }
+    }
     if (row < m) {
         const int i = row >> 1, r = row & 1;
         const int fi = matches[i].featureIndex;
@@ -321,78 +338,76 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
 }
 
 // ------------------------------------------------------------------------------------------ inverse of L
-// Doubling step s -> 2s:  inv([L11 0; L21 L22]) has the off-diagonal block X21 = -X22 L21 X11.  Two batched products
-// per level (T = L21 X11, X21 = -X22 T).  Levels s = 32, 64, 128 run here (32x32 output tile per workgroup, fp64
-// FMA: the whole level is a few microseconds of work); from s = 256 on the same two products go through the MFMA
-// GEMM (k_xty<double>, kernels_gemm.hip).  V = inv(L) row-major, W = V' (+ fp32 copy): after the last level
-// B = inv(L) A is ONE GEMM, B = W' A, with no dependency between row blocks.
-// mode 0: T[pair] = L21 * X11 ;  mode 1: X21 = -X22 * T
+// X = inv(L) by BLOCK COLUMNS, the rows of one chunk (<= 4 block rows = 128 rows) per launch:
+//     X_jj = inv(L_jj)  (published by the sweep),   X_aj = -inv(L_aa) sum_{c=j}^{a-1} L_ac X_cj   for a > j.
+// Block column j is independent of every other column, and row a of it needs only rows < a of the SAME column: one
+// workgroup per column, the chunk's rows in sequence, the X_aj of the chunk kept in LDS for the rows after them.  A
+// chunk's launch needs the sweep only up to the chunk's last panel, so it runs on the engine's second stream WHILE the
+// sweep factorises the next chunk (and B = inv(L) G follows chunk by chunk behind it, kernels_gemm.hip): when the sweep
+// ends, one chunk of the inverse and one row chunk of B are left instead of the whole inverse (12 dependent launches
+// of the doubling scheme this replaces) and the whole GEMM.
+// Each wavefront owns one 16x16 quadrant of the 32x32 block; products on the fp64 MFMA, operands fetched straight into
+// the MFMA operand layout (lane l: a[l % 16][l / 16], b[l / 16][l % 16]), the next product's operands requested before
+// the current product's MFMAs are issued.  V = inv(L) row-major, W = V' (+ fp32 copy) as before.
+constexpr int INV_CH = 4; // block rows per chunk
+
 __global__ void __launch_bounds__(256)
-k_triinv_level(const double *S, int ldS, int m, int m_pad, double *V, double *W, float *Wf, double *Tbuf, int ldw,
-               int s, int mode)
+k_inv_rows(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, int a_first, int a_count)
 {
-    __shared__ double sA[NB][NB + 1];
-    __shared__ double sB[NB][NB + 1];
-    const int tiles = s / NB;
-    const int pair = blockIdx.x / (tiles * tiles);
-    const int t = blockIdx.x % (tiles * tiles);
-    const int tr = t / tiles, tc = t % tiles;
-    const int r0 = pair * 2 * s; // first row of the pair's 2s x 2s diagonal block
-    if (r0 + s + tr * NB >= m_pad) return; // no such rows in the second half
-    const int tid = threadIdx.x;
-    // 16x16 block (bi, bj) of the 32x32 output tile per wavefront, products on the fp64 MFMA (as in k_chol_step)
     typedef double acc4 __attribute__((ext_vector_type(4)));
-    const int lane = tid & 63, wv = tid >> 6;
-    const int bi = wv >> 1, bj = wv & 1, lr = lane & 15, lk = lane >> 4;
-    acc4 acc = {0, 0, 0, 0};
-    // k-chunks that can be non-zero: X11 and X22 are lower triangular.
-    //   mode 0: X11[kk + r][tc*32 + c] = 0 when kk + 31 < tc*32      -> start at chunk tc
-    //   mode 1: X22[tr*32 + r][kk + c] = 0 when kk > tr*32 + 31      -> stop after chunk tr
-    const int kk_lo = mode == 0 ? tc * NB : 0;
-    const int kk_hi = mode == 0 ? s : (tr + 1) * NB;
-    // this thread's 4 + 4 elements of a chunk, fetched one chunk ahead of the MFMAs
-    double pa[4], pb[4];
-    auto fetch = [&](int kk) {
+    __shared__ double sX[INV_CH][NB][NB + 1]; // X_aj of the chunk's rows (operand of the rows below them)
+    __shared__ double sT[NB][NB + 1];
+    const int j = blockIdx.x;
+    const int a_last = a_first + a_count - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int qi = wv >> 1, qj = wv & 1, lr = lane & 15, lk = lane >> 4;
+    for (int a = max(a_first, j + 1); a <= a_last; ++a) {
+        // T = sum_c L_ac X_cj, this wavefront's quadrant
+        acc4 acc = {0, 0, 0, 0};
+        double pa[8], pb[8];
+        auto fetch = [&](int c) {
+            const double *Lp = LL + (size_t)(NB * a + 16 * qi + lr) * ldS + NB * c + lk;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + q * 256;
-            const int r = i / NB, c = i % NB;
-            if (mode == 0) {
-                const int gr = r0 + s + tr * NB + r, gc = r0 + kk + c; // L21 (rows m..m_pad of L are zero)
-                pa[q] = (gr < m) ? S[(size_t)gr * ldS + gc] : 0.0;
-                pb[q] = V[(size_t)(r0 + kk + r) * ldw + r0 + tc * NB + c]; // X11[kk + r][tc*32 + c]
-            } else {
-                pa[q] = V[(size_t)(r0 + s + tr * NB + r) * ldw + r0 + s + kk + c]; // X22[tr*32 + r][kk + c]
-                pb[q] = Tbuf[(size_t)(r0 + s + kk + r) * ldw + tc * NB + c];       // T[kk + r][tc*32 + c]
+            for (int kk = 0; kk < 8; ++kk) pa[kk] = Lp[4 * kk];
+            if (c > j && c >= a_first) {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) pb[kk] = sX[c - a_first][4 * kk + lk][16 * qj + lr];
+            } else { // the diagonal block inv(L_jj) or a row of an earlier chunk: final in V
+                const double *Xp = V + (size_t)(NB * c + lk) * ldw + NB * j + 16 * qj + lr;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) pb[kk] = Xp[(size_t)4 * kk * ldw];
             }
-        }
-    };
-    fetch(kk_lo);
-    for (int kk = kk_lo; kk < kk_hi; kk += NB) {
+        };
+        fetch(j);
+        for (int c = j; c < a; ++c) {
+            double ca[8], cb[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + q * 256;
-            sA[i / NB][i % NB] = pa[q];
-            sB[i / NB][i % NB] = pb[q];
+            for (int kk = 0; kk < 8; ++kk) { ca[kk] = pa[kk]; cb[kk] = pb[kk]; }
+            if (c + 1 < a) fetch(c + 1);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[kk], cb[kk], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sT[16 * qi + lk + 4 * v][16 * qj + lr] = acc[v];
+        // X_aj = -inv(L_aa) T
+        const double *Dp = V + (size_t)(NB * a + 16 * qi + lr) * ldw + NB * a + lk;
+        double da[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) da[kk] = Dp[4 * kk];
+        __syncthreads();
+        acc4 x = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(da[kk], sT[4 * kk + lk][16 * qj + lr], x, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = 16 * qi + lk + 4 * v, c = 16 * qj + lr;
+            const double val = -x[v];
+            sX[a - a_first][r][c] = val;
+            V[(size_t)(NB * a + r) * ldw + NB * j + c] = val;
+            W[(size_t)(NB * j + c) * ldw + NB * a + r] = val;
+            if (Wf) Wf[(size_t)(NB * j + c) * ldw + NB * a + r] = (float)val;
         }
         __syncthreads();
-        if (kk + NB < kk_hi) fetch(kk + NB);
-#pragma unroll
-        for (int k4 = 0; k4 < NB; k4 += 4)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[16 * bi + lr][k4 + lk], sB[k4 + lk][16 * bj + lr], acc, 0, 0, 0);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = 16 * bi + lk + 4 * q, c = 16 * bj + lr;
-        const int gi = r0 + s + tr * NB + r, gj = tc * NB + c;
-        if (mode == 0) {
-            Tbuf[(size_t)gi * ldw + gj] = acc[q];
-        } else {
-            V[(size_t)gi * ldw + r0 + gj] = -acc[q];
-            W[(size_t)(r0 + gj) * ldw + gi] = -acc[q];
-            if (Wf) Wf[(size_t)(r0 + gj) * ldw + gi] = (float)(-acc[q]);
-        }
     }
 }
 
@@ -416,21 +431,11 @@ __global__ void __launch_bounds__(256) k_yvec(const double *W, int ldw, int m, c
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, int ldpart, double *sq_part, double *cam_part,
-             const double *Bc, const T *P, RowMap rm, double *dsave, double *csave, int avg, const T *G, const double *y)
+             const double *Bc, const T *G, const double *y)
 {
     __shared__ double sc[64][13]; // fp64 camera columns of a chunk of rows of B
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int ks = blockIdx.y;
-    if (ks == 0 && csave && j < n) {
-        // phase 0 of k_diag_fix: keep the diagonal and the camera rows of P as they are before the downdate
-        // (avg: the first downdate after an arbitrary upload works on 0.5 (P(a,j) + P(j,a)))
-        const bool mine = owns_row(rm, j);
-        const T *prow = P + (size_t)local_row(rm, j) * ld;
-        if (mine) dsave[j] = (double)prow[j];
-#pragma unroll
-        for (int a = 0; a < 13; ++a)
-            csave[(size_t)a * ldpart + j] = avg ? (double)((T)0.5 * P[(size_t)a * ld + j] + (T)0.5 * prow[a]) : (double)P[(size_t)a * ld + j];
-    }
     const int per = (m + DX_SPLIT - 1) / DX_SPLIT;
     const int kb = ks * per, ke = min(m, kb + per);
     double s = 0.0, q = 0.0;
@@ -612,10 +617,15 @@ __global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, cons
 // P-update launcher lives in kernels_pupdate.hip
 void launch_p_update(EkfEngine *e, int m_pad);
 
+// One update = two streams.  Main stream: gather, S, the sweep (one launch per 32-wide panel), then the downdate and its
+// tail.  Side stream (e->stream_u), chunk by chunk (4 panels = 128 rows) behind the sweep: the chunk's block rows of
+// inv(L) (k_inv_rows) and the chunk's rows of B = inv(L) G (k_xty on a row range); after the last chunk, off the
+// downdate's critical path and concurrent with it: y = inv(L)' z, dx, the state update.  The downdate waits for B, its
+// tail (k_diag_fix needs the fp64 sums of k_dx_partial, k_normalize_cov the Jacobian k_state_apply leaves) for dx.
 template <typename T>
 static void update_impl(EkfEngine *e, int M, bool update_cov)
 {
-    hipStream_t s = e->stream;
+    hipStream_t s = e->stream, su = e->stream_u;
     const int m = 2 * M, n = e->n, ld = e->ldP, ldS = e->ldS, ldw = e->ldW;
     const int m_pad = round_up(m, NB);
     const int n_pad = round_up(n, LD_ALIGN);
@@ -623,18 +633,25 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     T *A = (T *)e->d.A; // B = inv(L) G
     double *V = e->d.Dinv, *W = e->d.W;
     float *Wf = e->f32 ? e->d.Wf : nullptr;
+    const bool fix = update_cov && sizeof(T) == 4;
     {
         dim3 grid((n_pad / (int)(16 / sizeof(T)) + 255) / 256, m_pad);
+        const int avg = e->p_exact_sym ? 0 : 1; // an AVG downdate only exists on an unsharded engine: every row is local
         k_gather<T><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const T *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
-                                         e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc);
+                                         e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc, (const T *)e->d.P, n, e->rm,
+                                         e->d.diag_save, fix ? e->d.cam_save : nullptr, avg);
     }
     {
         dim3 grid((M + 15) / 16, (M + 15) / 16);
         k_assemble_S<T><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts);
     }
-    for (int k0 = 0; k0 < m; k0 += NB) {
+    const int nbk = m_pad / NB; // panels = block rows
+    const int TM = sizeof(T) == 4 ? 128 : 64;
+    int chunk = 0;
+    for (int k = 0; k < nbk; ++k) {
+        const int k0 = k * NB;
         const int kb = min(NB, m - k0);
         const int k1 = k0 + kb;
         const int nrb = (m - k1 + NB - 1) / NB; // row blocks below the panel
@@ -642,51 +659,56 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const int n_rhs_blocks = max(1, (m - k1 + 255) / 256); // right-hand-side blocks, 256 rows each
         k_chol_step<<<n_stiles + n_rhs_blocks, 256, 0, s>>>(e->d.S, e->d.LL, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles, V, W, Wf,
                                                             ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr, e->d.zvec, e->d.Bc);
-    }
-    // inv(L) by doubling: 32 -> 64 -> ... until one block covers all rows
-    for (int sz = NB; sz < m_pad; sz *= 2) {
-        const int npairs = (m_pad - sz + 2 * sz - 1) / (2 * sz); // pairs whose second half has rows
-        {   // 32x32 output tiles on the fp64 MFMA at every level: these products are small (m^3/3 flop in total) and
-            // need many workgroups with short k-loops rather than big tiles (64x64 tiles left 3/4 of the CUs idle)
-            const int tiles = (sz / NB) * (sz / NB);
-            k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.LL, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 0);
-            k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.LL, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 1);
+        if (k % INV_CH != INV_CH - 1 && k != nbk - 1) continue;
+        // the chunk's panels are factorised (launch k published inv(L_kk) one launch earlier and stored column k of L):
+        // its rows of inv(L) and of B follow on the side stream while the sweep goes on
+        hipEvent_t ev = e->chunk_event(chunk);
+        (void)hipEventRecord(ev, s);
+        (void)hipStreamWaitEvent(su, ev, 0);
+        const int a_first = chunk * INV_CH, a_count = min(INV_CH, nbk - a_first);
+        if (a_first + a_count - 1 >= 1)
+            k_inv_rows<<<a_first + a_count - 1, 256, 0, su>>>(e->d.LL, ldS, V, W, Wf, ldw, a_first, a_count);
+        {   // B rows of the chunk = W' G restricted to these rows: k <= row (W upper triangular)
+            XtyArgs g{};
+            g.X = e->f32 ? (const void *)Wf : (const void *)W; g.ldx = ldw;
+            g.Y = G; g.ldy = ld;
+            g.C = A; g.ldc = ld;
+            g.M = m_pad; g.N = n_pad; g.K = m_pad;
+            g.row0_first = 0; g.row0_stride = 0; g.m_lim = m_pad;
+            g.tri = 2;
+            g.ti_first = a_first * NB / TM;
+            g.tiles_i = (a_count * NB + TM - 1) / TM;
+            g.tiles_j = (n_pad + TM - 1) / TM; g.alpha = 1.0;
+            g.n_split = g.tiles_i; // half units: twice the workgroups on what is a 47-tile launch at N = 1000
+            launch_xty(e, g, 1, e->f32, su);
         }
+        ++chunk;
     }
-    {   // B = inv(L) G = W' G : one GEMM, k <= row (W upper triangular)
-        const int TM = sizeof(T) == 4 ? 128 : 64;
-        XtyArgs g{};
-        g.X = e->f32 ? (const void *)Wf : (const void *)W; g.ldx = ldw;
-        g.Y = G; g.ldy = ld;
-        g.C = A; g.ldc = ld;
-        g.M = m_pad; g.N = n_pad; g.K = m_pad;
-        g.row0_first = 0; g.row0_stride = 0; g.m_lim = m_pad;
-        g.tri = 2; g.tiles_i = (m_pad + TM - 1) / TM; g.tiles_j = (n_pad + TM - 1) / TM; g.alpha = 1.0;
-        g.n_split = g.tiles_i / 2; // k-depth of row tile i is ~(i+1) TM: halve the units of the longer half
-        launch_xty(e, g, 1, e->f32);
-    }
-    {
+    (void)hipEventRecord(e->ev_b_done, su);
+    {   // dx and the state update: not needed by the downdate, concurrent with it
         dim3 grid((n + 255) / 256, DX_SPLIT);
-        const bool fix = update_cov && sizeof(T) == 4;
-        const int avg = e->p_exact_sym ? 0 : 1; // an AVG downdate only exists on an unsharded engine: every row is local
         const double *Bc = nullptr;
         const T *Gy = nullptr;
         if (sizeof(T) == 4) {
             Bc = e->d.Bc; // inv(L) Gc, produced by the right-hand-side blocks of k_chol_step
-            k_yvec<<<(m + 3) / 4, 256, 0, s>>>(W, ldw, m, e->d.zvec, e->d.yvec);
+            k_yvec<<<(m + 3) / 4, 256, 0, su>>>(W, ldw, m, e->d.zvec, e->d.yvec);
             Gy = G;
         }
-        k_dx_partial<T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld,
-                                             fix ? e->d.sq_part : nullptr, fix ? e->d.cam_part : nullptr, Bc, (const T *)e->d.P,
-                                             e->rm, e->d.diag_save, fix ? e->d.cam_save : nullptr, avg, Gy, e->d.yvec);
+        k_dx_partial<T><<<grid, 256, 0, su>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, fix ? e->d.sq_part : nullptr,
+                                              fix ? e->d.cam_part : nullptr, Bc, Gy, e->d.yvec);
         const int nt = max(e->N * 6, 1);
-        k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
-                                                       e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
+        k_state_apply<<<(nt + 255) / 256, 256, 0, su>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
+                                                        e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
     }
-    if (!update_cov) return;
-    const bool fix_diag = sizeof(T) == 4;
+    (void)hipEventRecord(e->ev_dx_done, su);
+    if (!update_cov) {
+        (void)hipStreamWaitEvent(s, e->ev_dx_done, 0);
+        return;
+    }
+    (void)hipStreamWaitEvent(s, e->ev_b_done, 0);
     launch_p_update(e, m_pad);
-    if (fix_diag) k_diag_fix<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save, e->d.cam_part, ld);
+    (void)hipStreamWaitEvent(s, e->ev_dx_done, 0);
+    if (fix) k_diag_fix<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save, e->d.cam_part, ld);
     const int nb = 1 + (n > 7 ? (n - 7 + 255) / 256 : 0);
     k_normalize_cov<T><<<nb, 256, 0, s>>>((T *)e->d.P, ld, n, e->d.state, e->rm);
 }
