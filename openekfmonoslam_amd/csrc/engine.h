@@ -103,6 +103,9 @@ struct DeviceArrays {
     void *A = nullptr;   // T [(mcap + 1) x ldP] : B = inv(L) G  (k-major operand of the downdate)
     double *S = nullptr;  // (mcap + slack) x ldS: lower triangle of S, updated in place by the sweep
     double *LL = nullptr; // same shape: L below the 32x32 diagonal blocks and L' mirrored above them
+    float *LLf = nullptr; // fp32 copy of the mirrored part (L', k-major): operand of the fp32 forward-substitution GEMMs
+    void *R = nullptr;    // T [(mcap + 1) x ldP]: working right-hand side of B = inv(L) G (G itself stays intact for dx)
+    double *zwork = nullptr; // [mcap + slack]: working vector of the backward substitution y = inv(L)' z
     double *nu = nullptr;
     double *Dinv = nullptr; // V = inv(L), row-major [mw x ldW], built up from 32x32 diagonal blocks by doubling
     double *W = nullptr;    // W = inv(L)' (upper triangular), row-major [mw x ldW]: the k-major operand of B = W' G
@@ -224,6 +227,8 @@ struct XtyArgs {
     int tri;                              // 0: all k; 1: Y[k][j] = 0 for k < j; 2: X[k][i] = 0 for k > i
     int tiles_i, tiles_j;                 // row tiles of this launch (from ti_first on) / column tiles
     int ti_first;                         // first row tile (a launch may cover a row range of the product)
+    int k_first;                          // first k (tri != 1): the k-range is [k_first, K), cut at I0 + TM when tri == 2
+    int accumulate;                       // C += alpha X'Y instead of C = alpha X'Y
     int n_split;                          // bottom row tiles cut into two half units (tri == 2, batch 1 only)
     double alpha;
 };

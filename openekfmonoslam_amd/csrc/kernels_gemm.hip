@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256, 3) k_xty(XtyArgs a)
     for (int r = 0; r < M::NACC; ++r) c00[r] = c01[r] = c10[r] = c11[r] = (T)0;
 
     // k-range: tri 1: Y[k][j] = 0 for k < j ; tri 2: X[k][i] = 0 for k > i
-    const int k_lo = a.tri == 1 ? J0 : 0;
+    const int k_lo = a.tri == 1 ? J0 : a.k_first;
     const int k_hi = a.tri == 2 ? min(a.K, I0 + TM) : a.K;
     const int nk = (k_hi - k_lo) / BK; // K, the tile edges and BK are multiples of 32 (16 for fp32): whole slabs
     using V = typename M::vec_t;
@@ -123,7 +123,8 @@ __global__ void __launch_bounds__(256, 3) k_xty(XtyArgs a)
             for (int r = 0; r < M::NACC; ++r) {
                 const int gi = bi + M::row(r, lane), gj = bj + M::col(lane);
                 if (gi < Mb && gj < a.N) {
-                    const T v = alpha * cc[r];
+                    T v = alpha * cc[r];
+                    if (a.accumulate) v += C[(size_t)gi * a.ldc + gj];
                     if (C) C[(size_t)gi * a.ldc + gj] = v;
                     if (Ct) Ct[(size_t)gj * a.ldct + gi] = (double)v;
                     if (Ctf) Ctf[(size_t)gj * a.ldct + gi] = (float)v;

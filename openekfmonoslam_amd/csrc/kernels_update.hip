@@ -5,9 +5,9 @@
 //     S  = G H' + R       (m x m fp64, lower triangle; block-sparse H => 13-term dot products)
 //     S  = L L'           (blocked right-looking Cholesky, fp64, one launch per 32-wide panel; z = inv(L) nu and, in the
 //                          fp32 configuration, the fp64 camera columns of B ride along as right-hand sides)
-//     inv(L)              (by block columns, chunk by chunk behind the sweep on a second stream, fp64 MFMA)
-//     B  = inv(L) G       (GEMM against the inverted factor, kernels_gemm.hip, one row chunk at a time behind the inverse)
-//     dx = B' z           (= K nu,  K = P H' inv(S))
+//     B  = inv(L) G       (blocked forward substitution in 128-row chunks behind the sweep on a second stream: diagonal-block
+//                          inverse on the fp64 MFMA, the two GEMMs of a chunk in kernels_gemm.hip)
+//     dx = B' z           (= K nu,  K = P H' inv(S); fp32 configuration: feature columns as (H P)' y, y = inv(L)' z)
 //     P <- sym(P) - B' B  (= 0.5 ((I-KH)P + ((I-KH)P)'), kernels_pupdate.hip -- the MFMA kernel)
 //     q normalisation and its Jacobian on the rows/columns 3..6 of P (Update.cpp:45-85, 303-317)
 //
@@ -23,7 +23,7 @@ namespace ekf {
 // dead-banded innovation nu (Update.cpp:125-135).  Rows m..m_pad of A are zero-filled for the k-tiled kernels.
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
+k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, T *R, int ld, int n_pad, const double *uv_tab,
          const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
          double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, const T *P, int n, RowMap rm,
          double *dsave, double *csave, int avg)
@@ -53,7 +53,11 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
     if (row < m) {
         const int i = row >> 1, r = row & 1;
         const int fi = matches[i].featureIndex;
-        if (j < n_pad) *(vec_t *)(A + (size_t)row * ld + j) = *(const vec_t *)(HP + (size_t)(2 * fi + r) * ld + j);
+        if (j < n_pad) {
+            const vec_t v = *(const vec_t *)(HP + (size_t)(2 * fi + r) * ld + j);
+            *(vec_t *)(A + (size_t)row * ld + j) = v; // G: stays intact (S, dx)
+            *(vec_t *)(R + (size_t)row * ld + j) = v; // working right-hand side of the forward substitution B = inv(L) G
+        }
         if (blockIdx.x == 0 && threadIdx.x < 16) Gc[(size_t)row * 16 + threadIdx.x] = threadIdx.x < 13 ? HPc[(size_t)(2 * fi + r) * 16 + threadIdx.x] : 0.0;
         if (blockIdx.x == 0 && r == 0) {
             const int t = threadIdx.x;
@@ -73,6 +77,7 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
 #pragma unroll
             for (int v = 0; v < VW; ++v) zero[v] = (T)0;
             *(vec_t *)(A + (size_t)row * ld + j) = zero;
+            *(vec_t *)(R + (size_t)row * ld + j) = zero;
         }
         if (blockIdx.x == 0 && threadIdx.x < 16) Gc[(size_t)row * 16 + threadIdx.x] = 0.0;
         if (blockIdx.x == 0 && threadIdx.x == 0) nu[row] = 0.0;
@@ -164,7 +169,7 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 //   nothing races.  Tile 0 = block (k+1, k+1): look-ahead factorisation, publishes Linv_{k+1}.
 //   nu block: z_k = Linv_k nu_k, then nu_i -= L_ik z_k = S_ik (Linv_k' z_k) for all rows below.
 __global__ void __launch_bounds__(256)
-k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, double *nu, int n_stiles, double *V,
+k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0, int kb, double *nu, int n_stiles, double *V,
             double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc)
 {
     __shared__ double sA[NB][NB + 1];
@@ -276,7 +281,10 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
             }
             for (int i = tid; i < NB * NB; i += 256) {
                 const int c = i / NB, r = i % NB;
-                if (i0 + r < m_pad && c < kb) LL[(size_t)(k0 + c) * ldS + i0 + r] = sLI[r][c];
+                if (i0 + r < m_pad && c < kb) {
+                    LL[(size_t)(k0 + c) * ldS + i0 + r] = sLI[r][c];
+                    if (LLf) LLf[(size_t)(k0 + c) * ldS + i0 + r] = (float)sLI[r][c];
+                }
             }
         }
         return;
@@ -352,12 +360,12 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
 constexpr int INV_CH = 4; // block rows per chunk
 
 __global__ void __launch_bounds__(256)
-k_inv_rows(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, int a_first, int a_count)
+k_inv_rows(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, int a_first, int a_count, int j0)
 {
     typedef double acc4 __attribute__((ext_vector_type(4)));
     __shared__ double sX[INV_CH][NB][NB + 1]; // X_aj of the chunk's rows (operand of the rows below them)
     __shared__ double sT[NB][NB + 1];
-    const int j = blockIdx.x;
+    const int j = j0 + blockIdx.x; // first column block of this launch: 0 = whole rows, a_first = the chunk's diagonal block only
     const int a_last = a_first + a_count - 1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int qi = wv >> 1, qj = wv & 1, lr = lane & 15, lk = lane >> 4;
@@ -412,20 +420,32 @@ k_inv_rows(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, 
 }
 
 // ------------------------------------------------------------------------------------------------- dx = B' z
-// y = inv(L)' z = W z (W upper triangular, fp64): with it dx = (H P)' y = G' inv(S) nu, the gain applied without going
-// through B.  fp32 configuration only: B = inv(L) G comes out of an fp32 MFMA GEMM (accumulation error ~ sqrt(m) eps per
-// element), G is the fp64-accumulated H P rounded once -- measured at N = 1000: the inverse-depth components were
-// 2e-7 ... 1e-6 off (up to 8e-5 of a small rho) through B' z.  One wavefront per row.
-__global__ void __launch_bounds__(256) k_yvec(const double *W, int ldw, int m, const double *z, double *y)
+// y = inv(L)' z by blocked BACKWARD substitution, one launch per 128-row chunk J from the last to the first:
+//     y_J = X_JJ' zw_J   (X_JJ = inv of the chunk's diagonal block of L, rows of W = X' are contiguous),
+//     zw_r -= sum_{k in J} L[k][r] y_k   for the rows r above the chunk (row r of the mirrored L' in LL is contiguous in k).
+// Every workgroup forms y_J itself (128 x 128 MACs); workgroup b then updates rows 256 b ... of the working vector.  Needs
+// only the diagonal-block inverses, so the inverse of the whole factor is never formed; runs beside the downdate.
+__global__ void __launch_bounds__(256)
+k_ystep(const double *W, int ldw, const double *LL, int ldS, int m_pad, int r0, int rows, double *zw, double *y)
 {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (i >= m) return;
-    const double *w = W + (size_t)i * ldw;
+    __shared__ double sy[128];
+    const int tid = threadIdx.x;
+    if (tid < 128) {
+        double s = 0.0;
+        if (tid < rows) {
+            const double *w = W + (size_t)(r0 + tid) * ldw + r0;
+            for (int k = tid; k < rows; ++k) s += w[k] * zw[r0 + k];
+        }
+        sy[tid] = s;
+        if (blockIdx.x == 0 && tid < rows) y[r0 + tid] = s;
+    }
+    __syncthreads();
+    const int r = blockIdx.x * 256 + tid;
+    if (r >= r0) return;
+    const double *l = LL + (size_t)r * ldS + r0;
     double s = 0.0;
-    for (int k = i + lane; k < m; k += 64) s += w[k] * z[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if (lane == 0) y[i] = s;
+    for (int k = 0; k < rows; ++k) s += l[k] * sy[k];
+    zw[r] -= s;
 }
 
 template <typename T>
@@ -452,7 +472,7 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
         if (j < n)
             for (int k = 0; k < cnt; ++k) {
                 const double b = (Bc && j < 13) ? sc[k][j] : (double)B[(size_t)(k0 + k) * ld + j];
-                // feature columns of the fp32 configuration: dx_j = sum_k (H P)_kj y_k (see k_yvec); camera columns: Bc' z (fp64)
+                // feature columns of the fp32 configuration: dx_j = sum_k (H P)_kj y_k (y = inv(S) nu from k_ystep: B comes out of fp32 MFMA GEMMs with an accumulation error of ~ sqrt(m) eps per element, G is the fp64-accumulated H P rounded once; measured at N = 1000: the inverse-depth components were 2e-7 ... 1e-6 off through B' z); camera columns: Bc' z (fp64)
                 if (G && j >= 13) s += (double)G[(size_t)(k0 + k) * ld + j] * y[k0 + k];
                 else s += b * z[k0 + k];
                 q += b * b; // (B'B)_jj in fp64, same pass over B: see k_diag_fix
@@ -618,10 +638,17 @@ __global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, cons
 void launch_p_update(EkfEngine *e, int m_pad);
 
 // One update = two streams.  Main stream: gather, S, the sweep (one launch per 32-wide panel), then the downdate and its
-// tail.  Side stream (e->stream_u), chunk by chunk (4 panels = 128 rows) behind the sweep: the chunk's block rows of
-// inv(L) (k_inv_rows) and the chunk's rows of B = inv(L) G (k_xty on a row range); after the last chunk, off the
-// downdate's critical path and concurrent with it: y = inv(L)' z, dx, the state update.  The downdate waits for B, its
-// tail (k_diag_fix needs the fp64 sums of k_dx_partial, k_normalize_cov the Jacobian k_state_apply leaves) for dx.
+// tail.  Side stream (e->stream_u), chunk by chunk (4 panels = 128 rows) behind the sweep, B = inv(L) G by blocked forward
+// substitution on the working copy R of G:
+//     X_cc = inverse of the chunk's 128 x 128 diagonal block of L      (k_inv_rows on the chunk's own columns)
+//     B_c  = X_cc R_c                                                  (k_xty, k inside the chunk)
+//     R_below -= L_below,c B_c                                         (k_xty accumulate, X operand = the mirrored L')
+// -- the big GEMM (the update of the rows below) of chunk c runs while the sweep factorises chunk c + 1, so when the sweep
+// ends only the last chunk's small diagonal pieces are left (the previous form, inverse of the whole factor by doubling
+// then one GEMM, put 12 + 1 dependent launches, ~200 us at m = 1000, behind the sweep).  After the last chunk, off the
+// downdate's critical path and concurrent with it: y = inv(L)' z by blocked backward substitution, dx, the state update.
+// The downdate waits for B; its tail (k_diag_fix needs the fp64 sums of k_dx_partial, k_normalize_cov the Jacobian
+// k_state_apply leaves) waits for dx.
 template <typename T>
 static void update_impl(EkfEngine *e, int M, bool update_cov)
 {
@@ -630,14 +657,16 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     const int m_pad = round_up(m, NB);
     const int n_pad = round_up(n, LD_ALIGN);
     T *G = (T *)e->d.G; // gathered rows of H P
+    T *R = (T *)e->d.R; // working right-hand side
     T *A = (T *)e->d.A; // B = inv(L) G
     double *V = e->d.Dinv, *W = e->d.W;
     float *Wf = e->f32 ? e->d.Wf : nullptr;
+    float *LLf = e->f32 ? e->d.LLf : nullptr;
     const bool fix = update_cov && sizeof(T) == 4;
     {
         dim3 grid((n_pad / (int)(16 / sizeof(T)) + 255) / 256, m_pad);
         const int avg = e->p_exact_sym ? 0 : 1; // an AVG downdate only exists on an unsharded engine: every row is local
-        k_gather<T><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const T *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
+        k_gather<T><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const T *)e->d.HP, G, R, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
                                          e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc, (const T *)e->d.P, n, e->rm,
                                          e->d.diag_save, fix ? e->d.cam_save : nullptr, avg);
@@ -648,8 +677,36 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts);
     }
     const int nbk = m_pad / NB; // panels = block rows
+    const int n_chunks = (nbk + INV_CH - 1) / INV_CH;
     const int TM = sizeof(T) == 4 ? 128 : 64;
-    int chunk = 0;
+    constexpr int CH = INV_CH * NB; // rows per chunk
+    // side-stream work of one chunk; issued one chunk late in HOST order so that the main queue never waits for the host
+    auto side_chunk = [&](int c) {
+        (void)hipStreamWaitEvent(su, e->chunk_event(c), 0);
+        const int a_first = c * INV_CH, a_count = min(INV_CH, nbk - a_first);
+        const int r0 = a_first * NB, rows = a_count * NB;
+        if (a_count > 1) k_inv_rows<<<a_count - 1, 256, 0, su>>>(e->d.LL, ldS, V, W, Wf, ldw, a_first, a_count, a_first);
+        XtyArgs g{};
+        g.ldy = ld; g.ldc = ld;
+        g.M = m_pad; g.N = n_pad;
+        g.row0_first = 0; g.row0_stride = 0; g.m_lim = m_pad;
+        g.tiles_j = (n_pad + TM - 1) / TM;
+        // B_c = X_cc R_c : X operand W = inv(L)' (k-major), k from the chunk's first row up to the row tile's end
+        g.X = e->f32 ? (const void *)Wf : (const void *)W; g.ldx = ldw;
+        g.Y = R; g.C = A;
+        g.tri = 2; g.k_first = r0; g.K = m_pad;
+        g.ti_first = r0 / TM; g.tiles_i = (rows + TM - 1) / TM; g.n_split = g.tiles_i;
+        g.alpha = 1.0; g.accumulate = 0;
+        launch_xty(e, g, 1, e->f32, su);
+        if (r0 + rows < m_pad) { // R_below -= L_below,c B_c : X operand = L' (mirrored part of LL, k-major), k = the chunk's rows
+            g.X = e->f32 ? (const void *)LLf : (const void *)e->d.LL; g.ldx = ldS;
+            g.Y = A; g.C = R;
+            g.tri = 0; g.k_first = r0; g.K = r0 + rows;
+            g.ti_first = (r0 + rows) / TM; g.tiles_i = (m_pad - (r0 + rows) + TM - 1) / TM; g.n_split = 0;
+            g.alpha = -1.0; g.accumulate = 1;
+            launch_xty(e, g, 1, e->f32, su);
+        }
+    };
     for (int k = 0; k < nbk; ++k) {
         const int k0 = k * NB;
         const int kb = min(NB, m - k0);
@@ -657,43 +714,29 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const int nrb = (m - k1 + NB - 1) / NB; // row blocks below the panel
         const int n_stiles = nrb * (nrb + 1) / 2;
         const int n_rhs_blocks = max(1, (m - k1 + 255) / 256); // right-hand-side blocks, 256 rows each
-        k_chol_step<<<n_stiles + n_rhs_blocks, 256, 0, s>>>(e->d.S, e->d.LL, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles, V, W, Wf,
+        k_chol_step<<<n_stiles + n_rhs_blocks, 256, 0, s>>>(e->d.S, e->d.LL, LLf, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles, V, W, Wf,
                                                             ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr, e->d.zvec, e->d.Bc);
         if (k % INV_CH != INV_CH - 1 && k != nbk - 1) continue;
-        // the chunk's panels are factorised (launch k published inv(L_kk) one launch earlier and stored column k of L):
-        // its rows of inv(L) and of B follow on the side stream while the sweep goes on
-        hipEvent_t ev = e->chunk_event(chunk);
-        (void)hipEventRecord(ev, s);
-        (void)hipStreamWaitEvent(su, ev, 0);
-        const int a_first = chunk * INV_CH, a_count = min(INV_CH, nbk - a_first);
-        if (a_first + a_count - 1 >= 1)
-            k_inv_rows<<<a_first + a_count - 1, 256, 0, su>>>(e->d.LL, ldS, V, W, Wf, ldw, a_first, a_count);
-        {   // B rows of the chunk = W' G restricted to these rows: k <= row (W upper triangular)
-            XtyArgs g{};
-            g.X = e->f32 ? (const void *)Wf : (const void *)W; g.ldx = ldw;
-            g.Y = G; g.ldy = ld;
-            g.C = A; g.ldc = ld;
-            g.M = m_pad; g.N = n_pad; g.K = m_pad;
-            g.row0_first = 0; g.row0_stride = 0; g.m_lim = m_pad;
-            g.tri = 2;
-            g.ti_first = a_first * NB / TM;
-            g.tiles_i = (a_count * NB + TM - 1) / TM;
-            g.tiles_j = (n_pad + TM - 1) / TM; g.alpha = 1.0;
-            g.n_split = g.tiles_i; // half units: twice the workgroups on what is a 47-tile launch at N = 1000
-            launch_xty(e, g, 1, e->f32, su);
-        }
-        ++chunk;
+        // the chunk's panels are factorised (inv(L_kk) published one launch earlier, column k of L stored by launch k)
+        const int c = k / INV_CH;
+        (void)hipEventRecord(e->chunk_event(c), s);
+        if (c > 0) side_chunk(c - 1);
     }
+    side_chunk(n_chunks - 1);
     (void)hipEventRecord(e->ev_b_done, su);
     {   // dx and the state update: not needed by the downdate, concurrent with it
-        dim3 grid((n + 255) / 256, DX_SPLIT);
         const double *Bc = nullptr;
         const T *Gy = nullptr;
         if (sizeof(T) == 4) {
             Bc = e->d.Bc; // inv(L) Gc, produced by the right-hand-side blocks of k_chol_step
-            k_yvec<<<(m + 3) / 4, 256, 0, su>>>(W, ldw, m, e->d.zvec, e->d.yvec);
             Gy = G;
+            (void)hipMemcpyAsync(e->d.zwork, e->d.zvec, (size_t)m_pad * sizeof(double), hipMemcpyDeviceToDevice, su);
+            for (int c = n_chunks - 1; c >= 0; --c) {
+                const int r0 = c * CH, rows = min(CH, m_pad - r0);
+                k_ystep<<<max(1, (r0 + 255) / 256), 256, 0, su>>>(W, ldw, e->d.LL, ldS, m_pad, r0, rows, e->d.zwork, e->d.yvec);
+            }
         }
+        dim3 grid((n + 255) / 256, DX_SPLIT);
         k_dx_partial<T><<<grid, 256, 0, su>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, fix ? e->d.sq_part : nullptr,
                                               fix ? e->d.cam_part : nullptr, Bc, Gy, e->d.yvec);
         const int nt = max(e->N * 6, 1);
