@@ -6,9 +6,11 @@ ellipse-gated matching, 1-point RANSAC, low-innovation update, outlier rescue, h
 keypoints/descriptors that are already resident in HBM when the timed region starts.
 
 N = 1 (default) runs the workload the north-star target is quoted on: synthetic 640x480, N = 1000 inverse-depth
-features, fp32 covariance (BASELINE.json configs[2]).  For --gpus N > 1 the path runs as N independent replicas of
-that workload, one process per GPU (at this map size the path is "replicas only"; the row-sharded
-variant is for N >= 2000); value is the whole-job aggregate.
+features, fp32 covariance (BASELINE.json configs[2]).  --gpus G > 1 runs ONE filter row-sharded over the G ranks
+ on the configuration BASELINE.json names for that GPU count -- 2 or 4 GPUs: configs[3] (N = 2000,
+1280x720), 8 GPUs: configs[4] (N = 5000, 1920x1080) -- with the exchange inside the engine (RCCL send/recv on the engine's
+stream); scaling "strong", value = frames of that one filter per second, and rank 0 also times the SAME workload on one
+GPU for the ratio.  `--mode replicas` runs G independent filters instead (the N <= 1000 sizes do not shard).
 
 Prints ONE JSON line (rank 0).
 """
@@ -177,10 +179,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="n1000_f32", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
-                    help="N > 1: independent replicas (default; the path does not shard at N <= 1000) or ONE filter "
-                         "row-sharded over the ranks (SURVEY 8(e), meant for N >= 2000)")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: n1000_f32 on one GPU; n2000_f32 on 2 or 4 GPUs; n5000_f32 on 8 GPUs")
+    ap.add_argument("--mode", default="auto", choices=["auto", "replicas", "sharded"],
+                    help="G > 1: ONE filter row-sharded over the ranks (auto / sharded; SURVEY 8(e)) or G independent "
+                         "replicas (replicas: what the path is at N <= 1000)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "callback"],
+                    help="sharded exchange: RCCL send/recv inside the engine on its stream (default) or the host callback "
+                         "over torch.distributed (the round-1 path, kept for comparison)")
+    ap.add_argument("--no-single-gpu-reference", action="store_true",
+                    help="sharded runs: skip the one-GPU timing of the same workload on rank 0")
     ap.add_argument("--emulate-shards", type=int, default=0,
                     help="functional check on ONE GPU: run the sharded filter with this many ranks in one process "
                          "(device-to-device exchange); not a scaling number")
@@ -204,6 +212,10 @@ def main():
     from openekfmonoslam_amd import engine
     from openekfmonoslam_amd.synth import SyntheticSequence
 
+    if args.workload is None:
+        args.workload = "n1000_f32" if (world == 1 or args.mode == "replicas") else ("n5000_f32" if world >= 8 else "n2000_f32")
+    if args.mode == "auto":
+        args.mode = "sharded" if world > 1 else "replicas"
     N, W, H, precision, dtype = WORKLOADS[args.workload]
     n_frames = args.warmup + args.steps
     seq = SyntheticSequence(N, n_frames, width=W, height=H)
@@ -220,7 +232,14 @@ def main():
             e.upload_frames(seq.frames)
     else:
         eng = engine.EkfEngine(seq.cam, seq.par, N, shard=(rank, world) if sharded else None, **kw)
-        if sharded:
+        if sharded and args.transport == "rccl":
+            # the engine's own communicator: rank 0 draws the id, torch.distributed only carries those 128 bytes
+            uid = torch.zeros(128, dtype=torch.uint8, device=ranks.device if ranks.dist.get_backend() == "nccl" else "cpu")
+            if rank == 0:
+                uid.copy_(torch.from_numpy(engine.comm_unique_id()))
+            ranks.dist.broadcast(uid, src=0)
+            eng.comm_init(uid.cpu().numpy())
+        elif sharded:
             from openekfmonoslam_amd.shard import DistributedExchange
 
             eng.set_exchange(DistributedExchange(ranks.dist, ranks.device))
@@ -306,6 +325,25 @@ def main():
         stages = {k: getattr(tm, k) / st for k in ("prediction_ms", "matching_ms", "ransac_ms", "update_li_ms",
                                                    "rescue_ms", "update_hi_ms")}
 
+    single_ref = None
+    if sharded and not args.no_single_gpu_reference:
+        if rank == 0:  # the SAME workload on one GPU (this rank's), for the strong-scaling ratio
+            e1 = engine.EkfEngine(seq.cam, seq.par, N, **kw)
+            e1.upload_frames(seq.frames)
+            e1.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+            for t in range(args.warmup):
+                e1.step_frame(t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in range(args.warmup, n_frames):
+                e1.step_frame(t)
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t0
+            e1.close()
+            single_ref = {"value": args.steps / dt1, "unit": "EKF updates/s", "ms_per_step": 1e3 * dt1 / args.steps,
+                          "note": "the same workload, steps and warm-up on ONE GPU (rank 0's), unsharded engine, measured "
+                                  "after the sharded run in the same process"}
+        ranks.barrier()
     if rank != 0:
         ranks.close()
         return
@@ -317,7 +355,9 @@ def main():
         par_desc = (f"{emulate} row shards of ONE filter emulated on ONE GPU (device-to-device exchange; functional "
                     "check, not a scaling number)")
     elif sharded:
-        par_desc = f"ONE filter row-sharded over {world} GPUs (camera rows replicated, H.P row blocks all-gathered over RCCL)"
+        par_desc = (f"ONE filter row-sharded over {world} GPUs (camera rows replicated, H.P row blocks exchanged "
+                    + ("by RCCL send/recv inside the engine, on its stream)" if args.transport == "rccl" else
+                       "through the host callback over torch.distributed)"))
     else:
         par_desc = f"{world} independent replicas (path does not shard at this N)"
     out = {
@@ -349,6 +389,8 @@ def main():
         "roofline": roof,
         "stage_ms_per_step": stages,
     }
+    if single_ref is not None:
+        out["single_gpu_same_workload"] = single_ref
     if world == 1 and not group and not ncc and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(seq, args.workload, eng, 1e-5 if precision else 1e-9)
     else:

@@ -249,6 +249,15 @@ enum { EKF_XCHG_HP = 0, EKF_XCHG_PRED_S = 1, EKF_XCHG_HPC = 2 };
  * rank's table holds every rank's rows (0 = ok).  It is called with the engine's stream idle. */
 int ekf_engine_create_sharded(const EkfEngineConfig *cfg, int rank, int world, EkfEngine **out);
 int ekf_set_exchange(EkfEngine *e, EkfExchangeFn fn, void *user);
+/* In-engine transport, one process per GPU: an RCCL communicator owned by the engine.  The exchange is then a grouped
+ * ncclSend / ncclRecv of the row blocks between every pair of ranks (the direct schedule for point-to-point xGMI: every
+ * rank's block travels over its own link to each peer), enqueued on the engine's stream -- no stream drain, no host
+ * callback.  Rank 0 obtains the id, the host distributes it (any out-of-band channel), every rank calls
+ * ekf_comm_init (collective).  RCCL is loaded at run time (librccl.so.1); EKF_ERR_COMM if it is not there.
+ * A communicator takes precedence over a callback installed with ekf_set_exchange. */
+#define EKF_COMM_ID_BYTES 128
+int ekf_comm_unique_id(uint8_t id[EKF_COMM_ID_BYTES]);
+int ekf_comm_init(EkfEngine *e, const uint8_t id[EKF_COMM_ID_BYTES]);
 /* P rows held by this rank: [*row_begin, *row_end) of the state (rank 0's range starts at 0: the camera rows,
  * which every rank also keeps).  On a sharded engine ekf_set_state takes the full n x n matrix and keeps its rows;
  * ekf_get_state fills only those rows of the caller's n x n buffer (camera rows + owned rows). */

@@ -9,6 +9,9 @@
 #include <cstring>
 #include <new>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types only: the library is loaded at run time (rccl_api)
+
 using namespace ekf;
 
 namespace ekf {
@@ -25,6 +28,44 @@ void launch_outlier_idx(EkfEngine *e, const EkfMatch *src, int M, int *idx);
             return EKF_ERR_HIP;                                                                               \
         }                                                                                                     \
     } while (0)
+
+// RCCL entry points used by the sharded engine, resolved from librccl.so.1 on first use (the same library
+// torch.distributed's "nccl" backend has loaded, when the host is PyTorch)
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+static RcclApi &rccl_api()
+{
+    static RcclApi api;
+    if (api.lib) return api;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (api.lib) break;
+    }
+    if (!api.lib) return api;
+#define RCCL_SYM(field, sym) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, sym))
+    RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+    RCCL_SYM(CommInitRank, "ncclCommInitRank");
+    RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    RCCL_SYM(GroupStart, "ncclGroupStart");
+    RCCL_SYM(GroupEnd, "ncclGroupEnd");
+    RCCL_SYM(Send, "ncclSend");
+    RCCL_SYM(Recv, "ncclRecv");
+    RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RCCL_SYM
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Send && api.Recv;
+    return api;
+}
 
 template <typename T>
 static hipError_t dalloc(T **p, size_t count, bool zero = true)
@@ -65,6 +106,7 @@ void ekf_engine_destroy(EkfEngine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->stream_u) (void)hipStreamSynchronize(e->stream_u);
+    if (e->stream_v) (void)hipStreamSynchronize(e->stream_v);
     DeviceArrays &d = e->d;
     void *ptrs[] = {d.state,     d.feat_pos,  d.feat_type, d.feat_covpos, d.feat_desc, d.feat_times_predicted, d.feat_times_matched, d.P, d.P2, d.mm_scratch, d.mm_index,        d.pred_vis, d.pred_vis_full, d.step_preds,
                     d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,
@@ -83,10 +125,14 @@ void ekf_engine_destroy(EkfEngine *e)
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
+    if (e->comm && rccl_api().ok) (void)rccl_api().CommDestroy((ncclComm_t)e->comm);
     if (e->h_mirror) (void)hipHostFree(e->h_mirror);
     if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
     if (e->stream_u) { (void)hipStreamSynchronize(e->stream_u); (void)hipStreamDestroy(e->stream_u); }
+    if (e->stream_v) { (void)hipStreamSynchronize(e->stream_v); (void)hipStreamDestroy(e->stream_v); }
     for (auto ev : e->ev_chunks)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto ev : e->ev_invs)
         if (ev) (void)hipEventDestroy(ev);
     if (e->ev_b_done) (void)hipEventDestroy(e->ev_b_done);
     if (e->ev_dx_done) (void)hipEventDestroy(e->ev_dx_done);
@@ -139,7 +185,13 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     if ((st = hipSetDevice(e->device)) != hipSuccess) return fail(st, "hipSetDevice");
     if ((st = hipStreamCreate(&e->stream)) != hipSuccess) return fail(st, "hipStreamCreate");
     if ((st = hipStreamCreate(&e->stream2)) != hipSuccess) return fail(st, "hipStreamCreate");
-    if ((st = hipStreamCreate(&e->stream_u)) != hipSuccess) return fail(st, "hipStreamCreate");
+    {   // the side streams of the update carry short dependent launches that must not queue behind the downdate's
+        // workgroups (measured: a 3 us launch waited 40-150 us for a slot at equal priority): highest priority
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if ((st = hipStreamCreateWithPriority(&e->stream_u, hipStreamNonBlocking, hi)) != hipSuccess) return fail(st, "hipStreamCreate");
+        if ((st = hipStreamCreateWithPriority(&e->stream_v, hipStreamNonBlocking, hi)) != hipSuccess) return fail(st, "hipStreamCreate");
+    }
     if ((st = hipEventCreateWithFlags(&e->ev_b_done, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
     if ((st = hipEventCreateWithFlags(&e->ev_dx_done, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
     if ((st = hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
@@ -265,6 +317,80 @@ int ekf_set_exchange(EkfEngine *e, EkfExchangeFn fn, void *user)
     if (!e) return EKF_ERR_INVALID_ARG;
     e->xchg = fn;
     e->xchg_user = user;
+    return EKF_OK;
+}
+
+int ekf_comm_unique_id(uint8_t id[EKF_COMM_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) == EKF_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    if (!id) return EKF_ERR_INVALID_ARG;
+    RcclApi &api = rccl_api();
+    if (!api.ok) return EKF_ERR_COMM;
+    ncclUniqueId u;
+    if (api.GetUniqueId(&u) != ncclSuccess) return EKF_ERR_COMM;
+    std::memcpy(id, &u, EKF_COMM_ID_BYTES);
+    return EKF_OK;
+}
+
+int ekf_comm_init(EkfEngine *e, const uint8_t id[EKF_COMM_ID_BYTES])
+{
+    if (!e || !id) return EKF_ERR_INVALID_ARG;
+    RcclApi &api = rccl_api();
+    if (!api.ok) {
+        e->err = "librccl.so.1 could not be loaded";
+        return EKF_ERR_COMM;
+    }
+    HIPCHK(hipSetDevice(e->device));
+    if (e->comm) {
+        (void)api.CommDestroy((ncclComm_t)e->comm);
+        e->comm = nullptr;
+    }
+    ncclUniqueId u;
+    std::memcpy(&u, id, EKF_COMM_ID_BYTES);
+    ncclComm_t c = nullptr;
+    const ncclResult_t r = api.CommInitRank(&c, e->shard_world, u, e->shard_rank);
+    if (r != ncclSuccess) {
+        e->err = std::string("ncclCommInitRank: ") + (api.GetErrorString ? api.GetErrorString(r) : "error");
+        return EKF_ERR_COMM;
+    }
+    e->comm = c;
+    return EKF_OK;
+}
+
+// Completes a replicated per-feature table: rank r owns rows [rb[r], rb[r+1]) of row_bytes each and has just written
+// them (on the engine's stream).  In-engine transport: every pair of ranks exchanges its blocks directly, enqueued on the
+// same stream; otherwise the host's callback (which needs the stream idle).
+static int exchange_rows(EkfEngine *e, int what, void *base, size_t row_bytes, const std::vector<int32_t> &rb, const char *name)
+{
+    const int world = e->shard_world, me = e->shard_rank;
+    if (e->comm) {
+        RcclApi &api = rccl_api();
+        ncclComm_t c = (ncclComm_t)e->comm;
+        uint8_t *b = (uint8_t *)base;
+        const size_t my_lo = (size_t)rb[me] * row_bytes, my_n = (size_t)(rb[me + 1] - rb[me]) * row_bytes;
+        ncclResult_t r = api.GroupStart();
+        for (int p = 0; p < world && r == ncclSuccess; ++p) {
+            if (p == me) continue;
+            const size_t lo = (size_t)rb[p] * row_bytes, cnt = (size_t)(rb[p + 1] - rb[p]) * row_bytes;
+            if (my_n > 0) r = api.Send(b + my_lo, my_n, ncclChar, p, c, e->stream);
+            if (r == ncclSuccess && cnt > 0) r = api.Recv(b + lo, cnt, ncclChar, p, c, e->stream);
+        }
+        const ncclResult_t r2 = api.GroupEnd();
+        if (r != ncclSuccess || r2 != ncclSuccess) {
+            e->err = std::string("RCCL exchange of ") + name + " failed";
+            return EKF_ERR_COMM;
+        }
+        return EKF_OK;
+    }
+    if (!e->xchg) {
+        e->err = "sharded engine without a transport (ekf_comm_init or ekf_set_exchange)";
+        return EKF_ERR_COMM;
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->xchg(e->xchg_user, what, base, row_bytes, rb.data(), world, me)) {
+        e->err = std::string("exchange of ") + name + " failed";
+        return EKF_ERR_COMM;
+    }
     return EKF_OK;
 }
 
@@ -739,26 +865,12 @@ static int predict_measurements_dev(EkfEngine *e, const int *d_idx, int count, i
     *n_out = np;
     if (e->shard_world > 1 && np > 0) {
         // every rank wrote the H.P rows and S_i of the features it owns: complete both tables
-        if (!e->xchg) {
-            e->err = "sharded engine without an exchange callback (ekf_set_exchange)";
-            return EKF_ERR_COMM;
-        }
-        HIPCHK(hipStreamSynchronize(e->stream));
         std::vector<int32_t> rb(e->shard_world + 1);
         for (int r = 0; r <= e->shard_world; ++r) rb[r] = 2 * e->shard_feat_begin[r];
-        if (e->xchg(e->xchg_user, EKF_XCHG_HP, e->d.HP, (size_t)e->ldP * (e->f32 ? 4 : 8), rb.data(), e->shard_world, e->shard_rank)) {
-            e->err = "exchange of the H.P row blocks failed";
-            return EKF_ERR_COMM;
-        }
-        if (e->f32 && e->xchg(e->xchg_user, EKF_XCHG_HPC, e->d.HPc, 16 * sizeof(double), rb.data(), e->shard_world, e->shard_rank)) {
-            e->err = "exchange of the fp64 camera columns of H.P failed";
-            return EKF_ERR_COMM;
-        }
+        if ((rc = exchange_rows(e, EKF_XCHG_HP, e->d.HP, (size_t)e->ldP * (e->f32 ? 4 : 8), rb, "the H.P row blocks"))) return rc;
+        if (e->f32 && (rc = exchange_rows(e, EKF_XCHG_HPC, e->d.HPc, 16 * sizeof(double), rb, "the fp64 camera columns of H.P"))) return rc;
         for (int r = 0; r <= e->shard_world; ++r) rb[r] = e->shard_feat_begin[r];
-        if (e->xchg(e->xchg_user, EKF_XCHG_PRED_S, e->d.pred_S, 4 * sizeof(double), rb.data(), e->shard_world, e->shard_rank)) {
-            e->err = "exchange of the innovation covariance blocks failed";
-            return EKF_ERR_COMM;
-        }
+        if ((rc = exchange_rows(e, EKF_XCHG_PRED_S, e->d.pred_S, 4 * sizeof(double), rb, "the innovation covariance blocks"))) return rc;
     }
     if (!d_idx && e->keep_step_preds) { // EKF.cpp:294-305 draws the step's predictions as they were BEFORE the updates
         launch_pack_predictions(e, e->d.plist, np, e->d.step_preds);

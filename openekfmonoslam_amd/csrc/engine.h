@@ -168,6 +168,7 @@ struct EkfEngine {
     ekf::RowMap rm{13, 13, 13};          // refreshed by set_state / map management
     std::vector<int> shard_feat_begin;   // [world + 1] first feature of each rank
     EkfExchangeFn xchg = nullptr;        // all-gather of per-feature row blocks between the ranks
+    void *comm = nullptr;                // ncclComm_t of the in-engine transport (ekf_comm_init), or null
     void *xchg_user = nullptr;
     bool p_exact_sym = false; // P known to be bitwise symmetric (engine-maintained invariant)
     int n_pred = 0;           // predictions of the last full prediction
@@ -181,18 +182,22 @@ struct EkfEngine {
     int pu_per_xcd = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // image-only work of the next frame, overlapped with the update
-    hipStream_t stream_u = nullptr;            // update: inverse / B chunks behind the sweep, dx beside the downdate
-    std::vector<hipEvent_t> ev_chunks;         // main -> side stream, one per chunk of the sweep
+    hipStream_t stream_u = nullptr;            // update: forward substitution B = inv(L) G, chunk by chunk behind the sweep
+    hipStream_t stream_v = nullptr;            // update: diagonal-block inverses behind the sweep; y, dx, state beside the downdate
+    std::vector<hipEvent_t> ev_chunks;         // main -> side streams, one per chunk of the sweep
+    std::vector<hipEvent_t> ev_invs;           // stream_v -> stream_u, one per chunk
     hipEvent_t ev_b_done = nullptr, ev_dx_done = nullptr;
-    hipEvent_t chunk_event(int i)
+    static hipEvent_t pooled_event(std::vector<hipEvent_t> &pool, int i)
     {
-        while ((int)ev_chunks.size() <= i) {
+        while ((int)pool.size() <= i) {
             hipEvent_t ev = nullptr;
             (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-            ev_chunks.push_back(ev);
+            pool.push_back(ev);
         }
-        return ev_chunks[i];
+        return pool[i];
     }
+    hipEvent_t chunk_event(int i) { return pooled_event(ev_chunks, i); }
+    hipEvent_t inv_event(int i) { return pooled_event(ev_invs, i); }
     hipEvent_t ev_main = nullptr, ev_prefetch = nullptr;
     ekf::DeviceArrays d;
     ekf::Frames frames;

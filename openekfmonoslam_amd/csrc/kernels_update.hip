@@ -637,18 +637,19 @@ __global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, cons
 // P-update launcher lives in kernels_pupdate.hip
 void launch_p_update(EkfEngine *e, int m_pad);
 
-// One update = two streams.  Main stream: gather, S, the sweep (one launch per 32-wide panel), then the downdate and its
-// tail.  Side stream (e->stream_u), chunk by chunk (4 panels = 128 rows) behind the sweep, B = inv(L) G by blocked forward
-// substitution on the working copy R of G:
-//     X_cc = inverse of the chunk's 128 x 128 diagonal block of L      (k_inv_rows on the chunk's own columns)
-//     B_c  = X_cc R_c                                                  (k_xty, k inside the chunk)
-//     R_below -= L_below,c B_c                                         (k_xty accumulate, X operand = the mirrored L')
-// -- the big GEMM (the update of the rows below) of chunk c runs while the sweep factorises chunk c + 1, so when the sweep
-// ends only the last chunk's small diagonal pieces are left (the previous form, inverse of the whole factor by doubling
-// then one GEMM, put 12 + 1 dependent launches, ~200 us at m = 1000, behind the sweep).  After the last chunk, off the
-// downdate's critical path and concurrent with it: y = inv(L)' z by blocked backward substitution, dx, the state update.
-// The downdate waits for B; its tail (k_diag_fix needs the fp64 sums of k_dx_partial, k_normalize_cov the Jacobian
-// k_state_apply leaves) waits for dx.
+// One update = three streams.  Main stream: gather, S, the sweep (one launch per 32-wide panel), then the downdate and
+// its tail.  Behind the sweep, chunk by chunk (4 panels = 128 rows), B = inv(L) G by blocked forward substitution on the
+// working copy R of G:
+//   stream_v   X_cc = inverse of the chunk's 128 x 128 diagonal block of L     (k_inv_rows on the chunk's own columns)
+//   stream_u   B_c  = X_cc R_c                                                 (k_xty, k inside the chunk)
+//              even chunk: R_{c+1} -= L_{c+1,c} B_c                            (the next chunk only, k = 128)
+//              odd chunk : R_below -= L_below,{c-1,c} B_{c-1,c}                (all rows below, k = 256: one pass over R per
+//                          PAIR of chunks -- with k = 128 the pass is bound by its reads and writes of R, not by the MFMAs)
+// so the big GEMMs run while the sweep factorises the following chunks and only the last chunk's small pieces are left
+// when it ends (the previous form -- inverse of the whole factor by doubling, then one GEMM -- put 12 + 1 dependent
+// launches, ~200 us at m = 1000, behind the sweep).  After the sweep, off the downdate's critical path and concurrent
+// with it (stream_v): y = inv(L)' z by blocked backward substitution, dx, the state update.  The downdate waits for B;
+// its tail (k_diag_fix needs the fp64 sums of k_dx_partial, k_normalize_cov the Jacobian k_state_apply leaves) for dx.
 template <typename T>
 static void update_impl(EkfEngine *e, int M, bool update_cov)
 {
@@ -681,11 +682,14 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     const int TM = sizeof(T) == 4 ? 128 : 64;
     constexpr int CH = INV_CH * NB; // rows per chunk
     // side-stream work of one chunk; issued one chunk late in HOST order so that the main queue never waits for the host
+    hipStream_t sv = e->stream_v;
     auto side_chunk = [&](int c) {
-        (void)hipStreamWaitEvent(su, e->chunk_event(c), 0);
         const int a_first = c * INV_CH, a_count = min(INV_CH, nbk - a_first);
         const int r0 = a_first * NB, rows = a_count * NB;
-        if (a_count > 1) k_inv_rows<<<a_count - 1, 256, 0, su>>>(e->d.LL, ldS, V, W, Wf, ldw, a_first, a_count, a_first);
+        (void)hipStreamWaitEvent(sv, e->chunk_event(c), 0);
+        if (a_count > 1) k_inv_rows<<<a_count - 1, 256, 0, sv>>>(e->d.LL, ldS, V, W, Wf, ldw, a_first, a_count, a_first);
+        (void)hipEventRecord(e->inv_event(c), sv);
+        (void)hipStreamWaitEvent(su, e->inv_event(c), 0);
         XtyArgs g{};
         g.ldy = ld; g.ldc = ld;
         g.M = m_pad; g.N = n_pad;
@@ -698,14 +702,21 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         g.ti_first = r0 / TM; g.tiles_i = (rows + TM - 1) / TM; g.n_split = g.tiles_i;
         g.alpha = 1.0; g.accumulate = 0;
         launch_xty(e, g, 1, e->f32, su);
-        if (r0 + rows < m_pad) { // R_below -= L_below,c B_c : X operand = L' (mirrored part of LL, k-major), k = the chunk's rows
-            g.X = e->f32 ? (const void *)LLf : (const void *)e->d.LL; g.ldx = ldS;
-            g.Y = A; g.C = R;
-            g.tri = 0; g.k_first = r0; g.K = r0 + rows;
-            g.ti_first = (r0 + rows) / TM; g.tiles_i = (m_pad - (r0 + rows) + TM - 1) / TM; g.n_split = 0;
-            g.alpha = -1.0; g.accumulate = 1;
-            launch_xty(e, g, 1, e->f32, su);
+        const int below = r0 + rows; // first row below the chunk
+        if (below >= m_pad) return;
+        // R -= L B : X operand = L' (mirrored part of LL, k-major)
+        g.X = e->f32 ? (const void *)LLf : (const void *)e->d.LL; g.ldx = ldS;
+        g.Y = A; g.C = R;
+        g.tri = 0; g.alpha = -1.0; g.accumulate = 1;
+        g.ti_first = below / TM;
+        if (c % 2 == 0) { // the next chunk only needs this chunk's term before its own solve
+            g.k_first = r0; g.K = below;
+            g.tiles_i = (min(CH, m_pad - below) + TM - 1) / TM; g.n_split = g.tiles_i;
+        } else {          // everything below the pair: the terms of both chunks in one pass
+            g.k_first = r0 - CH; g.K = below;
+            g.tiles_i = (m_pad - below + TM - 1) / TM; g.n_split = 0;
         }
+        launch_xty(e, g, 1, e->f32, su);
     };
     for (int k = 0; k < nbk; ++k) {
         const int k0 = k * NB;
@@ -724,26 +735,27 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     }
     side_chunk(n_chunks - 1);
     (void)hipEventRecord(e->ev_b_done, su);
-    {   // dx and the state update: not needed by the downdate, concurrent with it
+    {   // y, dx and the state update: not needed by the downdate, concurrent with it
         const double *Bc = nullptr;
         const T *Gy = nullptr;
         if (sizeof(T) == 4) {
             Bc = e->d.Bc; // inv(L) Gc, produced by the right-hand-side blocks of k_chol_step
             Gy = G;
-            (void)hipMemcpyAsync(e->d.zwork, e->d.zvec, (size_t)m_pad * sizeof(double), hipMemcpyDeviceToDevice, su);
+            (void)hipMemcpyAsync(e->d.zwork, e->d.zvec, (size_t)m_pad * sizeof(double), hipMemcpyDeviceToDevice, sv);
             for (int c = n_chunks - 1; c >= 0; --c) {
                 const int r0 = c * CH, rows = min(CH, m_pad - r0);
-                k_ystep<<<max(1, (r0 + 255) / 256), 256, 0, su>>>(W, ldw, e->d.LL, ldS, m_pad, r0, rows, e->d.zwork, e->d.yvec);
+                k_ystep<<<max(1, (r0 + 255) / 256), 256, 0, sv>>>(W, ldw, e->d.LL, ldS, m_pad, r0, rows, e->d.zwork, e->d.yvec);
             }
         }
+        (void)hipStreamWaitEvent(sv, e->ev_b_done, 0);
         dim3 grid((n + 255) / 256, DX_SPLIT);
-        k_dx_partial<T><<<grid, 256, 0, su>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, fix ? e->d.sq_part : nullptr,
+        k_dx_partial<T><<<grid, 256, 0, sv>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, fix ? e->d.sq_part : nullptr,
                                               fix ? e->d.cam_part : nullptr, Bc, Gy, e->d.yvec);
         const int nt = max(e->N * 6, 1);
-        k_state_apply<<<(nt + 255) / 256, 256, 0, su>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
+        k_state_apply<<<(nt + 255) / 256, 256, 0, sv>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
                                                         e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
     }
-    (void)hipEventRecord(e->ev_dx_done, su);
+    (void)hipEventRecord(e->ev_dx_done, sv);
     if (!update_cov) {
         (void)hipStreamWaitEvent(s, e->ev_dx_done, 0);
         return;

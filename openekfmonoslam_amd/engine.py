@@ -100,6 +100,8 @@ ABI = {
     "ekf_shard_rows": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "ekf_engine_create_sharded": (_i, [C.POINTER(EkfEngineConfig), _i, _i, C.POINTER(_vp)]),
     "ekf_set_exchange": (_i, [_vp, _vp, _vp]),
+    "ekf_comm_unique_id": (_i, [_vp]),
+    "ekf_comm_init": (_i, [_vp, _vp]),
     "ekf_shard_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "ekf_device_copy": (_i, [_vp, _vp, _vp, C.c_size_t]),
 }
@@ -152,6 +154,15 @@ def shard_rows(n_features, world, rank):
     return lo.value, hi.value
 
 
+def comm_unique_id():
+    """128-byte RCCL unique id (rank 0 of a sharded filter creates it, the host distributes it to every rank)."""
+    buf = np.zeros(128, dtype=np.uint8)
+    rc = load_library().ekf_comm_unique_id(_p(buf))
+    if rc:
+        raise EkfError(rc, "ekf_comm_unique_id (librccl.so.1 not loadable?)")
+    return buf
+
+
 class EkfEngine:
     """One device-resident filter (state, covariance, map, per-frame tables) on one MI355X."""
 
@@ -202,6 +213,12 @@ class EkfEngine:
 
         self._xchg_ref = EXCHANGE_FN(tramp)
         self._chk(self.L.ekf_set_exchange(self.h, C.cast(self._xchg_ref, _vp), None))
+
+    def comm_init(self, unique_id):
+        """collective over the ranks of a sharded filter: the engine's own RCCL communicator (in-stream exchange)"""
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        assert uid.size == 128
+        self._chk(self.L.ekf_comm_init(self.h, _p(uid)))
 
     def shard_info(self):
         r, w, lo, hi = _i(0), _i(1), _i(0), _i(0)

@@ -115,3 +115,27 @@ def test_sharded_engine_needs_an_exchange(eng_mod):
     with pytest.raises(eng_mod.EkfError) as ei:
         e.predict_measurements()
     assert ei.value.code == 7  # EKF_ERR_COMM
+
+
+def test_engine_owned_rccl_communicator_loads_and_runs(eng_mod):
+    """ekf_comm_unique_id / ekf_comm_init: the engine's own RCCL communicator (what `bench.py --gpus G` uses).  One GPU
+    allows one rank, so this pins library loading, communicator creation/destruction and that a world-1 sharded engine
+    with a communicator steps exactly like the unsharded engine; the >1-rank exchange itself (grouped ncclSend/ncclRecv
+    of the same row blocks the callback path moves) needs the multi-GPU node."""
+    seq = SyntheticSequence(50, 3)
+    uid = eng_mod.comm_unique_id()
+    assert uid.shape == (128,) and uid.any()
+    e = eng_mod.EkfEngine(seq.cam, seq.par, 50, max_keypoints=264, shard=(0, 1))
+    e.comm_init(uid)
+    ref = eng_mod.EkfEngine(seq.cam, seq.par, 50, max_keypoints=264)
+    for g in (e, ref):
+        g.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, _sym(seq.P0))
+    for t in range(3):
+        a, b = e.step(*seq.frames[t]), ref.step(*seq.frames[t])
+        for f in INFO_FIELDS:
+            assert getattr(a, f) == getattr(b, f)
+    xa, fa, Pa = e.get_state()
+    xb, fb, Pb = ref.get_state()
+    np.testing.assert_array_equal(xa, xb)
+    np.testing.assert_array_equal(Pa, Pb)
+    e.close()
