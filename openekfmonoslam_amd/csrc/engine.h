@@ -180,6 +180,7 @@ struct EkfEngine {
     int pu_tilemap_nt = -1;
     std::map<int, std::pair<void *, int>> pu_tables; // built work lists of the downdate: key -> (device list, units per XCD)
     int pu_per_xcd = 0;
+    bool pu_atomic = false; // downdate epilogue by no-return atomics (EKF_PU_ATOMIC=1)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // image-only work of the next frame, overlapped with the update
     hipStream_t stream_u = nullptr;            // update: forward substitution B = inv(L) G, chunk by chunk behind the sweep

@@ -421,20 +421,24 @@ k_inv_rows(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, 
 
 // ------------------------------------------------------------------------------------------------- dx = B' z
 // y = inv(L)' z by blocked BACKWARD substitution, one launch per 128-row chunk J from the last to the first:
-//     y_J = X_JJ' zw_J   (X_JJ = inv of the chunk's diagonal block of L, rows of W = X' are contiguous),
-//     zw_r -= sum_{k in J} L[k][r] y_k   for the rows r above the chunk (row r of the mirrored L' in LL is contiguous in k).
-// Every workgroup forms y_J itself (128 x 128 MACs); workgroup b then updates rows 256 b ... of the working vector.  Needs
-// only the diagonal-block inverses, so the inverse of the whole factor is never formed; runs beside the downdate.
+//     y_J = X_JJ' zw_J                       (X_JJ = inverse of the chunk's diagonal block of L, rows of V),
+//     zw_r -= sum_{k in J} L[k][r] y_k        for the rows r above the chunk.
+// Both sums run over the ROWS k of row-major matrices (V = inv(L), the lower part of LL = L) with the lanes on
+// consecutive columns, so every load is a coalesced row segment.  Every workgroup forms y_J itself (128 x 128 MACs);
+// workgroup b then updates rows 256 b ... of the working vector.  Needs only the diagonal-block inverses, so the inverse
+// of the whole factor is never formed; runs beside the downdate.
 __global__ void __launch_bounds__(256)
-k_ystep(const double *W, int ldw, const double *LL, int ldS, int m_pad, int r0, int rows, double *zw, double *y)
+k_ystep(const double *V, int ldw, const double *LL, int ldS, int r0, int rows, double *zw, double *y)
 {
-    __shared__ double sy[128];
+    __shared__ double sz[128], sy[128];
     const int tid = threadIdx.x;
+    if (tid < 128) sz[tid] = tid < rows ? zw[r0 + tid] : 0.0;
+    __syncthreads();
     if (tid < 128) {
         double s = 0.0;
         if (tid < rows) {
-            const double *w = W + (size_t)(r0 + tid) * ldw + r0;
-            for (int k = tid; k < rows; ++k) s += w[k] * zw[r0 + k];
+            const double *v = V + (size_t)r0 * ldw + r0 + tid; // X[k][i], k = row
+            for (int k = tid; k < rows; ++k) s += v[(size_t)k * ldw] * sz[k];
         }
         sy[tid] = s;
         if (blockIdx.x == 0 && tid < rows) y[r0 + tid] = s;
@@ -442,10 +446,15 @@ k_ystep(const double *W, int ldw, const double *LL, int ldS, int m_pad, int r0, 
     __syncthreads();
     const int r = blockIdx.x * 256 + tid;
     if (r >= r0) return;
-    const double *l = LL + (size_t)r * ldS + r0;
-    double s = 0.0;
-    for (int k = 0; k < rows; ++k) s += l[k] * sy[k];
-    zw[r] -= s;
+    const double *l = LL + (size_t)r0 * ldS + r; // L[k][r], k = row
+    double s0 = 0.0, s1 = 0.0;
+    int k = 0;
+    for (; k + 1 < rows; k += 2) {
+        s0 += l[(size_t)k * ldS] * sy[k];
+        s1 += l[(size_t)(k + 1) * ldS] * sy[k + 1];
+    }
+    if (k < rows) s0 += l[(size_t)k * ldS] * sy[k];
+    zw[r] -= s0 + s1;
 }
 
 template <typename T>
@@ -744,7 +753,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             (void)hipMemcpyAsync(e->d.zwork, e->d.zvec, (size_t)m_pad * sizeof(double), hipMemcpyDeviceToDevice, sv);
             for (int c = n_chunks - 1; c >= 0; --c) {
                 const int r0 = c * CH, rows = min(CH, m_pad - r0);
-                k_ystep<<<max(1, (r0 + 255) / 256), 256, 0, sv>>>(W, ldw, e->d.LL, ldS, m_pad, r0, rows, e->d.zwork, e->d.yvec);
+                k_ystep<<<max(1, (r0 + 255) / 256), 256, 0, sv>>>(V, ldw, e->d.LL, ldS, r0, rows, e->d.zwork, e->d.yvec);
             }
         }
         (void)hipStreamWaitEvent(sv, e->ev_b_done, 0);
