@@ -180,7 +180,6 @@ struct EkfEngine {
     int pu_tilemap_nt = -1;
     std::map<int, std::pair<void *, int>> pu_tables; // built work lists of the downdate: key -> (device list, units per XCD)
     int pu_per_xcd = 0;
-    bool pu_atomic = false; // downdate epilogue by no-return atomics (EKF_PU_ATOMIC=1)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // image-only work of the next frame, overlapped with the update
     hipStream_t stream_u = nullptr;            // update: forward substitution B = inv(L) G, chunk by chunk behind the sweep
@@ -235,6 +234,7 @@ struct XtyArgs {
     int ti_first;                         // first row tile (a launch may cover a row range of the product)
     int k_first;                          // first k (tri != 1): the k-range is [k_first, K), cut at I0 + TM when tri == 2
     int accumulate;                       // C += alpha X'Y instead of C = alpha X'Y
+    int deep;                             // fp32: 32-deep k-slabs (short k-ranges are bound by the load round trip per slab)
     int n_split;                          // bottom row tiles cut into two half units (tri == 2, batch 1 only)
     double alpha;
 };

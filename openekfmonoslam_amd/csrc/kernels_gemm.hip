@@ -14,7 +14,7 @@ namespace ekf {
 // BK: k-slab depth.  The fp64 instances are small, latency-bound GEMMs (a 64x64 tile's MFMAs of one 16-deep slab take
 // 0.2 us, a global load round trip over 1 us), so they run with 32-deep slabs: half as many round trips.
 template <typename T, int BK>
-__global__ void __launch_bounds__(256, 3) k_xty(XtyArgs a)
+__global__ void __launch_bounds__(256, BK * sizeof(T) >= 128 ? 2 : 3) k_xty(XtyArgs a)
 {
     using M = Mma<T>;
     constexpr int MB = M::MB, TM = 4 * MB, VEC = M::VEC;
@@ -138,7 +138,8 @@ void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32, hipStream_t
     (void)e;
     const int grid = batch * (a.tiles_i + a.n_split) * a.tiles_j;
     if (grid <= 0) return;
-    if (f32) k_xty<float, 16><<<grid, 256, 0, stream>>>(a);
+    if (f32 && a.deep) k_xty<float, 32><<<grid, 256, 0, stream>>>(a);
+    else if (f32) k_xty<float, 16><<<grid, 256, 0, stream>>>(a);
     else k_xty<double, 32><<<grid, 256, 0, stream>>>(a);
 }
 

@@ -21,9 +21,6 @@
 
 namespace ekf {
 
-__device__ __forceinline__ void pu_atomic_add(float *p, float v) { (void)unsafeAtomicAdd(p, v); }
-__device__ __forceinline__ void pu_atomic_add(double *p, double v) { (void)unsafeAtomicAdd(p, v); }
-
 #ifndef PU_MIN_WAVES
 #define PU_MIN_WAVES 3
 #endif
@@ -31,10 +28,7 @@ __device__ __forceinline__ void pu_atomic_add(double *p, double v) { (void)unsaf
 // camera block (13 live rows), tile row t >= 1 holds the owned global rows rm.r0 + (t-1) TM ..., stored from local
 // row rm.base + (t-1) TM; every (row tile, column tile) pair is computed and written in place, nothing is mirrored.
 // Swapping the operands of an MFMA product changes no bit, so P[i][j] here equals P[j][i] on the rank that owns j.
-// ATOMIC (experiment, EKF_PU_ATOMIC=1, fp32 only): the epilogue subtracts with no-return global_atomic_add_f32 instead of
-// load / subtract / store.  Every element of P is touched by exactly one lane of one workgroup, so the result is the same
-// fl(P - acc) bit for bit; the wavefront no longer waits for the 64 KB of P values of its tile.
-template <typename T, bool AVG, bool RECT, bool ATOMIC = false>
+template <typename T, bool AVG, bool RECT>
 __global__ void __launch_bounds__(256, PU_MIN_WAVES)
 k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, const int4 *units, RowMap rm, int stagger)
 {
@@ -147,7 +141,7 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
 #pragma unroll
         for (int y = 0; y < 2; ++y) {
             if (x == 1 && !full) continue;
-            if (!AVG && !ATOMIC && y == 0) {
+            if (!AVG && y == 0) {
 #pragma unroll
                 for (int yy = 0; yy < 2; ++yy) {
                     const int pbi = I0 + rbase + x * MB, pbj = J0 + wc * 2 * MB + yy * MB;
@@ -179,10 +173,7 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
                 const int li = M::row(r, lane), lj = M::col(lane);
                 const int gi = bi + li, gj = bj + lj;
                 T v = (T)0;
-                if (ATOMIC) {
-                    v = -cc[r];
-                    if (gi < ilim && gj < n) pu_atomic_add(&P[(size_t)(gi + p_off) * ldp + gj], v);
-                } else if (gi < ilim && gj < n) {
+                if (gi < ilim && gj < n) {
                     v = pv[y][r] - cc[r];
                     P[(size_t)(gi + p_off) * ldp + gj] = v;
                 }
@@ -196,10 +187,7 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
                     const int c = it * KI + klane; // column of the block = row of the mirror
                     const int gi = bi + idx, gj = bj + c;
                     const T v = sT[idx * (MB + 1) + c];
-                    if (gi < n && gj < n) {
-                        if (ATOMIC) pu_atomic_add(&P[(size_t)gj * ldp + gi], v);
-                        else P[(size_t)gj * ldp + gi] = v;
-                    }
+                    if (gi < n && gj < n) P[(size_t)gj * ldp + gi] = v;
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();
@@ -275,8 +263,6 @@ static void launch_p_update_t(EkfEngine *e, int m_pad, int grid, const int4 *tm,
         k_p_update<T, false, true><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, (m_pad < 512 && grid >= 768) ? 80 : 0);
     else if (avg)
         k_p_update<T, true, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, (m_pad < 512 && grid >= 768) ? 80 : 0);
-    else if (e->pu_atomic && sizeof(T) == 4)
-        k_p_update<T, false, false, true><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, (m_pad < 512 && grid >= 768) ? 80 : 0);
     else
         k_p_update<T, false, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, (m_pad < 512 && grid >= 768) ? 80 : 0);
 }

@@ -423,38 +423,55 @@ k_inv_rows(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, 
 // y = inv(L)' z by blocked BACKWARD substitution, one launch per 128-row chunk J from the last to the first:
 //     y_J = X_JJ' zw_J                       (X_JJ = inverse of the chunk's diagonal block of L, rows of V),
 //     zw_r -= sum_{k in J} L[k][r] y_k        for the rows r above the chunk.
-// Both sums run over the ROWS k of row-major matrices (V = inv(L), the lower part of LL = L) with the lanes on
-// consecutive columns, so every load is a coalesced row segment.  Every workgroup forms y_J itself (128 x 128 MACs);
-// workgroup b then updates rows 256 b ... of the working vector.  Needs only the diagonal-block inverses, so the inverse
+// Every workgroup forms y_J itself (128 x 128 MACs, coalesced rows of W = inv(L)'); workgroup b then updates rows 64 b ...
+// of the working vector (coalesced row segments of L).  The launches are a dependent chain of tiny kernels: what matters
+// is how many loads each lane has in flight, not the flop count (a one-load-per-iteration loop took 20 us per launch).  Needs only the diagonal-block inverses, so the inverse
 // of the whole factor is never formed; runs beside the downdate.
 __global__ void __launch_bounds__(256)
-k_ystep(const double *V, int ldw, const double *LL, int ldS, int r0, int rows, double *zw, double *y)
+k_ystep(const double *W, int ldw, const double *LL, int ldS, int r0, int rows, double *zw, double *y)
 {
-    __shared__ double sz[128], sy[128];
-    const int tid = threadIdx.x;
+    __shared__ double sz[128], sy[128], sp[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < 128) sz[tid] = tid < rows ? zw[r0 + tid] : 0.0;
     __syncthreads();
-    if (tid < 128) {
-        double s = 0.0;
-        if (tid < rows) {
-            const double *v = V + (size_t)r0 * ldw + r0 + tid; // X[k][i], k = row
-            for (int k = tid; k < rows; ++k) s += v[(size_t)k * ldw] * sz[k];
+    // y_J[i] = sum_k W[i][k] zw[k]  (W = inv(L)', its rows contiguous in k, zero for k < i): one wavefront per row, 32 rows
+    // per wavefront, every load of the block in flight before the first reduction
+    {
+        const double z0 = sz[lane], z1 = sz[lane + 64];
+        double part[32];
+#pragma unroll
+        for (int rr = 0; rr < 32; ++rr) {
+            const int i = wv * 32 + rr;
+            const double *w = W + (size_t)(r0 + i) * ldw + r0;
+            part[rr] = (i < rows) ? w[lane] * z0 + w[lane + 64] * z1 : 0.0;
         }
-        sy[tid] = s;
-        if (blockIdx.x == 0 && tid < rows) y[r0 + tid] = s;
+#pragma unroll
+        for (int rr = 0; rr < 32; ++rr) {
+            double s = part[rr];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == 0) {
+                const int i = wv * 32 + rr;
+                sy[i] = s;
+                if (blockIdx.x == 0 && i < rows) y[r0 + i] = s;
+            }
+        }
     }
     __syncthreads();
-    const int r = blockIdx.x * 256 + tid;
-    if (r >= r0) return;
-    const double *l = LL + (size_t)r0 * ldS + r; // L[k][r], k = row
-    double s0 = 0.0, s1 = 0.0;
-    int k = 0;
-    for (; k + 1 < rows; k += 2) {
-        s0 += l[(size_t)k * ldS] * sy[k];
-        s1 += l[(size_t)(k + 1) * ldS] * sy[k + 1];
+    // zw[r] -= sum_k L[k][r] y_k for 64 rows r of this workgroup: the k-range in 4 quarters (one per wavefront), eight loads
+    // in flight per lane, partial sums through LDS
+    const int r = blockIdx.x * 64 + lane;
+    double s = 0.0;
+    if (r < r0) {
+        const double *l = LL + (size_t)(r0 + wv * 32) * ldS + r; // L[k][r], k = row
+        const int kend = min(32, rows - wv * 32);
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k)
+            if (k < kend) s += l[(size_t)k * ldS] * sy[wv * 32 + k];
     }
-    if (k < rows) s0 += l[(size_t)k * ldS] * sy[k];
-    zw[r] -= s0 + s1;
+    sp[wv][lane] = s;
+    __syncthreads();
+    if (wv == 0 && r < r0) zw[r] -= (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
 }
 
 template <typename T>
@@ -709,7 +726,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         g.Y = R; g.C = A;
         g.tri = 2; g.k_first = r0; g.K = m_pad;
         g.ti_first = r0 / TM; g.tiles_i = (rows + TM - 1) / TM; g.n_split = g.tiles_i;
-        g.alpha = 1.0; g.accumulate = 0;
+        g.alpha = 1.0; g.accumulate = 0; g.deep = 1;
         launch_xty(e, g, 1, e->f32, su);
         const int below = r0 + rows; // first row below the chunk
         if (below >= m_pad) return;
@@ -753,7 +770,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             (void)hipMemcpyAsync(e->d.zwork, e->d.zvec, (size_t)m_pad * sizeof(double), hipMemcpyDeviceToDevice, sv);
             for (int c = n_chunks - 1; c >= 0; --c) {
                 const int r0 = c * CH, rows = min(CH, m_pad - r0);
-                k_ystep<<<max(1, (r0 + 255) / 256), 256, 0, sv>>>(V, ldw, e->d.LL, ldS, r0, rows, e->d.zwork, e->d.yvec);
+                k_ystep<<<max(1, (r0 + 63) / 64), 256, 0, sv>>>(W, ldw, e->d.LL, ldS, r0, rows, e->d.zwork, e->d.yvec);
             }
         }
         (void)hipStreamWaitEvent(sv, e->ev_b_done, 0);
