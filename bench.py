@@ -35,7 +35,20 @@ WORKLOADS = {
     "n2000_f32": (2000, 1280, 720, 1, "f32"),
     "n5000_f32": (5000, 1920, 1080, 1, "f32"),
 }
-PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}  # f32: MI355X_MICROARCH.md; f64: AMD datasheet figure (not in the guide)
+# f32: MI355X_MICROARCH.md (256 CUs x 256 flop/clk x 2.4 GHz).  f64: not in the guide; 256 CUs x 128 flop/clk (one
+# v_mfma_f64_16x16x4 = 2048 flop per 64 cycles per SIMD) x 2.4 GHz = 78.6, the datasheet figure.  What a pure MFMA loop
+# SUSTAINS on this GPU is measured by scripts/micro/mfma_peak.hip (profiles/r02_mfma_peak.json: 153.5 f32, 49.0 f64 --
+# the fp64 loop runs power-limited) and reported next to the spec peak as roofline.measured_mfma_loop_tflops.
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
+
+
+def measured_mfma_loop(dtype):
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_peak.json")), reverse=True):
+        with open(path) as f:
+            d = json.load(f)
+        return d["mfma_f32_32x32x2_tflops" if dtype == "f32" else "mfma_f64_16x16x4_tflops"], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def literal_flops(n, m):
@@ -301,6 +314,7 @@ def main():
                 "peak": PEAK_TFLOPS[dtype],
                 "unit": "TFLOP/s",
                 "frac": ach / PEAK_TFLOPS[dtype],
+                "measured_mfma_loop_tflops": measured_mfma_loop(dtype)[0],
                 "traffic": pmc_traffic[0],
                 "traffic_source": pmc_traffic[1],
                 "avg_launch_ms": avg_ms,

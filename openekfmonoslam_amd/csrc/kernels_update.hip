@@ -345,72 +345,74 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
     }
 }
 
-// ------------------------------------------------------------------------------------------ inverse of L
-// X = inv(L) by BLOCK COLUMNS, the rows of one chunk (<= 4 block rows = 128 rows) per launch:
+// ------------------------------------------------------------------------------- inverse of a diagonal chunk of L
+// X_cc = inverse of the 128 x 128 diagonal block of L that a chunk of 4 panels covers, by block columns:
 //     X_jj = inv(L_jj)  (published by the sweep),   X_aj = -inv(L_aa) sum_{c=j}^{a-1} L_ac X_cj   for a > j.
-// Block column j is independent of every other column, and row a of it needs only rows < a of the SAME column: one
-// workgroup per column, the chunk's rows in sequence, the X_aj of the chunk kept in LDS for the rows after them.  A
-// chunk's launch needs the sweep only up to the chunk's last panel, so it runs on the engine's second stream WHILE the
-// sweep factorises the next chunk (and B = inv(L) G follows chunk by chunk behind it, kernels_gemm.hip): when the sweep
-// ends, one chunk of the inverse and one row chunk of B are left instead of the whole inverse (12 dependent launches
-// of the doubling scheme this replaces) and the whole GEMM.
-// Each wavefront owns one 16x16 quadrant of the 32x32 block; products on the fp64 MFMA, operands fetched straight into
-// the MFMA operand layout (lane l: a[l % 16][l / 16], b[l / 16][l % 16]), the next product's operands requested before
-// the current product's MFMAs are issued.  V = inv(L) row-major, W = V' (+ fp32 copy) as before.
+// Block column j is independent of the others and row a of it needs only the rows above it of the SAME column: one
+// workgroup per column (3 at most), its rows in sequence, the X_aj kept in LDS for the rows after them.  Each wavefront
+// owns one 16x16 quadrant of the 32x32 blocks; products on the fp64 MFMA, operands fetched straight into the MFMA operand
+// layout (lane l: a[l % 16][l / 16], b[l / 16][l % 16]).  Latency is all that matters here (the launch sits between the
+// sweep and the chunk's solve): EVERY global operand the column can need -- six L tiles, three inv(L_aa), X_jj -- is
+// requested unconditionally before the first product (one round trip instead of one per product: 14 -> ~4 us); tiles of
+// block rows past the chunk's end are read (allocated, finite) and never used.  V = inv(L) row-major, W = V' (+ fp32 copy).
 constexpr int INV_CH = 4; // block rows per chunk
 
 __global__ void __launch_bounds__(256)
-k_inv_rows(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, int a_first, int a_count, int j0)
+k_inv_diag(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, int a_first, int a_count)
 {
     typedef double acc4 __attribute__((ext_vector_type(4)));
     __shared__ double sX[INV_CH][NB][NB + 1]; // X_aj of the chunk's rows (operand of the rows below them)
     __shared__ double sT[NB][NB + 1];
-    const int j = j0 + blockIdx.x; // first column block of this launch: 0 = whole rows, a_first = the chunk's diagonal block only
-    const int a_last = a_first + a_count - 1;
+    const int jl = blockIdx.x; // local column block 0..2
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int qi = wv >> 1, qj = wv & 1, lr = lane & 15, lk = lane >> 4;
-    for (int a = max(a_first, j + 1); a <= a_last; ++a) {
-        // T = sum_c L_ac X_cj, this wavefront's quadrant
+    // operands: L_{al,cl} (A layout) for 1 <= al <= 3, cl < al; inv(L_aa) (A layout) for al = 1..3; X_jj (B layout)
+    double pa[3][3][8], da[3][8], pb[8];
+#pragma unroll
+    for (int al = 1; al < INV_CH; ++al) {
+#pragma unroll
+        for (int cl = 0; cl < al; ++cl) {
+            const double *Lp = LL + (size_t)(NB * (a_first + al) + 16 * qi + lr) * ldS + NB * (a_first + cl) + lk;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) pa[al - 1][cl][kk] = Lp[4 * kk];
+        }
+        const double *Dp = V + (size_t)(NB * (a_first + al) + 16 * qi + lr) * ldw + NB * (a_first + al) + lk;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) da[al - 1][kk] = Dp[4 * kk];
+    }
+    {
+        const double *Xp = V + (size_t)(NB * (a_first + jl) + lk) * ldw + NB * (a_first + jl) + 16 * qj + lr;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) pb[kk] = Xp[(size_t)4 * kk * ldw];
+    }
+#pragma unroll
+    for (int al = 1; al < INV_CH; ++al) {
+        if (al <= jl || al >= a_count) continue; // uniform: rows at or above the column's diagonal block, rows past the chunk
         acc4 acc = {0, 0, 0, 0};
-        double pa[8], pb[8];
-        auto fetch = [&](int c) {
-            const double *Lp = LL + (size_t)(NB * a + 16 * qi + lr) * ldS + NB * c + lk;
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) pa[kk] = Lp[4 * kk];
-            if (c > j && c >= a_first) {
+        for (int cl = 0; cl < al; ++cl) {
+            if (cl < jl) continue;
+            if (cl == jl) {
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) pb[kk] = sX[c - a_first][4 * kk + lk][16 * qj + lr];
-            } else { // the diagonal block inv(L_jj) or a row of an earlier chunk: final in V
-                const double *Xp = V + (size_t)(NB * c + lk) * ldw + NB * j + 16 * qj + lr;
+                for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[al - 1][cl][kk], pb[kk], acc, 0, 0, 0);
+            } else {
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) pb[kk] = Xp[(size_t)4 * kk * ldw];
+                for (int kk = 0; kk < 8; ++kk)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[al - 1][cl][kk], sX[cl][4 * kk + lk][16 * qj + lr], acc, 0, 0, 0);
             }
-        };
-        fetch(j);
-        for (int c = j; c < a; ++c) {
-            double ca[8], cb[8];
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) { ca[kk] = pa[kk]; cb[kk] = pb[kk]; }
-            if (c + 1 < a) fetch(c + 1);
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[kk], cb[kk], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) sT[16 * qi + lk + 4 * v][16 * qj + lr] = acc[v];
-        // X_aj = -inv(L_aa) T
-        const double *Dp = V + (size_t)(NB * a + 16 * qi + lr) * ldw + NB * a + lk;
-        double da[8];
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) da[kk] = Dp[4 * kk];
         __syncthreads();
         acc4 x = {0, 0, 0, 0};
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(da[kk], sT[4 * kk + lk][16 * qj + lr], x, 0, 0, 0);
+        for (int kk = 0; kk < 8; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(da[al - 1][kk], sT[4 * kk + lk][16 * qj + lr], x, 0, 0, 0);
+        const int a = a_first + al, j = a_first + jl;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int r = 16 * qi + lk + 4 * v, c = 16 * qj + lr;
             const double val = -x[v];
-            sX[a - a_first][r][c] = val;
+            sX[al][r][c] = val;
             V[(size_t)(NB * a + r) * ldw + NB * j + c] = val;
             W[(size_t)(NB * j + c) * ldw + NB * a + r] = val;
             if (Wf) Wf[(size_t)(NB * j + c) * ldw + NB * a + r] = (float)val;
@@ -419,7 +421,6 @@ k_inv_rows(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, 
     }
 }
 
-// ------------------------------------------------------------------------------------------------- dx = B' z
 // y = inv(L)' z by blocked BACKWARD substitution, one launch per 128-row chunk J from the last to the first:
 //     y_J = X_JJ' zw_J                       (X_JJ = inverse of the chunk's diagonal block of L, rows of V),
 //     zw_r -= sum_{k in J} L[k][r] y_k        for the rows r above the chunk.
@@ -443,7 +444,7 @@ k_ystep(const double *W, int ldw, const double *LL, int ldS, int r0, int rows, d
         for (int rr = 0; rr < 32; ++rr) {
             const int i = wv * 32 + rr;
             const double *w = W + (size_t)(r0 + i) * ldw + r0;
-            part[rr] = (i < rows) ? w[lane] * z0 + w[lane + 64] * z1 : 0.0;
+            part[rr] = w[lane] * z0 + w[lane + 64] * z1; // unconditional: a uniform branch here would serialise the loads
         }
 #pragma unroll
         for (int rr = 0; rr < 32; ++rr) {
@@ -452,7 +453,7 @@ k_ystep(const double *W, int ldw, const double *LL, int ldS, int r0, int rows, d
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
             if (lane == 0) {
                 const int i = wv * 32 + rr;
-                sy[i] = s;
+                sy[i] = i < rows ? s : 0.0;
                 if (blockIdx.x == 0 && i < rows) y[r0 + i] = s;
             }
         }
@@ -464,10 +465,8 @@ k_ystep(const double *W, int ldw, const double *LL, int ldS, int r0, int rows, d
     double s = 0.0;
     if (r < r0) {
         const double *l = LL + (size_t)(r0 + wv * 32) * ldS + r; // L[k][r], k = row
-        const int kend = min(32, rows - wv * 32);
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k)
-            if (k < kend) s += l[(size_t)k * ldS] * sy[wv * 32 + k];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += l[(size_t)k * ldS] * sy[wv * 32 + k]; // rows past the chunk's end: allocated, times 0
     }
     sp[wv][lane] = s;
     __syncthreads();
@@ -666,8 +665,8 @@ void launch_p_update(EkfEngine *e, int m_pad);
 // One update = three streams.  Main stream: gather, S, the sweep (one launch per 32-wide panel), then the downdate and
 // its tail.  Behind the sweep, chunk by chunk (4 panels = 128 rows), B = inv(L) G by blocked forward substitution on the
 // working copy R of G:
-//   stream_v   X_cc = inverse of the chunk's 128 x 128 diagonal block of L     (k_inv_rows on the chunk's own columns)
-//   stream_u   B_c  = X_cc R_c                                                 (k_xty, k inside the chunk)
+//   stream_u   X_cc = inverse of the chunk's 128 x 128 diagonal block of L     (k_inv_diag)
+//              B_c  = X_cc R_c                                                 (k_xty, k inside the chunk)
 //              even chunk: R_{c+1} -= L_{c+1,c} B_c                            (the next chunk only, k = 128)
 //              odd chunk : R_below -= L_below,{c-1,c} B_{c-1,c}                (all rows below, k = 256: one pass over R per
 //                          PAIR of chunks -- with k = 128 the pass is bound by its reads and writes of R, not by the MFMAs)
@@ -712,10 +711,8 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     auto side_chunk = [&](int c) {
         const int a_first = c * INV_CH, a_count = min(INV_CH, nbk - a_first);
         const int r0 = a_first * NB, rows = a_count * NB;
-        (void)hipStreamWaitEvent(sv, e->chunk_event(c), 0);
-        if (a_count > 1) k_inv_rows<<<a_count - 1, 256, 0, sv>>>(e->d.LL, ldS, V, W, Wf, ldw, a_first, a_count, a_first);
-        (void)hipEventRecord(e->inv_event(c), sv);
-        (void)hipStreamWaitEvent(su, e->inv_event(c), 0);
+        (void)hipStreamWaitEvent(su, e->chunk_event(c), 0);
+        if (a_count > 1) k_inv_diag<<<a_count - 1, 256, 0, su>>>(e->d.LL, ldS, V, W, Wf, ldw, a_first, a_count);
         XtyArgs g{};
         g.ldy = ld; g.ldc = ld;
         g.M = m_pad; g.N = n_pad;
@@ -767,6 +764,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         if (sizeof(T) == 4) {
             Bc = e->d.Bc; // inv(L) Gc, produced by the right-hand-side blocks of k_chol_step
             Gy = G;
+            (void)hipStreamWaitEvent(sv, e->ev_b_done, 0); // z is final, every diagonal chunk of L is inverted
             (void)hipMemcpyAsync(e->d.zwork, e->d.zvec, (size_t)m_pad * sizeof(double), hipMemcpyDeviceToDevice, sv);
             for (int c = n_chunks - 1; c >= 0; --c) {
                 const int r0 = c * CH, rows = min(CH, m_pad - r0);
