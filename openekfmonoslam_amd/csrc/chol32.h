@@ -310,8 +310,15 @@ __device__ __forceinline__ bool block_chol_inv32_mf(double (*a)[CH_NB + 1], doub
 // The LDL' factors of the pivot blocks, needed only by the final in-block solves, are computed once after the sweep
 // (one lane per block) from the saved blocks.  cond(D) <= cond(S) (S = H P H' + R, lambda_min >= pixelError), so the
 // cofactor form loses nothing that matters at fp64.
-__device__ __forceinline__ bool block_chol_inv32_adj(double (*a)[CH_NB + 1], double (*x)[CH_NB + 1])
+// TR (micro-benchmark only): thread 0 stores clock64() at six points of every pivot step, each behind a full wait.
+template <bool TR = false>
+__device__ __forceinline__ bool block_chol_inv32_adj(double (*a)[CH_NB + 1], double (*x)[CH_NB + 1], long long *tr = nullptr)
 {
+#define CH_TR(slot)                                                       \
+    if (TR) {                                                            \
+        __builtin_amdgcn_s_waitcnt(0);                                   \
+        if (t == 0) tr[J * 6 + (slot)] = clock64();                      \
+    }
     typedef double acc4 __attribute__((ext_vector_type(4)));
     __shared__ double pc[2][CH_NB][4];      // pc[buf][r][k] = A[r][4J + k]
     __shared__ double pr[2][4][2 * CH_NB];  // pr[buf][k][c] = [A | X][4J + k][c]
@@ -352,7 +359,9 @@ __device__ __forceinline__ bool block_chol_inv32_adj(double (*a)[CH_NB + 1], dou
             const acc4 &src = (j0 < 16) ? m0 : m1;
             pr[p][lq][16 * w + lc] = src[v0];
         }
+        CH_TR(0)
         __syncthreads();
+        CH_TR(1)
         const double(*pn)[4] = pc[p];
         // the relabelled symmetric block: P[u][v] = D[perm u][perm v]
         const double da = pn[j0 + p0][p0];
@@ -364,6 +373,7 @@ __device__ __forceinline__ bool block_chol_inv32_adj(double (*a)[CH_NB + 1], dou
             const int c = t - r * (r + 1) / 2;
             dsv[J][t] = pn[j0 + r][c];
         }
+        CH_TR(2)
         const double m01 = da * dc - db * db, m02 = da * de - db * dd, m12 = db * de - dc * dd;
         const double n01 = dd * dh - de * dg, n02 = dd * di - df * dg, n12 = de * di - df * dh;
         const double C33 = df * m01 - de * m02 + dd * m12;
@@ -374,15 +384,22 @@ __device__ __forceinline__ bool block_chol_inv32_adj(double (*a)[CH_NB + 1], dou
         ok = ok && da > 0.0 && m01 > 0.0 && C33 > 0.0 && det > 0.0;
         const double rdet = fast_rcp(det);
         const double q0 = C03 * rdet, q1 = C13 * rdet, q2 = C23 * rdet, q3 = C33 * rdet; // relabelled column of inv(D)
+        if (TR) { if (q0 + q1 + q2 + q3 == 12345.678) tr[100] = 1; }
+        CH_TR(3)
         const int r0 = lc, r1 = 16 + lc;
         double w0 = pn[r0][p0] * q0 + pn[r0][p1] * q1 + pn[r0][p2] * q2 + pn[r0][p3] * q3;
         double w1 = pn[r1][p0] * q0 + pn[r1][p1] * q1 + pn[r1][p2] * q2 + pn[r1][p3] * q3;
         if (r0 < j0 + 4) w0 = 0.0;
         if (r1 < j0 + 4) w1 = 0.0;
         const double bv = pr[p][lq][16 * w + lc];
+        if (TR) { if (w0 + w1 + bv == 12345.678) tr[100] = 1; }
+        CH_TR(4)
         m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-w0, bv, m0, 0, 0, 0);
         m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-w1, bv, m1, 0, 0, 0);
+        if (TR) { if (m0[0] + m1[3] == 12345.678) tr[100] = 1; }
+        CH_TR(5)
     }
+#undef CH_TR
     __syncthreads();
     if (w >= 2) {
 #pragma unroll

@@ -428,7 +428,9 @@ k_inv_diag(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, 
 // of the working vector (coalesced row segments of L).  The launches are a dependent chain of tiny kernels: what matters
 // is how many loads each lane has in flight, not the flop count (a one-load-per-iteration loop took 20 us per launch).  Needs only the diagonal-block inverses, so the inverse
 // of the whole factor is never formed; runs beside the downdate.
-__global__ void __launch_bounds__(256)
+// EKF_LEAN: at most 56 VGPRs, what is left per SIMD beside three 152-VGPR wavefronts of the downdate
+#define EKF_LEAN __attribute__((amdgpu_num_vgpr(56)))
+__global__ void __launch_bounds__(256) EKF_LEAN
 k_ystep(const double *W, int ldw, const double *LL, int ldS, int r0, int rows, double *zw, double *y)
 {
     __shared__ double sz[128], sy[128], sp[4][64];
@@ -439,22 +441,24 @@ k_ystep(const double *W, int ldw, const double *LL, int ldS, int r0, int rows, d
     // per wavefront, every load of the block in flight before the first reduction
     {
         const double z0 = sz[lane], z1 = sz[lane + 64];
-        double part[32];
+#pragma unroll 1
+        for (int r8 = 0; r8 < 32; r8 += 4) { // 4 rows = 8 loads in flight per lane; small enough to run beside the downdate
+            double part[4];
 #pragma unroll
-        for (int rr = 0; rr < 32; ++rr) {
-            const int i = wv * 32 + rr;
-            const double *w = W + (size_t)(r0 + i) * ldw + r0;
-            part[rr] = w[lane] * z0 + w[lane + 64] * z1; // unconditional: a uniform branch here would serialise the loads
-        }
+            for (int rr = 0; rr < 4; ++rr) {
+                const double *w = W + (size_t)(r0 + wv * 32 + r8 + rr) * ldw + r0;
+                part[rr] = w[lane] * z0 + w[lane + 64] * z1; // unconditional: a uniform branch here would serialise the loads
+            }
 #pragma unroll
-        for (int rr = 0; rr < 32; ++rr) {
-            double s = part[rr];
+            for (int rr = 0; rr < 4; ++rr) {
+                double s = part[rr];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            if (lane == 0) {
-                const int i = wv * 32 + rr;
-                sy[i] = i < rows ? s : 0.0;
-                if (blockIdx.x == 0 && i < rows) y[r0 + i] = s;
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                if (lane == 0) {
+                    const int i = wv * 32 + r8 + rr;
+                    sy[i] = i < rows ? s : 0.0;
+                    if (blockIdx.x == 0 && i < rows) y[r0 + i] = s;
+                }
             }
         }
     }
@@ -465,7 +469,7 @@ k_ystep(const double *W, int ldw, const double *LL, int ldS, int r0, int rows, d
     double s = 0.0;
     if (r < r0) {
         const double *l = LL + (size_t)(r0 + wv * 32) * ldS + r; // L[k][r], k = row
-#pragma unroll
+#pragma unroll 4
         for (int k = 0; k < 32; ++k) s += l[(size_t)k * ldS] * sy[wv * 32 + k]; // rows past the chunk's end: allocated, times 0
     }
     sp[wv][lane] = s;
@@ -473,8 +477,11 @@ k_ystep(const double *W, int ldw, const double *LL, int ldS, int r0, int rows, d
     if (wv == 0 && r < r0) zw[r] -= (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256)
+// PART 0: dx (and, fp32 covariance, the fp64 diagonal of B'B); PART 1 / 2 (fp32 covariance): camera rows 0..6 / 7..12 of B'B
+// in fp64.  Three instances instead of one kernel with everything: beside the downdate (3 workgroups of 152 VGPRs per SIMD) a wavefront
+// is only admitted if it needs <= 56 VGPRs -- the combined kernel needed 74 and simply queued until the downdate was over.
+template <typename T, int PART>
+__global__ void __launch_bounds__(256) EKF_LEAN
 k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, int ldpart, double *sq_part, double *cam_part,
              const double *Bc, const T *G, const double *y)
 {
@@ -484,9 +491,10 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
     const int per = (m + DX_SPLIT - 1) / DX_SPLIT;
     const int kb = ks * per, ke = min(m, kb + per);
     double s = 0.0, q = 0.0;
-    double c[13];
+    constexpr int A0 = PART == 2 ? 7 : 0, NA = PART == 0 ? 1 : (PART == 1 ? 7 : 6);
+    double c[NA];
 #pragma unroll
-    for (int a = 0; a < 13; ++a) c[a] = 0.0;
+    for (int a = 0; a < NA; ++a) c[a] = 0.0;
     for (int k0 = kb; k0 < ke; k0 += 64) {
         const int cnt = min(64, ke - k0);
         if (Bc) { // fp64 camera columns of B (fp32 covariance only)
@@ -497,22 +505,27 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
         if (j < n)
             for (int k = 0; k < cnt; ++k) {
                 const double b = (Bc && j < 13) ? sc[k][j] : (double)B[(size_t)(k0 + k) * ld + j];
-                // feature columns of the fp32 configuration: dx_j = sum_k (H P)_kj y_k (y = inv(S) nu from k_ystep: B comes out of fp32 MFMA GEMMs with an accumulation error of ~ sqrt(m) eps per element, G is the fp64-accumulated H P rounded once; measured at N = 1000: the inverse-depth components were 2e-7 ... 1e-6 off through B' z); camera columns: Bc' z (fp64)
-                if (G && j >= 13) s += (double)G[(size_t)(k0 + k) * ld + j] * y[k0 + k];
-                else s += b * z[k0 + k];
-                q += b * b; // (B'B)_jj in fp64, same pass over B: see k_diag_fix
-                if (cam_part) {
+                if (PART == 0) {
+                    // feature columns of the fp32 configuration: dx_j = sum_k (H P)_kj y_k with y = inv(S) nu from k_ystep
+                    // (B comes out of fp32 MFMA GEMMs with an accumulation error of ~ sqrt(m) eps per element, G is the
+                    // fp64-accumulated H P rounded once; measured at N = 1000: the inverse-depth components were
+                    // 2e-7 ... 1e-6 off through B' z); camera columns: Bc' z (fp64)
+                    if (G && j >= 13) s += (double)G[(size_t)(k0 + k) * ld + j] * y[k0 + k];
+                    else s += b * z[k0 + k];
+                    q += b * b; // (B'B)_jj in fp64, same pass over B: see k_diag_fix
+                } else {
 #pragma unroll
-                    for (int a = 0; a < 13; ++a) c[a] += sc[k][a] * b; // (B'B)_aj, camera rows
+                    for (int a = 0; a < NA; ++a) c[a] += sc[k][A0 + a] * b; // (B'B)_aj, camera rows
                 }
             }
     }
     if (j >= n) return;
-    part[(size_t)ks * ldpart + j] = s;
-    if (sq_part) sq_part[(size_t)ks * ldpart + j] = q;
-    if (cam_part) {
+    if (PART == 0) {
+        part[(size_t)ks * ldpart + j] = s;
+        if (sq_part) sq_part[(size_t)ks * ldpart + j] = q;
+    } else {
 #pragma unroll
-        for (int a = 0; a < 13; ++a) cam_part[((size_t)ks * 13 + a) * ldpart + j] = c[a];
+        for (int a = 0; a < NA; ++a) cam_part[((size_t)ks * 13 + A0 + a) * ldpart + j] = c[a];
     }
 }
 
@@ -569,15 +582,17 @@ __device__ inline void quat_norm_dev(double *st)
 
 // stateUpdate (Update.cpp:147-204): x += dx with the DELTA dead-band on every component; R(q) recomputed from
 // the un-normalised q (:168).
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) EKF_LEAN
 k_state_apply(double *st, double *feat_pos, const int *feat_type, const int *feat_covpos, int N, const double *part,
               int ldpart, int normalise)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t == 0) {
         double *x = st + ST_X;
-        for (int i = 0; i < 13; ++i) {
+#pragma unroll 1
+        for (int i = 0; i < 13; ++i) { // rolled loops: this kernel must stay small enough to run beside the downdate
             double s = 0.0;
+#pragma unroll 1
             for (int ks = 0; ks < DX_SPLIT; ++ks) s += part[(size_t)ks * ldpart + i];
             if (fabs(s) > EKF_DELTA) x[i] += s;
         }
@@ -591,6 +606,7 @@ k_state_apply(double *st, double *feat_pos, const int *feat_type, const int *fea
     if (a >= feat_dim(feat_type[f])) return;
     const int j = feat_covpos[f] + a;
     double s = 0.0;
+#pragma unroll 4
     for (int ks = 0; ks < DX_SPLIT; ++ks) s += part[(size_t)ks * ldpart + j];
     if (fabs(s) > EKF_DELTA) feat_pos[6 * f + a] += s;
 }
@@ -711,8 +727,10 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     auto side_chunk = [&](int c) {
         const int a_first = c * INV_CH, a_count = min(INV_CH, nbk - a_first);
         const int r0 = a_first * NB, rows = a_count * NB;
-        (void)hipStreamWaitEvent(su, e->chunk_event(c), 0);
-        if (a_count > 1) k_inv_diag<<<a_count - 1, 256, 0, su>>>(e->d.LL, ldS, V, W, Wf, ldw, a_first, a_count);
+        (void)hipStreamWaitEvent(sv, e->chunk_event(c), 0);
+        if (a_count > 1) k_inv_diag<<<a_count - 1, 256, 0, sv>>>(e->d.LL, ldS, V, W, Wf, ldw, a_first, a_count);
+        (void)hipEventRecord(e->inv_event(c), sv);
+        (void)hipStreamWaitEvent(su, e->inv_event(c), 0);
         XtyArgs g{};
         g.ldy = ld; g.ldc = ld;
         g.M = m_pad; g.N = n_pad;
@@ -737,7 +755,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             g.tiles_i = (min(CH, m_pad - below) + TM - 1) / TM; g.n_split = g.tiles_i;
         } else {          // everything below the pair: the terms of both chunks in one pass
             g.k_first = r0 - CH; g.K = below;
-            g.tiles_i = (m_pad - below + TM - 1) / TM; g.n_split = 0;
+            g.tiles_i = (m_pad - below + TM - 1) / TM; g.n_split = g.tiles_i;
         }
         launch_xty(e, g, 1, e->f32, su);
     };
@@ -758,13 +776,13 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     }
     side_chunk(n_chunks - 1);
     (void)hipEventRecord(e->ev_b_done, su);
-    {   // y, dx and the state update: not needed by the downdate, concurrent with it
+    {   // y, dx and the state update: not needed by the downdate, concurrent with it.  y follows the last diagonal inverse
+        // directly (z is final once the sweep is); the sums over B wait for B.
         const double *Bc = nullptr;
         const T *Gy = nullptr;
         if (sizeof(T) == 4) {
             Bc = e->d.Bc; // inv(L) Gc, produced by the right-hand-side blocks of k_chol_step
             Gy = G;
-            (void)hipStreamWaitEvent(sv, e->ev_b_done, 0); // z is final, every diagonal chunk of L is inverted
             (void)hipMemcpyAsync(e->d.zwork, e->d.zvec, (size_t)m_pad * sizeof(double), hipMemcpyDeviceToDevice, sv);
             for (int c = n_chunks - 1; c >= 0; --c) {
                 const int r0 = c * CH, rows = min(CH, m_pad - r0);
@@ -773,11 +791,15 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         }
         (void)hipStreamWaitEvent(sv, e->ev_b_done, 0);
         dim3 grid((n + 255) / 256, DX_SPLIT);
-        k_dx_partial<T><<<grid, 256, 0, sv>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, fix ? e->d.sq_part : nullptr,
-                                              fix ? e->d.cam_part : nullptr, Bc, Gy, e->d.yvec);
+        k_dx_partial<T, 0><<<grid, 256, 0, sv>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, fix ? e->d.sq_part : nullptr,
+                                                 nullptr, Bc, Gy, e->d.yvec);
         const int nt = max(e->N * 6, 1);
         k_state_apply<<<(nt + 255) / 256, 256, 0, sv>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
                                                         e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
+        if (fix) {
+            k_dx_partial<T, 1><<<grid, 256, 0, sv>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, nullptr, e->d.cam_part, Bc, Gy, e->d.yvec);
+            k_dx_partial<T, 2><<<grid, 256, 0, sv>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, nullptr, e->d.cam_part, Bc, Gy, e->d.yvec);
+        }
     }
     (void)hipEventRecord(e->ev_dx_done, sv);
     if (!update_cov) {

@@ -35,6 +35,19 @@ __global__ void __launch_bounds__(256) k_run(const double *A, double *Linv, long
     if (threadIdx.x == 0) { ticks[0] = c_acc; ticks[1] = w_acc; ticks[2] = ok; }
 }
 
+__global__ void __launch_bounds__(256) k_trace(const double *A, long long *tr)
+{
+    __shared__ double sa[CH_NB][CH_NB + 1], sx[CH_NB][CH_NB + 1];
+    for (int it = 0; it < 3; ++it) {
+        for (int i = threadIdx.x; i < CH_NB * CH_NB; i += 256) {
+            const int r = i / CH_NB, c = i % CH_NB;
+            sa[r][c] = c <= r ? A[r * CH_NB + c] : 0.0;
+        }
+        __syncthreads();
+        block_chol_inv32_adj<true>(sa, sx, tr);
+    }
+}
+
 int main()
 {
     const int n = CH_NB;
@@ -90,6 +103,20 @@ int main()
             for (int j = i + 1; j < n; ++j) upper = std::fmax(upper, std::fabs(L[i * n + j]));
         std::printf("variant %d: ok=%lld  cycles/call %.0f  wall us/call %.2f  (kernel %.1f us / %d reps = %.2f us)  |LinvALinv'-I| %.2e  upper %.1e\n",
                     v, t[2], (double)t[0] / reps, (double)t[1] / reps / 100.0, ms * 1e3, reps, ms * 1e3 / reps, err, upper);
+    }
+    {   // where a pivot step of the cofactor variant spends its cycles (thread 0, each point behind s_waitcnt 0)
+        long long *dTr;
+        hipMalloc(&dTr, 128 * 8);
+        hipMemset(dTr, 0, 128 * 8);
+        k_trace<<<1, 256>>>(dA, dTr);
+        hipDeviceSynchronize();
+        long long tr[128];
+        hipMemcpy(tr, dTr, 128 * 8, hipMemcpyDeviceToHost);
+        std::printf("step: publish->barrier | barrier | block loads | cofactors+rcp | w, pivot-row loads | mfma | to next publish\n");
+        for (int J = 0; J < 8; ++J) {
+            const long long *q = tr + 6 * J;
+            std::printf("%d: %lld %lld %lld %lld %lld %lld\n", J, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], J < 7 ? q[6] - q[5] : 0LL);
+        }
     }
     return 0;
 }
