@@ -137,6 +137,7 @@ void ekf_engine_destroy(EkfEngine *e)
         if (ev) (void)hipEventDestroy(ev);
     if (e->ev_b_done) (void)hipEventDestroy(e->ev_b_done);
     if (e->ev_dx_done) (void)hipEventDestroy(e->ev_dx_done);
+    if (e->ev_y_done) (void)hipEventDestroy(e->ev_y_done);
     if (e->ev_main) (void)hipEventDestroy(e->ev_main);
     if (e->ev_prefetch) (void)hipEventDestroy(e->ev_prefetch);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -195,6 +196,7 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     }
     if ((st = hipEventCreateWithFlags(&e->ev_b_done, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
     if ((st = hipEventCreateWithFlags(&e->ev_dx_done, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
+    if ((st = hipEventCreateWithFlags(&e->ev_y_done, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
     if ((st = hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
     if ((st = hipEventCreateWithFlags(&e->ev_prefetch, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
     DeviceArrays &d = e->d;

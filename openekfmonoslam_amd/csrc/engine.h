@@ -186,7 +186,7 @@ struct EkfEngine {
     hipStream_t stream_v = nullptr;            // update: diagonal-block inverses behind the sweep; y, dx, state beside the downdate
     std::vector<hipEvent_t> ev_chunks;         // main -> side streams, one per chunk of the sweep
     std::vector<hipEvent_t> ev_invs;           // stream_v -> stream_u, one per chunk
-    hipEvent_t ev_b_done = nullptr, ev_dx_done = nullptr;
+    hipEvent_t ev_b_done = nullptr, ev_dx_done = nullptr, ev_y_done = nullptr;
     static hipEvent_t pooled_event(std::vector<hipEvent_t> &pool, int i)
     {
         while ((int)pool.size() <= i) {

@@ -427,10 +427,11 @@ k_inv_diag(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, 
 // Every workgroup forms y_J itself (128 x 128 MACs, coalesced rows of W = inv(L)'); workgroup b then updates rows 64 b ...
 // of the working vector (coalesced row segments of L).  The launches are a dependent chain of tiny kernels: what matters
 // is how many loads each lane has in flight, not the flop count (a one-load-per-iteration loop took 20 us per launch).  Needs only the diagonal-block inverses, so the inverse
-// of the whole factor is never formed; runs beside the downdate.
-// EKF_LEAN: at most 56 VGPRs, what is left per SIMD beside three 152-VGPR wavefronts of the downdate
+// of the whole factor is never formed.  Runs on the main stream between the sweep and the downdate, while the side stream
+// finishes B: the chain of launches then costs nothing and never competes with the downdate for wavefront slots.
+// EKF_LEAN: kernels meant to run beside the downdate -- 56 VGPRs are left per SIMD next to its three 152-VGPR wavefronts
 #define EKF_LEAN __attribute__((amdgpu_num_vgpr(56)))
-__global__ void __launch_bounds__(256) EKF_LEAN
+__global__ void __launch_bounds__(256)
 k_ystep(const double *W, int ldw, const double *LL, int ldS, int r0, int rows, double *zw, double *y)
 {
     __shared__ double sz[128], sy[128], sp[4][64];
@@ -441,16 +442,16 @@ k_ystep(const double *W, int ldw, const double *LL, int ldS, int r0, int rows, d
     // per wavefront, every load of the block in flight before the first reduction
     {
         const double z0 = sz[lane], z1 = sz[lane + 64];
-#pragma unroll 1
-        for (int r8 = 0; r8 < 32; r8 += 4) { // 4 rows = 8 loads in flight per lane; small enough to run beside the downdate
-            double part[4];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
+        for (int r8 = 0; r8 < 32; r8 += 16) { // 16 rows = 32 loads in flight per lane
+            double part[16];
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
                 const double *w = W + (size_t)(r0 + wv * 32 + r8 + rr) * ldw + r0;
                 part[rr] = w[lane] * z0 + w[lane + 64] * z1; // unconditional: a uniform branch here would serialise the loads
             }
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
+            for (int rr = 0; rr < 16; ++rr) {
                 double s = part[rr];
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -469,7 +470,7 @@ k_ystep(const double *W, int ldw, const double *LL, int ldS, int r0, int rows, d
     double s = 0.0;
     if (r < r0) {
         const double *l = LL + (size_t)(r0 + wv * 32) * ldS + r; // L[k][r], k = row
-#pragma unroll 4
+#pragma unroll
         for (int k = 0; k < 32; ++k) s += l[(size_t)k * ldS] * sy[wv * 32 + k]; // rows past the chunk's end: allocated, times 0
     }
     sp[wv][lane] = s;
@@ -776,20 +777,27 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     }
     side_chunk(n_chunks - 1);
     (void)hipEventRecord(e->ev_b_done, su);
-    {   // y, dx and the state update: not needed by the downdate, concurrent with it.  y follows the last diagonal inverse
-        // directly (z is final once the sweep is); the sums over B wait for B.
-        const double *Bc = nullptr;
-        const T *Gy = nullptr;
-        if (sizeof(T) == 4) {
-            Bc = e->d.Bc; // inv(L) Gc, produced by the right-hand-side blocks of k_chol_step
-            Gy = G;
-            (void)hipMemcpyAsync(e->d.zwork, e->d.zvec, (size_t)m_pad * sizeof(double), hipMemcpyDeviceToDevice, sv);
-            for (int c = n_chunks - 1; c >= 0; --c) {
-                const int r0 = c * CH, rows = min(CH, m_pad - r0);
-                k_ystep<<<max(1, (r0 + 63) / 64), 256, 0, sv>>>(W, ldw, e->d.LL, ldS, r0, rows, e->d.zwork, e->d.yvec);
-            }
+    const bool want_y = sizeof(T) == 4;
+    if (want_y) {
+        // y = inv(L)' z on the MAIN stream, which would otherwise idle until B is complete: needs the diagonal inverses
+        // of every chunk (the last one was just enqueued on stream_v) and z (final with the sweep)
+        (void)hipStreamWaitEvent(s, e->inv_event(n_chunks - 1), 0);
+        (void)hipMemcpyAsync(e->d.zwork, e->d.zvec, (size_t)m_pad * sizeof(double), hipMemcpyDeviceToDevice, s);
+        for (int c = n_chunks - 1; c >= 0; --c) {
+            const int r0 = c * CH, rows = min(CH, m_pad - r0);
+            k_ystep<<<max(1, (r0 + 63) / 64), 256, 0, s>>>(W, ldw, e->d.LL, ldS, r0, rows, e->d.zwork, e->d.yvec);
         }
+        (void)hipEventRecord(e->ev_y_done, s);
+    }
+    if (update_cov) { // the downdate is enqueued BEFORE the host spends its time on the side chain below
+        (void)hipStreamWaitEvent(s, e->ev_b_done, 0);
+        launch_p_update(e, m_pad);
+    }
+    {   // dx, the fp64 sums and the state update: not needed by the downdate, beside it (lean kernels)
+        const double *Bc = sizeof(T) == 4 ? e->d.Bc : nullptr; // inv(L) Gc, from the right-hand-side blocks of k_chol_step
+        const T *Gy = sizeof(T) == 4 ? G : nullptr;
         (void)hipStreamWaitEvent(sv, e->ev_b_done, 0);
+        if (want_y) (void)hipStreamWaitEvent(sv, e->ev_y_done, 0);
         dim3 grid((n + 255) / 256, DX_SPLIT);
         k_dx_partial<T, 0><<<grid, 256, 0, sv>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, fix ? e->d.sq_part : nullptr,
                                                  nullptr, Bc, Gy, e->d.yvec);
@@ -802,13 +810,8 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         }
     }
     (void)hipEventRecord(e->ev_dx_done, sv);
-    if (!update_cov) {
-        (void)hipStreamWaitEvent(s, e->ev_dx_done, 0);
-        return;
-    }
-    (void)hipStreamWaitEvent(s, e->ev_b_done, 0);
-    launch_p_update(e, m_pad);
     (void)hipStreamWaitEvent(s, e->ev_dx_done, 0);
+    if (!update_cov) return;
     if (fix) k_diag_fix<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save, e->d.cam_part, ld);
     const int nb = 1 + (n > 7 ? (n - 7 + 255) / 256 : 0);
     k_normalize_cov<T><<<nb, 256, 0, s>>>((T *)e->d.P, ld, n, e->d.state, e->rm);
