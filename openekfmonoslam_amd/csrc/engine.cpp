@@ -105,6 +105,7 @@ void ekf_engine_destroy(EkfEngine *e)
 {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    e->side.shutdown();
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->stream_u) (void)hipStreamSynchronize(e->stream_u);
     if (e->stream_v) (void)hipStreamSynchronize(e->stream_v);

@@ -2,8 +2,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
+#include <functional>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -149,6 +155,65 @@ struct Frames {
     uint8_t *desc = nullptr;
 };
 
+// Submission thread of the update's side streams.  An update issues ~60 extra HIP calls for stream_u / stream_v (events,
+// diagonal inverses, the GEMMs of the forward substitution); issued from the caller's thread between the sweep's launches
+// they made the sweep -- 33 dependent ~10 us kernels -- wait for the HOST (measured: 17 us per panel instead of 10.7).
+// The caller's thread now only posts closures; this thread makes the calls.  A ticket counts executed closures: before
+// the caller lets the main stream wait on an event a closure records, it waits for that closure's ticket.
+struct SideWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    std::atomic<long> done{0};
+    long posted = 0;
+    bool stop = false;
+    void start(int device)
+    {
+        if (th.joinable()) return;
+        th = std::thread([this, device] {
+            (void)hipSetDevice(device);
+            for (;;) {
+                std::function<void()> f;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [this] { return stop || !q.empty(); });
+                    if (q.empty()) return;
+                    f = std::move(q.front());
+                    q.pop_front();
+                }
+                f();
+                done.fetch_add(1, std::memory_order_release);
+            }
+        });
+    }
+    long post(std::function<void()> f)
+    {
+        long ticket;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            q.push_back(std::move(f));
+            ticket = ++posted;
+        }
+        cv.notify_one();
+        return ticket;
+    }
+    void wait(long ticket)
+    {
+        while (done.load(std::memory_order_acquire) < ticket) std::this_thread::yield();
+    }
+    void shutdown()
+    {
+        if (!th.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_one();
+        th.join();
+    }
+};
+
 } // namespace ekf
 
 struct EkfEngine {
@@ -187,6 +252,7 @@ struct EkfEngine {
     std::vector<hipEvent_t> ev_chunks;         // main -> side streams, one per chunk of the sweep
     std::vector<hipEvent_t> ev_invs;           // stream_v -> stream_u, one per chunk
     hipEvent_t ev_b_done = nullptr, ev_dx_done = nullptr, ev_y_done = nullptr;
+    ekf::SideWorker side; // host thread that submits to stream_u / stream_v
     static hipEvent_t pooled_event(std::vector<hipEvent_t> &pool, int i)
     {
         while ((int)pool.size() <= i) {

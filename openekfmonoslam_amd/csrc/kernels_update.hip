@@ -429,8 +429,6 @@ k_inv_diag(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, 
 // is how many loads each lane has in flight, not the flop count (a one-load-per-iteration loop took 20 us per launch).  Needs only the diagonal-block inverses, so the inverse
 // of the whole factor is never formed.  Runs on the main stream between the sweep and the downdate, while the side stream
 // finishes B: the chain of launches then costs nothing and never competes with the downdate for wavefront slots.
-// EKF_LEAN: kernels meant to run beside the downdate -- 56 VGPRs are left per SIMD next to its three 152-VGPR wavefronts
-#define EKF_LEAN __attribute__((amdgpu_num_vgpr(56)))
 __global__ void __launch_bounds__(256)
 k_ystep(const double *W, int ldw, const double *LL, int ldS, int r0, int rows, double *zw, double *y)
 {
@@ -478,11 +476,12 @@ k_ystep(const double *W, int ldw, const double *LL, int ldS, int r0, int rows, d
     if (wv == 0 && r < r0) zw[r] -= (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
 }
 
-// PART 0: dx (and, fp32 covariance, the fp64 diagonal of B'B); PART 1 / 2 (fp32 covariance): camera rows 0..6 / 7..12 of B'B
-// in fp64.  Three instances instead of one kernel with everything: beside the downdate (3 workgroups of 152 VGPRs per SIMD) a wavefront
-// is only admitted if it needs <= 56 VGPRs -- the combined kernel needed 74 and simply queued until the downdate was over.
+// PART 3: everything in one pass over B (what the update uses: dx, the fp64 diagonal and the 13 camera rows of B'B).
+// PART 0 / 1 / 2: dx + diagonal / camera rows 0..6 / camera rows 7..12 as separate lean instances (<= 56 VGPRs, what fits
+// on a SIMD beside three 152-VGPR wavefronts of the downdate).  Running them beside the downdate was measured and lost:
+// they took 4-10x longer there and slowed the downdate by 70 us, more than the 30 us the combined kernel costs in front.
 template <typename T, int PART>
-__global__ void __launch_bounds__(256) EKF_LEAN
+__global__ void __launch_bounds__(256)
 k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, int ldpart, double *sq_part, double *cam_part,
              const double *Bc, const T *G, const double *y)
 {
@@ -492,7 +491,8 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
     const int per = (m + DX_SPLIT - 1) / DX_SPLIT;
     const int kb = ks * per, ke = min(m, kb + per);
     double s = 0.0, q = 0.0;
-    constexpr int A0 = PART == 2 ? 7 : 0, NA = PART == 0 ? 1 : (PART == 1 ? 7 : 6);
+    constexpr int A0 = PART == 2 ? 7 : 0, NA = PART == 0 ? 1 : (PART == 1 ? 7 : (PART == 2 ? 6 : 13));
+    constexpr bool DO_DX = PART == 0 || PART == 3, DO_CAM = PART >= 1;
     double c[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) c[a] = 0.0;
@@ -506,7 +506,7 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
         if (j < n)
             for (int k = 0; k < cnt; ++k) {
                 const double b = (Bc && j < 13) ? sc[k][j] : (double)B[(size_t)(k0 + k) * ld + j];
-                if (PART == 0) {
+                if (DO_DX) {
                     // feature columns of the fp32 configuration: dx_j = sum_k (H P)_kj y_k with y = inv(S) nu from k_ystep
                     // (B comes out of fp32 MFMA GEMMs with an accumulation error of ~ sqrt(m) eps per element, G is the
                     // fp64-accumulated H P rounded once; measured at N = 1000: the inverse-depth components were
@@ -514,17 +514,19 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
                     if (G && j >= 13) s += (double)G[(size_t)(k0 + k) * ld + j] * y[k0 + k];
                     else s += b * z[k0 + k];
                     q += b * b; // (B'B)_jj in fp64, same pass over B: see k_diag_fix
-                } else {
+                }
+                if (DO_CAM && cam_part) {
 #pragma unroll
                     for (int a = 0; a < NA; ++a) c[a] += sc[k][A0 + a] * b; // (B'B)_aj, camera rows
                 }
             }
     }
     if (j >= n) return;
-    if (PART == 0) {
+    if (DO_DX) {
         part[(size_t)ks * ldpart + j] = s;
         if (sq_part) sq_part[(size_t)ks * ldpart + j] = q;
-    } else {
+    }
+    if (DO_CAM && cam_part) {
 #pragma unroll
         for (int a = 0; a < NA; ++a) cam_part[((size_t)ks * 13 + A0 + a) * ldpart + j] = c[a];
     }
@@ -583,7 +585,7 @@ __device__ inline void quat_norm_dev(double *st)
 
 // stateUpdate (Update.cpp:147-204): x += dx with the DELTA dead-band on every component; R(q) recomputed from
 // the un-normalised q (:168).
-__global__ void __launch_bounds__(256) EKF_LEAN
+__global__ void __launch_bounds__(256)
 k_state_apply(double *st, double *feat_pos, const int *feat_type, const int *feat_covpos, int N, const double *part,
               int ldpart, int normalise)
 {
@@ -689,9 +691,9 @@ void launch_p_update(EkfEngine *e, int m_pad);
 //                          PAIR of chunks -- with k = 128 the pass is bound by its reads and writes of R, not by the MFMAs)
 // so the big GEMMs run while the sweep factorises the following chunks and only the last chunk's small pieces are left
 // when it ends (the previous form -- inverse of the whole factor by doubling, then one GEMM -- put 12 + 1 dependent
-// launches, ~200 us at m = 1000, behind the sweep).  After the sweep, off the downdate's critical path and concurrent
-// with it (stream_v): y = inv(L)' z by blocked backward substitution, dx, the state update.  The downdate waits for B;
-// its tail (k_diag_fix needs the fp64 sums of k_dx_partial, k_normalize_cov the Jacobian k_state_apply leaves) for dx.
+// launches, ~200 us at m = 1000, behind the sweep).  The side streams are fed by the engine's worker thread (SideWorker).
+// After the sweep the main stream, idle until B is complete, runs y = inv(L)' z (blocked backward substitution); then dx,
+// the state update and the downdate follow on it in order.
 template <typename T>
 static void update_impl(EkfEngine *e, int M, bool update_cov)
 {
@@ -723,9 +725,12 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     const int n_chunks = (nbk + INV_CH - 1) / INV_CH;
     const int TM = sizeof(T) == 4 ? 128 : 64;
     constexpr int CH = INV_CH * NB; // rows per chunk
-    // side-stream work of one chunk; issued one chunk late in HOST order so that the main queue never waits for the host
+    // side-stream work of one chunk, submitted by the engine's worker thread (SideWorker, engine.h)
     hipStream_t sv = e->stream_v;
-    auto side_chunk = [&](int c) {
+    e->side.start(e->device);
+    (void)e->chunk_event(n_chunks - 1); // the event pools grow here, on the caller's thread, never under the worker
+    (void)e->inv_event(n_chunks - 1);
+    auto side_chunk = [=](int c) {
         const int a_first = c * INV_CH, a_count = min(INV_CH, nbk - a_first);
         const int r0 = a_first * NB, rows = a_count * NB;
         (void)hipStreamWaitEvent(sv, e->chunk_event(c), 0);
@@ -760,6 +765,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         }
         launch_xty(e, g, 1, e->f32, su);
     };
+    long ticket_last = 0;
     for (int k = 0; k < nbk; ++k) {
         const int k0 = k * NB;
         const int kb = min(NB, m - k0);
@@ -773,45 +779,34 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         // the chunk's panels are factorised (inv(L_kk) published one launch earlier, column k of L stored by launch k)
         const int c = k / INV_CH;
         (void)hipEventRecord(e->chunk_event(c), s);
-        if (c > 0) side_chunk(c - 1);
+        ticket_last = e->side.post([=] { side_chunk(c); });
     }
-    side_chunk(n_chunks - 1);
-    (void)hipEventRecord(e->ev_b_done, su);
-    const bool want_y = sizeof(T) == 4;
-    if (want_y) {
+    const long ticket_b = e->side.post([=] { (void)hipEventRecord(e->ev_b_done, su); });
+    if (sizeof(T) == 4) {
         // y = inv(L)' z on the MAIN stream, which would otherwise idle until B is complete: needs the diagonal inverses
-        // of every chunk (the last one was just enqueued on stream_v) and z (final with the sweep)
+        // of every chunk (the event the last chunk's closure records on stream_v) and z (final with the sweep)
+        e->side.wait(ticket_last);
         (void)hipStreamWaitEvent(s, e->inv_event(n_chunks - 1), 0);
         (void)hipMemcpyAsync(e->d.zwork, e->d.zvec, (size_t)m_pad * sizeof(double), hipMemcpyDeviceToDevice, s);
         for (int c = n_chunks - 1; c >= 0; --c) {
             const int r0 = c * CH, rows = min(CH, m_pad - r0);
             k_ystep<<<max(1, (r0 + 63) / 64), 256, 0, s>>>(W, ldw, e->d.LL, ldS, r0, rows, e->d.zwork, e->d.yvec);
         }
-        (void)hipEventRecord(e->ev_y_done, s);
     }
-    if (update_cov) { // the downdate is enqueued BEFORE the host spends its time on the side chain below
-        (void)hipStreamWaitEvent(s, e->ev_b_done, 0);
-        launch_p_update(e, m_pad);
-    }
-    {   // dx, the fp64 sums and the state update: not needed by the downdate, beside it (lean kernels)
+    e->side.wait(ticket_b); // every closure has run: nothing of this update is left to submit from the worker
+    (void)hipStreamWaitEvent(s, e->ev_b_done, 0);
+    {
         const double *Bc = sizeof(T) == 4 ? e->d.Bc : nullptr; // inv(L) Gc, from the right-hand-side blocks of k_chol_step
         const T *Gy = sizeof(T) == 4 ? G : nullptr;
-        (void)hipStreamWaitEvent(sv, e->ev_b_done, 0);
-        if (want_y) (void)hipStreamWaitEvent(sv, e->ev_y_done, 0);
         dim3 grid((n + 255) / 256, DX_SPLIT);
-        k_dx_partial<T, 0><<<grid, 256, 0, sv>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, fix ? e->d.sq_part : nullptr,
-                                                 nullptr, Bc, Gy, e->d.yvec);
+        k_dx_partial<T, 3><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, fix ? e->d.sq_part : nullptr,
+                                                fix ? e->d.cam_part : nullptr, Bc, Gy, e->d.yvec);
         const int nt = max(e->N * 6, 1);
-        k_state_apply<<<(nt + 255) / 256, 256, 0, sv>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
-                                                        e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
-        if (fix) {
-            k_dx_partial<T, 1><<<grid, 256, 0, sv>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, nullptr, e->d.cam_part, Bc, Gy, e->d.yvec);
-            k_dx_partial<T, 2><<<grid, 256, 0, sv>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, nullptr, e->d.cam_part, Bc, Gy, e->d.yvec);
-        }
+        k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
+                                                       e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
     }
-    (void)hipEventRecord(e->ev_dx_done, sv);
-    (void)hipStreamWaitEvent(s, e->ev_dx_done, 0);
     if (!update_cov) return;
+    launch_p_update(e, m_pad);
     if (fix) k_diag_fix<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save, e->d.cam_part, ld);
     const int nb = 1 + (n > 7 ? (n - 7 + 255) / 256 : 0);
     k_normalize_cov<T><<<nb, 256, 0, s>>>((T *)e->d.P, ld, n, e->d.state, e->rm);
