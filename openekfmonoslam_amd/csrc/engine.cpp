@@ -105,7 +105,6 @@ void ekf_engine_destroy(EkfEngine *e)
 {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    e->side.shutdown();
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->stream_u) (void)hipStreamSynchronize(e->stream_u);
     if (e->stream_v) (void)hipStreamSynchronize(e->stream_v);
@@ -114,7 +113,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,
                     d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
-                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.W, d.Wf, d.G, d.LL, d.LLf, d.R, d.zwork, d.gates, d.cell_resp, d.cell_xy,
+                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.W, d.Wf, d.G, d.LL, d.Tbuf, d.gates, d.cell_resp, d.cell_xy,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.sq_part, d.diag_save, d.cam_part, d.cam_save, d.HPc, d.Gc, d.Bc, d.zvec, d.yvec,
                     e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq};
     for (void *p : ptrs)
@@ -170,6 +169,7 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
         e->desc_f32 = true;
         e->desc_bytes = 4 * cols;
     } else if ((cfg->flags & 0xff) != 0) { delete e; return EKF_ERR_INVALID_ARG; }
+    if (const char *v = std::getenv("EKF_XTY_DEEP")) e->xty_deep = v[0] == '1';
     e->shard_rank = rank;
     e->shard_world = world;
     e->cap = cfg->max_features;
@@ -226,8 +226,6 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
         d.A = raw;
         if ((st = dalloc(&raw, (size_t)(mcap + 1) * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc G");
         d.G = raw;
-        if ((st = dalloc(&raw, (size_t)(mcap + 1) * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc R");
-        d.R = raw;
     }
     ALLOC(d.mm_scratch, (size_t)60 * cap + 4 * (size_t)e->ldP + 64);
     ALLOC(d.mm_index, (size_t)e->ncap + 8);
@@ -265,11 +263,10 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     const size_t mw = (size_t)round_up((int)mcap, 128) + 128;
     ALLOC(d.S, mw * e->ldS);
     ALLOC(d.LL, mw * e->ldS);
-    if (e->f32) ALLOC(d.LLf, mw * e->ldS);
-    ALLOC(d.zwork, mw);
     ALLOC(d.nu, mcap);
     ALLOC(d.Dinv, mw * e->ldW);
     ALLOC(d.W, mw * e->ldW);
+    ALLOC(d.Tbuf, mw * e->ldW);
     if (e->f32) ALLOC(d.Wf, mw * e->ldW);
     ALLOC(d.mHs, 14 * cap);
     ALLOC(d.mHf, 12 * cap);

@@ -109,9 +109,7 @@ struct DeviceArrays {
     void *A = nullptr;   // T [(mcap + 1) x ldP] : B = inv(L) G  (k-major operand of the downdate)
     double *S = nullptr;  // (mcap + slack) x ldS: lower triangle of S, updated in place by the sweep
     double *LL = nullptr; // same shape: L below the 32x32 diagonal blocks and L' mirrored above them
-    float *LLf = nullptr; // fp32 copy of the mirrored part (L', k-major): operand of the fp32 forward-substitution GEMMs
-    void *R = nullptr;    // T [(mcap + 1) x ldP]: working right-hand side of B = inv(L) G (G itself stays intact for dx)
-    double *zwork = nullptr; // [mcap + slack]: working vector of the backward substitution y = inv(L)' z
+    double *Tbuf = nullptr; // [mw x ldW] scratch of the doubling steps (T = L21 X11)
     double *nu = nullptr;
     double *Dinv = nullptr; // V = inv(L), row-major [mw x ldW], built up from 32x32 diagonal blocks by doubling
     double *W = nullptr;    // W = inv(L)' (upper triangular), row-major [mw x ldW]: the k-major operand of B = W' G
@@ -155,65 +153,6 @@ struct Frames {
     uint8_t *desc = nullptr;
 };
 
-// Submission thread of the update's side streams.  An update issues ~60 extra HIP calls for stream_u / stream_v (events,
-// diagonal inverses, the GEMMs of the forward substitution); issued from the caller's thread between the sweep's launches
-// they made the sweep -- 33 dependent ~10 us kernels -- wait for the HOST (measured: 17 us per panel instead of 10.7).
-// The caller's thread now only posts closures; this thread makes the calls.  A ticket counts executed closures: before
-// the caller lets the main stream wait on an event a closure records, it waits for that closure's ticket.
-struct SideWorker {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<std::function<void()>> q;
-    std::atomic<long> done{0};
-    long posted = 0;
-    bool stop = false;
-    void start(int device)
-    {
-        if (th.joinable()) return;
-        th = std::thread([this, device] {
-            (void)hipSetDevice(device);
-            for (;;) {
-                std::function<void()> f;
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [this] { return stop || !q.empty(); });
-                    if (q.empty()) return;
-                    f = std::move(q.front());
-                    q.pop_front();
-                }
-                f();
-                done.fetch_add(1, std::memory_order_release);
-            }
-        });
-    }
-    long post(std::function<void()> f)
-    {
-        long ticket;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            q.push_back(std::move(f));
-            ticket = ++posted;
-        }
-        cv.notify_one();
-        return ticket;
-    }
-    void wait(long ticket)
-    {
-        while (done.load(std::memory_order_acquire) < ticket) std::this_thread::yield();
-    }
-    void shutdown()
-    {
-        if (!th.joinable()) return;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
-        }
-        cv.notify_one();
-        th.join();
-    }
-};
-
 } // namespace ekf
 
 struct EkfEngine {
@@ -245,6 +184,7 @@ struct EkfEngine {
     int pu_tilemap_nt = -1;
     std::map<int, std::pair<void *, int>> pu_tables; // built work lists of the downdate: key -> (device list, units per XCD)
     int pu_per_xcd = 0;
+    bool xty_deep = false; // B GEMM on 32-deep slabs (EKF_XTY_DEEP=1, experiment)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // image-only work of the next frame, overlapped with the update
     hipStream_t stream_u = nullptr;            // update: forward substitution B = inv(L) G, chunk by chunk behind the sweep
@@ -252,7 +192,6 @@ struct EkfEngine {
     std::vector<hipEvent_t> ev_chunks;         // main -> side streams, one per chunk of the sweep
     std::vector<hipEvent_t> ev_invs;           // stream_v -> stream_u, one per chunk
     hipEvent_t ev_b_done = nullptr, ev_dx_done = nullptr, ev_y_done = nullptr;
-    ekf::SideWorker side; // host thread that submits to stream_u / stream_v
     static hipEvent_t pooled_event(std::vector<hipEvent_t> &pool, int i)
     {
         while ((int)pool.size() <= i) {

@@ -5,8 +5,8 @@
 //     S  = G H' + R       (m x m fp64, lower triangle; block-sparse H => 13-term dot products)
 //     S  = L L'           (blocked right-looking Cholesky, fp64, one launch per 32-wide panel; z = inv(L) nu and, in the
 //                          fp32 configuration, the fp64 camera columns of B ride along as right-hand sides)
-//     B  = inv(L) G       (blocked forward substitution in 128-row chunks behind the sweep on a second stream: diagonal-block
-//                          inverse on the fp64 MFMA, the two GEMMs of a chunk in kernels_gemm.hip)
+//     inv(L)              (128 x 128 diagonal chunks beside the sweep, then doubling levels on the fp64 MFMA)
+//     B  = inv(L) G       (ONE GEMM against the inverted factor, kernels_gemm.hip)
 //     dx = B' z           (= K nu,  K = P H' inv(S); fp32 configuration: feature columns as (H P)' y, y = inv(L)' z)
 //     P <- sym(P) - B' B  (= 0.5 ((I-KH)P + ((I-KH)P)'), kernels_pupdate.hip -- the MFMA kernel)
 //     q normalisation and its Jacobian on the rows/columns 3..6 of P (Update.cpp:45-85, 303-317)
@@ -23,7 +23,7 @@ namespace ekf {
 // dead-banded innovation nu (Update.cpp:125-135).  Rows m..m_pad of A are zero-filled for the k-tiled kernels.
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, T *R, int ld, int n_pad, const double *uv_tab,
+k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
          const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
          double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, const T *P, int n, RowMap rm,
          double *dsave, double *csave, int avg)
@@ -53,11 +53,7 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, T *R, int
     if (row < m) {
         const int i = row >> 1, r = row & 1;
         const int fi = matches[i].featureIndex;
-        if (j < n_pad) {
-            const vec_t v = *(const vec_t *)(HP + (size_t)(2 * fi + r) * ld + j);
-            *(vec_t *)(A + (size_t)row * ld + j) = v; // G: stays intact (S, dx)
-            *(vec_t *)(R + (size_t)row * ld + j) = v; // working right-hand side of the forward substitution B = inv(L) G
-        }
+        if (j < n_pad) *(vec_t *)(A + (size_t)row * ld + j) = *(const vec_t *)(HP + (size_t)(2 * fi + r) * ld + j);
         if (blockIdx.x == 0 && threadIdx.x < 16) Gc[(size_t)row * 16 + threadIdx.x] = threadIdx.x < 13 ? HPc[(size_t)(2 * fi + r) * 16 + threadIdx.x] : 0.0;
         if (blockIdx.x == 0 && r == 0) {
             const int t = threadIdx.x;
@@ -77,7 +73,6 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, T *R, int
 #pragma unroll
             for (int v = 0; v < VW; ++v) zero[v] = (T)0;
             *(vec_t *)(A + (size_t)row * ld + j) = zero;
-            *(vec_t *)(R + (size_t)row * ld + j) = zero;
         }
         if (blockIdx.x == 0 && threadIdx.x < 16) Gc[(size_t)row * 16 + threadIdx.x] = 0.0;
         if (blockIdx.x == 0 && threadIdx.x == 0) nu[row] = 0.0;
@@ -169,7 +164,7 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 //   nothing races.  Tile 0 = block (k+1, k+1): look-ahead factorisation, publishes Linv_{k+1}.
 //   nu block: z_k = Linv_k nu_k, then nu_i -= L_ik z_k = S_ik (Linv_k' z_k) for all rows below.
 __global__ void __launch_bounds__(256)
-k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0, int kb, double *nu, int n_stiles, double *V,
+k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, double *nu, int n_stiles, double *V,
             double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc)
 {
     __shared__ double sA[NB][NB + 1];
@@ -281,10 +276,7 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
             }
             for (int i = tid; i < NB * NB; i += 256) {
                 const int c = i / NB, r = i % NB;
-                if (i0 + r < m_pad && c < kb) {
-                    LL[(size_t)(k0 + c) * ldS + i0 + r] = sLI[r][c];
-                    if (LLf) LLf[(size_t)(k0 + c) * ldS + i0 + r] = (float)sLI[r][c];
-                }
+                if (i0 + r < m_pad && c < kb) LL[(size_t)(k0 + c) * ldS + i0 + r] = sLI[r][c];
             }
         }
         return;
@@ -421,65 +413,98 @@ k_inv_diag(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, 
     }
 }
 
-// y = inv(L)' z by blocked BACKWARD substitution, one launch per 128-row chunk J from the last to the first:
-//     y_J = X_JJ' zw_J                       (X_JJ = inverse of the chunk's diagonal block of L, rows of V),
-//     zw_r -= sum_{k in J} L[k][r] y_k        for the rows r above the chunk.
-// Every workgroup forms y_J itself (128 x 128 MACs, coalesced rows of W = inv(L)'); workgroup b then updates rows 64 b ...
-// of the working vector (coalesced row segments of L).  The launches are a dependent chain of tiny kernels: what matters
-// is how many loads each lane has in flight, not the flop count (a one-load-per-iteration loop took 20 us per launch).  Needs only the diagonal-block inverses, so the inverse
-// of the whole factor is never formed.  Runs on the main stream between the sweep and the downdate, while the side stream
-// finishes B: the chain of launches then costs nothing and never competes with the downdate for wavefront slots.
+// ------------------------------------------------------------------------------------------ inverse of L
+// Doubling step s -> 2s:  inv([L11 0; L21 L22]) has the off-diagonal block X21 = -X22 L21 X11.  Two batched products
+// per level (T = L21 X11, X21 = -X22 T), 32x32 output tile per workgroup on the fp64 MFMA.  The levels start at s = 128:
+// the 128 x 128 diagonal chunks are already inverted when the sweep ends (k_inv_diag, beside the sweep).  V = inv(L)
+// row-major, W = V' (+ fp32 copy): after the last level B = inv(L) A is ONE GEMM, B = W' A, with no dependency between
+// row blocks.
+// mode 0: T[pair] = L21 * X11 ;  mode 1: X21 = -X22 * T
 __global__ void __launch_bounds__(256)
-k_ystep(const double *W, int ldw, const double *LL, int ldS, int r0, int rows, double *zw, double *y)
+k_triinv_level(const double *S, int ldS, int m, int m_pad, double *V, double *W, float *Wf, double *Tbuf, int ldw,
+               int s, int mode)
 {
-    __shared__ double sz[128], sy[128], sp[4][64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid < 128) sz[tid] = tid < rows ? zw[r0 + tid] : 0.0;
-    __syncthreads();
-    // y_J[i] = sum_k W[i][k] zw[k]  (W = inv(L)', its rows contiguous in k, zero for k < i): one wavefront per row, 32 rows
-    // per wavefront, every load of the block in flight before the first reduction
-    {
-        const double z0 = sz[lane], z1 = sz[lane + 64];
+    __shared__ double sA[NB][NB + 1];
+    __shared__ double sB[NB][NB + 1];
+    const int tiles = s / NB;
+    const int pair = blockIdx.x / (tiles * tiles);
+    const int t = blockIdx.x % (tiles * tiles);
+    const int tr = t / tiles, tc = t % tiles;
+    const int r0 = pair * 2 * s; // first row of the pair's 2s x 2s diagonal block
+    if (r0 + s + tr * NB >= m_pad) return; // no such rows in the second half
+    const int tid = threadIdx.x;
+    // 16x16 block (bi, bj) of the 32x32 output tile per wavefront, products on the fp64 MFMA (as in k_chol_step)
+    typedef double acc4 __attribute__((ext_vector_type(4)));
+    const int lane = tid & 63, wv = tid >> 6;
+    const int bi = wv >> 1, bj = wv & 1, lr = lane & 15, lk = lane >> 4;
+    acc4 acc = {0, 0, 0, 0};
+    // k-chunks that can be non-zero: X11 and X22 are lower triangular.
+    //   mode 0: X11[kk + r][tc*32 + c] = 0 when kk + 31 < tc*32      -> start at chunk tc
+    //   mode 1: X22[tr*32 + r][kk + c] = 0 when kk > tr*32 + 31      -> stop after chunk tr
+    const int kk_lo = mode == 0 ? tc * NB : 0;
+    const int kk_hi = mode == 0 ? s : (tr + 1) * NB;
+    // this thread's 4 + 4 elements of a chunk, fetched one chunk ahead of the MFMAs
+    double pa[4], pb[4];
+    auto fetch = [&](int kk) {
 #pragma unroll
-        for (int r8 = 0; r8 < 32; r8 += 16) { // 16 rows = 32 loads in flight per lane
-            double part[16];
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                const double *w = W + (size_t)(r0 + wv * 32 + r8 + rr) * ldw + r0;
-                part[rr] = w[lane] * z0 + w[lane + 64] * z1; // unconditional: a uniform branch here would serialise the loads
-            }
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                double s = part[rr];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-                if (lane == 0) {
-                    const int i = wv * 32 + r8 + rr;
-                    sy[i] = i < rows ? s : 0.0;
-                    if (blockIdx.x == 0 && i < rows) y[r0 + i] = s;
-                }
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * 256;
+            const int r = i / NB, c = i % NB;
+            if (mode == 0) {
+                const int gr = r0 + s + tr * NB + r, gc = r0 + kk + c; // L21 (rows m..m_pad of L are zero)
+                pa[q] = (gr < m) ? S[(size_t)gr * ldS + gc] : 0.0;
+                pb[q] = V[(size_t)(r0 + kk + r) * ldw + r0 + tc * NB + c]; // X11[kk + r][tc*32 + c]
+            } else {
+                pa[q] = V[(size_t)(r0 + s + tr * NB + r) * ldw + r0 + s + kk + c]; // X22[tr*32 + r][kk + c]
+                pb[q] = Tbuf[(size_t)(r0 + s + kk + r) * ldw + tc * NB + c];       // T[kk + r][tc*32 + c]
             }
         }
-    }
-    __syncthreads();
-    // zw[r] -= sum_k L[k][r] y_k for 64 rows r of this workgroup: the k-range in 4 quarters (one per wavefront), eight loads
-    // in flight per lane, partial sums through LDS
-    const int r = blockIdx.x * 64 + lane;
-    double s = 0.0;
-    if (r < r0) {
-        const double *l = LL + (size_t)(r0 + wv * 32) * ldS + r; // L[k][r], k = row
+    };
+    fetch(kk_lo);
+    for (int kk = kk_lo; kk < kk_hi; kk += NB) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) s += l[(size_t)k * ldS] * sy[wv * 32 + k]; // rows past the chunk's end: allocated, times 0
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * 256;
+            sA[i / NB][i % NB] = pa[q];
+            sB[i / NB][i % NB] = pb[q];
+        }
+        __syncthreads();
+        if (kk + NB < kk_hi) fetch(kk + NB);
+#pragma unroll
+        for (int k4 = 0; k4 < NB; k4 += 4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[16 * bi + lr][k4 + lk], sB[k4 + lk][16 * bj + lr], acc, 0, 0, 0);
+        __syncthreads();
     }
-    sp[wv][lane] = s;
-    __syncthreads();
-    if (wv == 0 && r < r0) zw[r] -= (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 16 * bi + lk + 4 * q, c = 16 * bj + lr;
+        const int gi = r0 + s + tr * NB + r, gj = tc * NB + c;
+        if (mode == 0) {
+            Tbuf[(size_t)gi * ldw + gj] = acc[q];
+        } else {
+            V[(size_t)gi * ldw + r0 + gj] = -acc[q];
+            W[(size_t)(r0 + gj) * ldw + gi] = -acc[q];
+            if (Wf) Wf[(size_t)(r0 + gj) * ldw + gi] = (float)(-acc[q]);
+        }
+    }
 }
 
-// PART 3: everything in one pass over B (what the update uses: dx, the fp64 diagonal and the 13 camera rows of B'B).
-// PART 0 / 1 / 2: dx + diagonal / camera rows 0..6 / camera rows 7..12 as separate lean instances (<= 56 VGPRs, what fits
-// on a SIMD beside three 152-VGPR wavefronts of the downdate).  Running them beside the downdate was measured and lost:
-// they took 4-10x longer there and slowed the downdate by 70 us, more than the 30 us the combined kernel costs in front.
+// y = inv(L)' z = W z (W upper triangular, fp64): with it dx = (H P)' y = G' inv(S) nu, the gain applied without going
+// through B.  fp32 configuration only: B = inv(L) G comes out of an fp32 MFMA GEMM (accumulation error ~ sqrt(m) eps per
+// element), G is the fp64-accumulated H P rounded once -- measured at N = 1000: the inverse-depth components were
+// 2e-7 ... 1e-6 off (up to 8e-5 of a small rho) through B' z.  One wavefront per row.
+__global__ void __launch_bounds__(256) k_yvec(const double *W, int ldw, int m, const double *z, double *y)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= m) return;
+    const double *w = W + (size_t)i * ldw;
+    double s = 0.0;
+    for (int k = i + lane; k < m; k += 64) s += w[k] * z[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) y[i] = s;
+}
+
 template <typename T, int PART>
 __global__ void __launch_bounds__(256)
 k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, int ldpart, double *sq_part, double *cam_part,
@@ -592,10 +617,8 @@ k_state_apply(double *st, double *feat_pos, const int *feat_type, const int *fea
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t == 0) {
         double *x = st + ST_X;
-#pragma unroll 1
-        for (int i = 0; i < 13; ++i) { // rolled loops: this kernel must stay small enough to run beside the downdate
+        for (int i = 0; i < 13; ++i) {
             double s = 0.0;
-#pragma unroll 1
             for (int ks = 0; ks < DX_SPLIT; ++ks) s += part[(size_t)ks * ldpart + i];
             if (fabs(s) > EKF_DELTA) x[i] += s;
         }
@@ -609,7 +632,6 @@ k_state_apply(double *st, double *feat_pos, const int *feat_type, const int *fea
     if (a >= feat_dim(feat_type[f])) return;
     const int j = feat_covpos[f] + a;
     double s = 0.0;
-#pragma unroll 4
     for (int ks = 0; ks < DX_SPLIT; ++ks) s += part[(size_t)ks * ldpart + j];
     if (fabs(s) > EKF_DELTA) feat_pos[6 * f + a] += s;
 }
@@ -681,37 +703,29 @@ __global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, cons
 // P-update launcher lives in kernels_pupdate.hip
 void launch_p_update(EkfEngine *e, int m_pad);
 
-// One update = three streams.  Main stream: gather, S, the sweep (one launch per 32-wide panel), then the downdate and
-// its tail.  Behind the sweep, chunk by chunk (4 panels = 128 rows), B = inv(L) G by blocked forward substitution on the
-// working copy R of G:
-//   stream_u   X_cc = inverse of the chunk's 128 x 128 diagonal block of L     (k_inv_diag)
-//              B_c  = X_cc R_c                                                 (k_xty, k inside the chunk)
-//              even chunk: R_{c+1} -= L_{c+1,c} B_c                            (the next chunk only, k = 128)
-//              odd chunk : R_below -= L_below,{c-1,c} B_{c-1,c}                (all rows below, k = 256: one pass over R per
-//                          PAIR of chunks -- with k = 128 the pass is bound by its reads and writes of R, not by the MFMAs)
-// so the big GEMMs run while the sweep factorises the following chunks and only the last chunk's small pieces are left
-// when it ends (the previous form -- inverse of the whole factor by doubling, then one GEMM -- put 12 + 1 dependent
-// launches, ~200 us at m = 1000, behind the sweep).  The side streams are fed by the engine's worker thread (SideWorker).
-// After the sweep the main stream, idle until B is complete, runs y = inv(L)' z (blocked backward substitution); then dx,
-// the state update and the downdate follow on it in order.
+// One update: gather, S, the sweep (one launch per 32-wide panel), inv(L), B = inv(L) G as one GEMM, y, dx, the state
+// update, the downdate and its tail, all on the engine's stream -- except the inverses of the 128 x 128 diagonal chunks of
+// L, which a side stream (stream_v) computes chunk by chunk BEHIND the sweep (k_inv_diag: three workgroups per chunk, they
+// do not disturb the sweep), so that the doubling levels left for after the sweep start at 128 instead of 32.
+// Measured and rejected this round: B by blocked forward substitution on a side stream beside the
+// sweep.  Its short-k GEMMs are latency-bound (~4x the time of the single GEMM) and their workgroups take the CUs the
+// sweep's latency-critical launches need (a panel step went from 10.7 to 15-49 us): 1.12 ms per update against 0.97.
 template <typename T>
 static void update_impl(EkfEngine *e, int M, bool update_cov)
 {
-    hipStream_t s = e->stream, su = e->stream_u;
+    hipStream_t s = e->stream, sv = e->stream_v;
     const int m = 2 * M, n = e->n, ld = e->ldP, ldS = e->ldS, ldw = e->ldW;
     const int m_pad = round_up(m, NB);
     const int n_pad = round_up(n, LD_ALIGN);
     T *G = (T *)e->d.G; // gathered rows of H P
-    T *R = (T *)e->d.R; // working right-hand side
     T *A = (T *)e->d.A; // B = inv(L) G
     double *V = e->d.Dinv, *W = e->d.W;
     float *Wf = e->f32 ? e->d.Wf : nullptr;
-    float *LLf = e->f32 ? e->d.LLf : nullptr;
     const bool fix = update_cov && sizeof(T) == 4;
     {
         dim3 grid((n_pad / (int)(16 / sizeof(T)) + 255) / 256, m_pad);
         const int avg = e->p_exact_sym ? 0 : 1; // an AVG downdate only exists on an unsharded engine: every row is local
-        k_gather<T><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const T *)e->d.HP, G, R, ld, n_pad, e->d.pred_uv,
+        k_gather<T><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const T *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
                                          e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc, (const T *)e->d.P, n, e->rm,
                                          e->d.diag_save, fix ? e->d.cam_save : nullptr, avg);
@@ -723,49 +737,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     }
     const int nbk = m_pad / NB; // panels = block rows
     const int n_chunks = (nbk + INV_CH - 1) / INV_CH;
-    const int TM = sizeof(T) == 4 ? 128 : 64;
-    constexpr int CH = INV_CH * NB; // rows per chunk
-    // side-stream work of one chunk, submitted by the engine's worker thread (SideWorker, engine.h)
-    hipStream_t sv = e->stream_v;
-    e->side.start(e->device);
-    (void)e->chunk_event(n_chunks - 1); // the event pools grow here, on the caller's thread, never under the worker
-    (void)e->inv_event(n_chunks - 1);
-    auto side_chunk = [=](int c) {
-        const int a_first = c * INV_CH, a_count = min(INV_CH, nbk - a_first);
-        const int r0 = a_first * NB, rows = a_count * NB;
-        (void)hipStreamWaitEvent(sv, e->chunk_event(c), 0);
-        if (a_count > 1) k_inv_diag<<<a_count - 1, 256, 0, sv>>>(e->d.LL, ldS, V, W, Wf, ldw, a_first, a_count);
-        (void)hipEventRecord(e->inv_event(c), sv);
-        (void)hipStreamWaitEvent(su, e->inv_event(c), 0);
-        XtyArgs g{};
-        g.ldy = ld; g.ldc = ld;
-        g.M = m_pad; g.N = n_pad;
-        g.row0_first = 0; g.row0_stride = 0; g.m_lim = m_pad;
-        g.tiles_j = (n_pad + TM - 1) / TM;
-        // B_c = X_cc R_c : X operand W = inv(L)' (k-major), k from the chunk's first row up to the row tile's end
-        g.X = e->f32 ? (const void *)Wf : (const void *)W; g.ldx = ldw;
-        g.Y = R; g.C = A;
-        g.tri = 2; g.k_first = r0; g.K = m_pad;
-        g.ti_first = r0 / TM; g.tiles_i = (rows + TM - 1) / TM; g.n_split = g.tiles_i;
-        g.alpha = 1.0; g.accumulate = 0; g.deep = 1;
-        launch_xty(e, g, 1, e->f32, su);
-        const int below = r0 + rows; // first row below the chunk
-        if (below >= m_pad) return;
-        // R -= L B : X operand = L' (mirrored part of LL, k-major)
-        g.X = e->f32 ? (const void *)LLf : (const void *)e->d.LL; g.ldx = ldS;
-        g.Y = A; g.C = R;
-        g.tri = 0; g.alpha = -1.0; g.accumulate = 1;
-        g.ti_first = below / TM;
-        if (c % 2 == 0) { // the next chunk only needs this chunk's term before its own solve
-            g.k_first = r0; g.K = below;
-            g.tiles_i = (min(CH, m_pad - below) + TM - 1) / TM; g.n_split = g.tiles_i;
-        } else {          // everything below the pair: the terms of both chunks in one pass
-            g.k_first = r0 - CH; g.K = below;
-            g.tiles_i = (m_pad - below + TM - 1) / TM; g.n_split = g.tiles_i;
-        }
-        launch_xty(e, g, 1, e->f32, su);
-    };
-    long ticket_last = 0;
+    constexpr int CH = INV_CH * NB;
     for (int k = 0; k < nbk; ++k) {
         const int k0 = k * NB;
         const int kb = min(NB, m - k0);
@@ -773,31 +745,50 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const int nrb = (m - k1 + NB - 1) / NB; // row blocks below the panel
         const int n_stiles = nrb * (nrb + 1) / 2;
         const int n_rhs_blocks = max(1, (m - k1 + 255) / 256); // right-hand-side blocks, 256 rows each
-        k_chol_step<<<n_stiles + n_rhs_blocks, 256, 0, s>>>(e->d.S, e->d.LL, LLf, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles, V, W, Wf,
+        k_chol_step<<<n_stiles + n_rhs_blocks, 256, 0, s>>>(e->d.S, e->d.LL, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles, V, W, Wf,
                                                             ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr, e->d.zvec, e->d.Bc);
         if (k % INV_CH != INV_CH - 1 && k != nbk - 1) continue;
-        // the chunk's panels are factorised (inv(L_kk) published one launch earlier, column k of L stored by launch k)
+        // the chunk's panels are factorised (inv(L_kk) published one launch earlier, column k of L stored by launch k):
+        // its 128 x 128 diagonal block of L is inverted beside the sweep
         const int c = k / INV_CH;
-        (void)hipEventRecord(e->chunk_event(c), s);
-        ticket_last = e->side.post([=] { side_chunk(c); });
-    }
-    const long ticket_b = e->side.post([=] { (void)hipEventRecord(e->ev_b_done, su); });
-    if (sizeof(T) == 4) {
-        // y = inv(L)' z on the MAIN stream, which would otherwise idle until B is complete: needs the diagonal inverses
-        // of every chunk (the event the last chunk's closure records on stream_v) and z (final with the sweep)
-        e->side.wait(ticket_last);
-        (void)hipStreamWaitEvent(s, e->inv_event(n_chunks - 1), 0);
-        (void)hipMemcpyAsync(e->d.zwork, e->d.zvec, (size_t)m_pad * sizeof(double), hipMemcpyDeviceToDevice, s);
-        for (int c = n_chunks - 1; c >= 0; --c) {
-            const int r0 = c * CH, rows = min(CH, m_pad - r0);
-            k_ystep<<<max(1, (r0 + 63) / 64), 256, 0, s>>>(W, ldw, e->d.LL, ldS, r0, rows, e->d.zwork, e->d.yvec);
+        const int a_first = c * INV_CH, a_count = min(INV_CH, nbk - a_first);
+        if (a_count > 1) {
+            (void)hipEventRecord(e->chunk_event(c), s);
+            (void)hipStreamWaitEvent(sv, e->chunk_event(c), 0);
+            k_inv_diag<<<a_count - 1, 256, 0, sv>>>(e->d.LL, ldS, V, W, Wf, ldw, a_first, a_count);
         }
     }
-    e->side.wait(ticket_b); // every closure has run: nothing of this update is left to submit from the worker
+    (void)hipEventRecord(e->ev_b_done, sv);
     (void)hipStreamWaitEvent(s, e->ev_b_done, 0);
+    // inv(L) by doubling from the 128-chunks: 128 -> 256 -> ... until one block covers all rows
+    for (int sz = CH; sz < m_pad; sz *= 2) {
+        const int npairs = (m_pad - sz + 2 * sz - 1) / (2 * sz); // pairs whose second half has rows
+        const int tiles = (sz / NB) * (sz / NB);
+        k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.LL, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 0);
+        k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.LL, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 1);
+    }
+    (void)n_chunks;
+    {   // B = inv(L) G = W' G : one GEMM, k <= row (W upper triangular)
+        const int TM = sizeof(T) == 4 ? 128 : 64;
+        XtyArgs g{};
+        g.X = e->f32 ? (const void *)Wf : (const void *)W; g.ldx = ldw;
+        g.Y = G; g.ldy = ld;
+        g.C = A; g.ldc = ld;
+        g.M = m_pad; g.N = n_pad; g.K = m_pad;
+        g.row0_first = 0; g.row0_stride = 0; g.m_lim = m_pad;
+        g.tri = 2; g.tiles_i = (m_pad + TM - 1) / TM; g.tiles_j = (n_pad + TM - 1) / TM; g.alpha = 1.0;
+        g.n_split = g.tiles_i / 2; // k-depth of row tile i is ~(i+1) TM: halve the units of the longer half
+        g.deep = e->xty_deep ? 1 : 0;
+        launch_xty(e, g, 1, e->f32, s);
+    }
     {
-        const double *Bc = sizeof(T) == 4 ? e->d.Bc : nullptr; // inv(L) Gc, from the right-hand-side blocks of k_chol_step
-        const T *Gy = sizeof(T) == 4 ? G : nullptr;
+        const double *Bc = nullptr;
+        const T *Gy = nullptr;
+        if (sizeof(T) == 4) {
+            Bc = e->d.Bc; // inv(L) Gc, produced by the right-hand-side blocks of k_chol_step
+            k_yvec<<<(m + 3) / 4, 256, 0, s>>>(W, ldw, m, e->d.zvec, e->d.yvec);
+            Gy = G;
+        }
         dim3 grid((n + 255) / 256, DX_SPLIT);
         k_dx_partial<T, 3><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, fix ? e->d.sq_part : nullptr,
                                                 fix ? e->d.cam_part : nullptr, Bc, Gy, e->d.yvec);
