@@ -127,8 +127,11 @@ def load_library():
         import torch  # noqa: F401  (pulls in torch's libamdhip64 before ours resolves the same SONAME)
     except Exception:
         pass
-    L = C.CDLL(LIB_PATH)
+    override = os.environ.get("EKF_ENGINE_LIB")  # A/B timing of another build of the engine (scripts/build_variant.sh)
+    L = C.CDLL(os.path.abspath(override) if override else LIB_PATH)
     for name, (rt, at) in ABI.items():
+        if override and not hasattr(L, name):
+            continue
         fn = getattr(L, name)
         fn.restype = rt
         fn.argtypes = at
