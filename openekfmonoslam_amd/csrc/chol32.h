@@ -301,153 +301,4 @@ __device__ __forceinline__ bool block_chol_inv32_mf(double (*a)[CH_NB + 1], doub
     return ok;
 }
 
-// Same elimination, the 4x4 pivot step without its chain of four dependent reciprocals: what a lane needs from the pivot
-// block D is ONE column of inv(D) (column lq = lane / 16, the k-index it feeds to the MFMA), and a column of the inverse
-// of a 4x4 matrix is four 3x3 cofactors over the determinant -- 2x2 minors, cofactors, determinant, one reciprocal:
-// ~30 independent-ish operations of depth ~8 instead of an LDL' factorisation plus two triangular solves of depth ~50.
-// Every lane relabels the block so that its column is the LAST one (indices lq and 3 swapped on the way out of LDS); the
-// four numbers that then decide positive definiteness (leading minors a, ac - b^2, the 3x3 one, det) are by-products.
-// The LDL' factors of the pivot blocks, needed only by the final in-block solves, are computed once after the sweep
-// (one lane per block) from the saved blocks.  cond(D) <= cond(S) (S = H P H' + R, lambda_min >= pixelError), so the
-// cofactor form loses nothing that matters at fp64.
-// TR (micro-benchmark only): thread 0 stores clock64() at six points of every pivot step, each behind a full wait.
-template <bool TR = false>
-__device__ __forceinline__ bool block_chol_inv32_adj(double (*a)[CH_NB + 1], double (*x)[CH_NB + 1], long long *tr = nullptr)
-{
-#define CH_TR(slot)                                                       \
-    if (TR) {                                                            \
-        __builtin_amdgcn_s_waitcnt(0);                                   \
-        if (t == 0) tr[J * 6 + (slot)] = clock64();                      \
-    }
-    typedef double acc4 __attribute__((ext_vector_type(4)));
-    __shared__ double pc[2][CH_NB][4];      // pc[buf][r][k] = A[r][4J + k]
-    __shared__ double pr[2][4][2 * CH_NB];  // pr[buf][k][c] = [A | X][4J + k][c]
-    __shared__ double dsv[8][10];           // the pivot blocks as they were eliminated (lower triangle, row-major)
-    __shared__ double fac[8][10];
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int lc = lane & 15, lq = lane >> 4;
-    acc4 m0, m1;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int r0 = lq + 4 * v, r1 = 16 + lq + 4 * v, c = 16 * w + lc;
-        if (w < 2) {
-            m0[v] = c <= r0 ? a[r0][c] : a[c][r0];
-            m1[v] = c <= r1 ? a[r1][c] : a[c][r1];
-        } else {
-            m0[v] = (c - CH_NB == r0) ? 1.0 : 0.0;
-            m1[v] = (c - CH_NB == r1) ? 1.0 : 0.0;
-        }
-    }
-    // relabelling: index lq <-> 3
-    const int p0 = lq == 0 ? 3 : 0, p1 = lq == 1 ? 3 : 1, p2 = lq == 2 ? 3 : 2, p3 = lq;
-    bool ok = true;
-#pragma unroll
-    for (int J = 0; J < 8; ++J) {
-        const int p = J & 1, j0 = 4 * J;
-        if (w == j0 / 16) {
-            const int k = lc - (j0 % 16);
-            if (k >= 0 && k < 4) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    pc[p][lq + 4 * v][k] = m0[v];
-                    pc[p][16 + lq + 4 * v][k] = m1[v];
-                }
-            }
-        }
-        {
-            const int v0 = (j0 % 16) / 4;
-            const acc4 &src = (j0 < 16) ? m0 : m1;
-            pr[p][lq][16 * w + lc] = src[v0];
-        }
-        CH_TR(0)
-        __syncthreads();
-        CH_TR(1)
-        const double(*pn)[4] = pc[p];
-        // the relabelled symmetric block: P[u][v] = D[perm u][perm v]
-        const double da = pn[j0 + p0][p0];
-        const double db = pn[j0 + p1][p0], dc = pn[j0 + p1][p1];
-        const double dd = pn[j0 + p2][p0], de = pn[j0 + p2][p1], df = pn[j0 + p2][p2];
-        const double dg = pn[j0 + p3][p0], dh = pn[j0 + p3][p1], di = pn[j0 + p3][p2], dj = pn[j0 + p3][p3];
-        if (t < 10) { // keep the block (original labelling) for the factors the final solves need
-            const int r = t < 1 ? 0 : (t < 3 ? 1 : (t < 6 ? 2 : 3));
-            const int c = t - r * (r + 1) / 2;
-            dsv[J][t] = pn[j0 + r][c];
-        }
-        CH_TR(2)
-        const double m01 = da * dc - db * db, m02 = da * de - db * dd, m12 = db * de - dc * dd;
-        const double n01 = dd * dh - de * dg, n02 = dd * di - df * dg, n12 = de * di - df * dh;
-        const double C33 = df * m01 - de * m02 + dd * m12;
-        const double C23 = -(di * m01 - dh * m02 + dg * m12);
-        const double C13 = da * n12 - db * n02 + dd * n01;
-        const double C03 = -(db * n12 - dc * n02 + de * n01);
-        const double det = dg * C03 + dh * C13 + di * C23 + dj * C33;
-        ok = ok && da > 0.0 && m01 > 0.0 && C33 > 0.0 && det > 0.0;
-        const double rdet = fast_rcp(det);
-        const double q0 = C03 * rdet, q1 = C13 * rdet, q2 = C23 * rdet, q3 = C33 * rdet; // relabelled column of inv(D)
-        if (TR) { if (q0 + q1 + q2 + q3 == 12345.678) tr[100] = 1; }
-        CH_TR(3)
-        const int r0 = lc, r1 = 16 + lc;
-        double w0 = pn[r0][p0] * q0 + pn[r0][p1] * q1 + pn[r0][p2] * q2 + pn[r0][p3] * q3;
-        double w1 = pn[r1][p0] * q0 + pn[r1][p1] * q1 + pn[r1][p2] * q2 + pn[r1][p3] * q3;
-        if (r0 < j0 + 4) w0 = 0.0;
-        if (r1 < j0 + 4) w1 = 0.0;
-        const double bv = pr[p][lq][16 * w + lc];
-        if (TR) { if (w0 + w1 + bv == 12345.678) tr[100] = 1; }
-        CH_TR(4)
-        m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-w0, bv, m0, 0, 0, 0);
-        m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-w1, bv, m1, 0, 0, 0);
-        if (TR) { if (m0[0] + m1[3] == 12345.678) tr[100] = 1; }
-        CH_TR(5)
-    }
-#undef CH_TR
-    __syncthreads();
-    if (w >= 2) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            x[lq + 4 * v][16 * (w - 2) + lc] = m0[v];
-            x[16 + lq + 4 * v][16 * (w - 2) + lc] = m1[v];
-        }
-    }
-    if (t < 8) { // LDL' of pivot block t: l10 l20 l30 l21 l31 l32 and the reciprocal pivots
-        const double *dv = dsv[t];
-        const double d00 = dv[0], d10 = dv[1], d11 = dv[2], d20 = dv[3], d21 = dv[4], d22 = dv[5], d30 = dv[6], d31 = dv[7],
-                     d32 = dv[8], d33 = dv[9];
-        const double i0 = fast_rcp(d00);
-        const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
-        const double e11 = d11 - l10 * d10;
-        const double e21 = d21 - l20 * d10, e31 = d31 - l30 * d10;
-        const double i1 = fast_rcp(e11);
-        const double l21 = e21 * i1, l31 = e31 * i1;
-        const double e22 = d22 - l20 * d20 - l21 * e21;
-        const double e32 = d32 - l30 * d20 - l31 * e21;
-        const double i2 = fast_rcp(e22);
-        const double l32 = e32 * i2;
-        const double e33 = d33 - l30 * d30 - l31 * e31 - l32 * e32;
-        const double i3 = fast_rcp(e33);
-        double *f = fac[t];
-        f[0] = l10; f[1] = l20; f[2] = l30; f[3] = l21; f[4] = l31; f[5] = l32;
-        f[6] = i0; f[7] = i1; f[8] = i2; f[9] = i3;
-    }
-    __syncthreads();
-    const int r = t >> 3, c0 = (t & 7) * 4;
-    const int base = r & ~3, q = r & 3;
-    const double *f = fac[r >> 2];
-    double res[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int c = c0 + e;
-        const double u0 = x[base][c];
-        const double u1 = x[base + 1][c] - f[0] * u0;
-        const double u2 = x[base + 2][c] - f[1] * u0 - f[3] * u1;
-        const double u3 = x[base + 3][c] - f[2] * u0 - f[4] * u1 - f[5] * u2;
-        res[e] = q == 0 ? u0 : (q == 1 ? u1 : (q == 2 ? u2 : u3));
-    }
-    const double sr = sqrt(f[6 + q]);
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) x[r][c0 + e] = (c0 + e <= r) ? res[e] * sr : 0.0;
-    __syncthreads();
-    return ok;
-}
-
 } // namespace ekf

@@ -106,8 +106,6 @@ void ekf_engine_destroy(EkfEngine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    if (e->stream_u) (void)hipStreamSynchronize(e->stream_u);
-    if (e->stream_v) (void)hipStreamSynchronize(e->stream_v);
     DeviceArrays &d = e->d;
     void *ptrs[] = {d.state,     d.feat_pos,  d.feat_type, d.feat_covpos, d.feat_desc, d.feat_times_predicted, d.feat_times_matched, d.P, d.P2, d.mm_scratch, d.mm_index,        d.pred_vis, d.pred_vis_full, d.step_preds,
                     d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,
@@ -129,15 +127,6 @@ void ekf_engine_destroy(EkfEngine *e)
     if (e->comm && rccl_api().ok) (void)rccl_api().CommDestroy((ncclComm_t)e->comm);
     if (e->h_mirror) (void)hipHostFree(e->h_mirror);
     if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
-    if (e->stream_u) { (void)hipStreamSynchronize(e->stream_u); (void)hipStreamDestroy(e->stream_u); }
-    if (e->stream_v) { (void)hipStreamSynchronize(e->stream_v); (void)hipStreamDestroy(e->stream_v); }
-    for (auto ev : e->ev_chunks)
-        if (ev) (void)hipEventDestroy(ev);
-    for (auto ev : e->ev_invs)
-        if (ev) (void)hipEventDestroy(ev);
-    if (e->ev_b_done) (void)hipEventDestroy(e->ev_b_done);
-    if (e->ev_dx_done) (void)hipEventDestroy(e->ev_dx_done);
-    if (e->ev_y_done) (void)hipEventDestroy(e->ev_y_done);
     if (e->ev_main) (void)hipEventDestroy(e->ev_main);
     if (e->ev_prefetch) (void)hipEventDestroy(e->ev_prefetch);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -169,7 +158,6 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
         e->desc_f32 = true;
         e->desc_bytes = 4 * cols;
     } else if ((cfg->flags & 0xff) != 0) { delete e; return EKF_ERR_INVALID_ARG; }
-    if (const char *v = std::getenv("EKF_XTY_DEEP")) e->xty_deep = v[0] == '1';
     e->shard_rank = rank;
     e->shard_world = world;
     e->cap = cfg->max_features;
@@ -188,16 +176,6 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     if ((st = hipSetDevice(e->device)) != hipSuccess) return fail(st, "hipSetDevice");
     if ((st = hipStreamCreate(&e->stream)) != hipSuccess) return fail(st, "hipStreamCreate");
     if ((st = hipStreamCreate(&e->stream2)) != hipSuccess) return fail(st, "hipStreamCreate");
-    {   // the side streams of the update carry short dependent launches that must not queue behind the downdate's
-        // workgroups (measured: a 3 us launch waited 40-150 us for a slot at equal priority): highest priority
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if ((st = hipStreamCreateWithPriority(&e->stream_u, hipStreamNonBlocking, hi)) != hipSuccess) return fail(st, "hipStreamCreate");
-        if ((st = hipStreamCreateWithPriority(&e->stream_v, hipStreamNonBlocking, hi)) != hipSuccess) return fail(st, "hipStreamCreate");
-    }
-    if ((st = hipEventCreateWithFlags(&e->ev_b_done, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
-    if ((st = hipEventCreateWithFlags(&e->ev_dx_done, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
-    if ((st = hipEventCreateWithFlags(&e->ev_y_done, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
     if ((st = hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
     if ((st = hipEventCreateWithFlags(&e->ev_prefetch, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
     DeviceArrays &d = e->d;

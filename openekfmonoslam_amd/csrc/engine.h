@@ -2,14 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include <atomic>
-#include <condition_variable>
 #include <cstdint>
-#include <deque>
-#include <functional>
 #include <map>
-#include <mutex>
-#include <thread>
 #include <string>
 #include <vector>
 
@@ -184,25 +178,8 @@ struct EkfEngine {
     int pu_tilemap_nt = -1;
     std::map<int, std::pair<void *, int>> pu_tables; // built work lists of the downdate: key -> (device list, units per XCD)
     int pu_per_xcd = 0;
-    bool xty_deep = false; // B GEMM on 32-deep slabs (EKF_XTY_DEEP=1, experiment)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // image-only work of the next frame, overlapped with the update
-    hipStream_t stream_u = nullptr;            // update: forward substitution B = inv(L) G, chunk by chunk behind the sweep
-    hipStream_t stream_v = nullptr;            // update: diagonal-block inverses behind the sweep; y, dx, state beside the downdate
-    std::vector<hipEvent_t> ev_chunks;         // main -> side streams, one per chunk of the sweep
-    std::vector<hipEvent_t> ev_invs;           // stream_v -> stream_u, one per chunk
-    hipEvent_t ev_b_done = nullptr, ev_dx_done = nullptr, ev_y_done = nullptr;
-    static hipEvent_t pooled_event(std::vector<hipEvent_t> &pool, int i)
-    {
-        while ((int)pool.size() <= i) {
-            hipEvent_t ev = nullptr;
-            (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-            pool.push_back(ev);
-        }
-        return pool[i];
-    }
-    hipEvent_t chunk_event(int i) { return pooled_event(ev_chunks, i); }
-    hipEvent_t inv_event(int i) { return pooled_event(ev_invs, i); }
     hipEvent_t ev_main = nullptr, ev_prefetch = nullptr;
     ekf::DeviceArrays d;
     ekf::Frames frames;

@@ -99,21 +99,10 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
         PU_STORE(3, 0)
     }
     __syncthreads();
-    // The P values of the tile are requested EARLY: those of the first block row at the top of the last k-slab (the slab
-    // staging registers are free by then; the round trip hides behind that slab's MFMAs), those of the second block row
-    // right after the loop -- the epilogue used to expose one HBM round trip per block row.
-    typename M::acc_t pv00, pv01, pv10, pv11; // named: an indexed array here ends up in scratch
-#define PU_LOADP(dst, x, yy)                                                                                       \
-    {                                                                                                              \
-        const int pbi = I0 + rbase + (x) * MB, pbj = J0 + wc * 2 * MB + (yy) * MB;                                 \
-        _Pragma("unroll") for (int r = 0; r < M::NACC; ++r) {                                                      \
-            const int gi = pbi + M::row(r, lane), gj = pbj + M::col(lane);                                         \
-            dst[r] = (gi < ilim && gj < n) ? P[(size_t)(gi + p_off) * ldp + gj] : (T)0;                            \
-        }                                                                                                          \
-    }
-    for (int kt = 0; kt + 1 < nk; ++kt) {
+    for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        {   // prefetch the next slab into registers while this one is consumed from LDS
+        const bool more = kt + 1 < nk;
+        if (more) { // prefetch the next slab into registers while this one is consumed from LDS
             const size_t off = (size_t)(kt + 1) * slab;
             PU_LOAD(0, off)
             PU_LOAD(1, off)
@@ -124,22 +113,14 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
         }
         if (full) pu_slab<T, true, TM>(sI[buf], sJ[buf], klane, rbase + idx, wc * 2 * MB + idx, c00, c01, c10, c11);
         else pu_slab<T, false, TM>(sI[buf], sJ[buf], klane, rbase + idx, wc * 2 * MB + idx, c00, c01, c10, c11);
-        PU_STORE(0, buf ^ 1)
-        PU_STORE(1, buf ^ 1)
-        if (LOADS == 4) {
-            PU_STORE(2, buf ^ 1)
-            PU_STORE(3, buf ^ 1)
+        if (more) {
+            PU_STORE(0, buf ^ 1)
+            PU_STORE(1, buf ^ 1)
+            if (LOADS == 4) {
+                PU_STORE(2, buf ^ 1)
+                PU_STORE(3, buf ^ 1)
+            }
         }
-        __syncthreads();
-    }
-    {   // last slab, peeled: no prefetch any more, the staging registers carry the first block row's P values instead
-        const int buf = (nk - 1) & 1;
-        if (!AVG) {
-            PU_LOADP(pv00, 0, 0)
-            PU_LOADP(pv01, 0, 1)
-        }
-        if (full) pu_slab<T, true, TM>(sI[buf], sJ[buf], klane, rbase + idx, wc * 2 * MB + idx, c00, c01, c10, c11);
-        else pu_slab<T, false, TM>(sI[buf], sJ[buf], klane, rbase + idx, wc * 2 * MB + idx, c00, c01, c10, c11);
         __syncthreads();
     }
 #undef PU_STORE
@@ -152,16 +133,25 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
     //    instead of scattered 4-byte stores).
     //  - AVG (first update after an arbitrary upload): P(i,j) <- 0.5 (P(i,j) + P(j,i)) - acc on i <= j, mirrored.
     T *sT = smem + wv * MB * (MB + 1);
-    if (!AVG && full) {
-        PU_LOADP(pv10, 1, 0)
-        PU_LOADP(pv11, 1, 1)
-    }
-#undef PU_LOADP
+    // the P values of BOTH blocks of a block row are requested before the first one is needed: the epilogue of a tile
+    // is a 64 KB read-modify-write whose latency was exposed once per MFMA block
+    typename M::acc_t pv[2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) {
             if (x == 1 && !full) continue;
+            if (!AVG && y == 0) {
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy) {
+                    const int pbi = I0 + rbase + x * MB, pbj = J0 + wc * 2 * MB + yy * MB;
+#pragma unroll
+                    for (int r = 0; r < M::NACC; ++r) {
+                        const int gi = pbi + M::row(r, lane), gj = pbj + M::col(lane);
+                        pv[yy][r] = (gi < ilim && gj < n) ? P[(size_t)(gi + p_off) * ldp + gj] : (T)0;
+                    }
+                }
+            }
             const int bi = I0 + rbase + x * MB, bj = J0 + wc * 2 * MB + y * MB;
             const typename M::acc_t &cc = x == 0 ? (y == 0 ? c00 : c01) : (y == 0 ? c10 : c11);
             if (AVG) {
@@ -184,8 +174,7 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
                 const int gi = bi + li, gj = bj + lj;
                 T v = (T)0;
                 if (gi < ilim && gj < n) {
-                    const typename M::acc_t &pp = x == 0 ? (y == 0 ? pv00 : pv01) : (y == 0 ? pv10 : pv11);
-                    v = pp[r] - cc[r];
+                    v = pv[y][r] - cc[r];
                     P[(size_t)(gi + p_off) * ldp + gj] = v;
                 }
                 if (!diag) sT[li * (MB + 1) + lj] = v;

@@ -5,9 +5,9 @@
 //     S  = G H' + R       (m x m fp64, lower triangle; block-sparse H => 13-term dot products)
 //     S  = L L'           (blocked right-looking Cholesky, fp64, one launch per 32-wide panel; z = inv(L) nu and, in the
 //                          fp32 configuration, the fp64 camera columns of B ride along as right-hand sides)
-//     inv(L)              (128 x 128 diagonal chunks beside the sweep, then doubling levels on the fp64 MFMA)
+//     inv(L)              (128 x 128 diagonal chunks in one launch, then doubling levels, fp64 MFMA)
 //     B  = inv(L) G       (ONE GEMM against the inverted factor, kernels_gemm.hip)
-//     dx = B' z           (= K nu,  K = P H' inv(S); fp32 configuration: feature columns as (H P)' y, y = inv(L)' z)
+//     dx = B' z           (= K nu,  K = P H' inv(S))
 //     P <- sym(P) - B' B  (= 0.5 ((I-KH)P + ((I-KH)P)'), kernels_pupdate.hip -- the MFMA kernel)
 //     q normalisation and its Jacobian on the rows/columns 3..6 of P (Update.cpp:45-85, 303-317)
 //
@@ -25,8 +25,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
          const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
-         double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, const T *P, int n, RowMap rm,
-         double *dsave, double *csave, int avg)
+         double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc)
 {
     const int row = blockIdx.y;
     // 16 bytes per thread: the copy is pure HBM traffic (n_pad and ld are multiples of 128 elements)
@@ -34,22 +33,6 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
     typedef T vec_t __attribute__((ext_vector_type(VW)));
     const int j = (blockIdx.x * 256 + threadIdx.x) * VW;
     const int m = 2 * M;
-    if (row == 0 && csave) {
-        // phase 0 of k_diag_fix (fp32 covariance): keep the diagonal and the camera rows of P as they are before the
-        // downdate (avg: the first downdate after an arbitrary upload works on 0.5 (P(a,j) + P(j,a))).  P is not
-        // touched between here and the downdate.
-#pragma unroll
-        for (int v = 0; v < VW; ++v) {
-            const int jj = j + v;
-            if (jj >= n) break;
-            const bool mine = owns_row(rm, jj);
-            const T *prow = P + (size_t)local_row(rm, jj) * ld;
-            if (mine) dsave[jj] = (double)prow[jj];
-#pragma unroll
-            for (int a = 0; a < 13; ++a)
-                csave[(size_t)a * ld + jj] = avg ? (double)((T)0.5 * P[(size_t)a * ld + jj] + (T)0.5 * prow[a]) : (double)P[(size_t)a * ld + jj];
-        }
-    }
     if (row < m) {
         const int i = row >> 1, r = row & 1;
         const int fi = matches[i].featureIndex;
@@ -347,11 +330,15 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
 // sweep and the chunk's solve): EVERY global operand the column can need -- six L tiles, three inv(L_aa), X_jj -- is
 // requested unconditionally before the first product (one round trip instead of one per product: 14 -> ~4 us); tiles of
 // block rows past the chunk's end are read (allocated, finite) and never used.  V = inv(L) row-major, W = V' (+ fp32 copy).
+// One launch for ALL chunks (blockIdx.y = chunk) right after the sweep: it replaces the first two doubling levels
+// (32 -> 64 -> 128: four dependent launches of k_triinv_level) by one.
 constexpr int INV_CH = 4; // block rows per chunk
 
 __global__ void __launch_bounds__(256)
-k_inv_diag(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, int a_first, int a_count)
+k_inv_diag(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, int nbk)
 {
+    const int a_first = blockIdx.y * INV_CH, a_count = min(INV_CH, nbk - a_first);
+    if ((int)blockIdx.x >= a_count - 1) return; // a column needs at least one block row below its diagonal block
     typedef double acc4 __attribute__((ext_vector_type(4)));
     __shared__ double sX[INV_CH][NB][NB + 1]; // X_aj of the chunk's rows (operand of the rows below them)
     __shared__ double sT[NB][NB + 1];
@@ -415,10 +402,9 @@ k_inv_diag(const double *LL, int ldS, double *V, double *W, float *Wf, int ldw, 
 
 // ------------------------------------------------------------------------------------------ inverse of L
 // Doubling step s -> 2s:  inv([L11 0; L21 L22]) has the off-diagonal block X21 = -X22 L21 X11.  Two batched products
-// per level (T = L21 X11, X21 = -X22 T), 32x32 output tile per workgroup on the fp64 MFMA.  The levels start at s = 128:
-// the 128 x 128 diagonal chunks are already inverted when the sweep ends (k_inv_diag, beside the sweep).  V = inv(L)
-// row-major, W = V' (+ fp32 copy): after the last level B = inv(L) A is ONE GEMM, B = W' A, with no dependency between
-// row blocks.
+// per level (T = L21 X11, X21 = -X22 T), 32x32 output tile per workgroup on the fp64 MFMA.  The levels start at s = 128
+// (k_inv_diag inverts the 128 x 128 diagonal chunks in one launch).  V = inv(L) row-major, W = V' (+ fp32 copy): after the
+// last level B = inv(L) A is ONE GEMM, B = W' A, with no dependency between row blocks.
 // mode 0: T[pair] = L21 * X11 ;  mode 1: X21 = -X22 * T
 __global__ void __launch_bounds__(256)
 k_triinv_level(const double *S, int ldS, int m, int m_pad, double *V, double *W, float *Wf, double *Tbuf, int ldw,
@@ -489,6 +475,7 @@ k_triinv_level(const double *S, int ldS, int m, int m_pad, double *V, double *W,
     }
 }
 
+// ------------------------------------------------------------------------------------------------- dx = B' z
 // y = inv(L)' z = W z (W upper triangular, fp64): with it dx = (H P)' y = G' inv(S) nu, the gain applied without going
 // through B.  fp32 configuration only: B = inv(L) G comes out of an fp32 MFMA GEMM (accumulation error ~ sqrt(m) eps per
 // element), G is the fp64-accumulated H P rounded once -- measured at N = 1000: the inverse-depth components were
@@ -505,22 +492,30 @@ __global__ void __launch_bounds__(256) k_yvec(const double *W, int ldw, int m, c
     if (lane == 0) y[i] = s;
 }
 
-template <typename T, int PART>
+template <typename T>
 __global__ void __launch_bounds__(256)
 k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, int ldpart, double *sq_part, double *cam_part,
-             const double *Bc, const T *G, const double *y)
+             const double *Bc, const T *P, RowMap rm, double *dsave, double *csave, int avg, const T *G, const double *y)
 {
     __shared__ double sc[64][13]; // fp64 camera columns of a chunk of rows of B
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int ks = blockIdx.y;
+    if (ks == 0 && csave && j < n) {
+        // phase 0 of k_diag_fix: keep the diagonal and the camera rows of P as they are before the downdate
+        // (avg: the first downdate after an arbitrary upload works on 0.5 (P(a,j) + P(j,a)))
+        const bool mine = owns_row(rm, j);
+        const T *prow = P + (size_t)local_row(rm, j) * ld;
+        if (mine) dsave[j] = (double)prow[j];
+#pragma unroll
+        for (int a = 0; a < 13; ++a)
+            csave[(size_t)a * ldpart + j] = avg ? (double)((T)0.5 * P[(size_t)a * ld + j] + (T)0.5 * prow[a]) : (double)P[(size_t)a * ld + j];
+    }
     const int per = (m + DX_SPLIT - 1) / DX_SPLIT;
     const int kb = ks * per, ke = min(m, kb + per);
     double s = 0.0, q = 0.0;
-    constexpr int A0 = PART == 2 ? 7 : 0, NA = PART == 0 ? 1 : (PART == 1 ? 7 : (PART == 2 ? 6 : 13));
-    constexpr bool DO_DX = PART == 0 || PART == 3, DO_CAM = PART >= 1;
-    double c[NA];
+    double c[13];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) c[a] = 0.0;
+    for (int a = 0; a < 13; ++a) c[a] = 0.0;
     for (int k0 = kb; k0 < ke; k0 += 64) {
         const int cnt = min(64, ke - k0);
         if (Bc) { // fp64 camera columns of B (fp32 covariance only)
@@ -531,29 +526,22 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
         if (j < n)
             for (int k = 0; k < cnt; ++k) {
                 const double b = (Bc && j < 13) ? sc[k][j] : (double)B[(size_t)(k0 + k) * ld + j];
-                if (DO_DX) {
-                    // feature columns of the fp32 configuration: dx_j = sum_k (H P)_kj y_k with y = inv(S) nu from k_ystep
-                    // (B comes out of fp32 MFMA GEMMs with an accumulation error of ~ sqrt(m) eps per element, G is the
-                    // fp64-accumulated H P rounded once; measured at N = 1000: the inverse-depth components were
-                    // 2e-7 ... 1e-6 off through B' z); camera columns: Bc' z (fp64)
-                    if (G && j >= 13) s += (double)G[(size_t)(k0 + k) * ld + j] * y[k0 + k];
-                    else s += b * z[k0 + k];
-                    q += b * b; // (B'B)_jj in fp64, same pass over B: see k_diag_fix
-                }
-                if (DO_CAM && cam_part) {
+                // feature columns of the fp32 configuration: dx_j = sum_k (H P)_kj y_k (see k_yvec); camera columns: Bc' z (fp64)
+                if (G && j >= 13) s += (double)G[(size_t)(k0 + k) * ld + j] * y[k0 + k];
+                else s += b * z[k0 + k];
+                q += b * b; // (B'B)_jj in fp64, same pass over B: see k_diag_fix
+                if (cam_part) {
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) c[a] += sc[k][A0 + a] * b; // (B'B)_aj, camera rows
+                    for (int a = 0; a < 13; ++a) c[a] += sc[k][a] * b; // (B'B)_aj, camera rows
                 }
             }
     }
     if (j >= n) return;
-    if (DO_DX) {
-        part[(size_t)ks * ldpart + j] = s;
-        if (sq_part) sq_part[(size_t)ks * ldpart + j] = q;
-    }
-    if (DO_CAM && cam_part) {
+    part[(size_t)ks * ldpart + j] = s;
+    if (sq_part) sq_part[(size_t)ks * ldpart + j] = q;
+    if (cam_part) {
 #pragma unroll
-        for (int a = 0; a < NA; ++a) cam_part[((size_t)ks * 13 + A0 + a) * ldpart + j] = c[a];
+        for (int a = 0; a < 13; ++a) cam_part[((size_t)ks * 13 + a) * ldpart + j] = c[a];
     }
 }
 
@@ -703,17 +691,10 @@ __global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, cons
 // P-update launcher lives in kernels_pupdate.hip
 void launch_p_update(EkfEngine *e, int m_pad);
 
-// One update: gather, S, the sweep (one launch per 32-wide panel), inv(L), B = inv(L) G as one GEMM, y, dx, the state
-// update, the downdate and its tail, all on the engine's stream -- except the inverses of the 128 x 128 diagonal chunks of
-// L, which a side stream (stream_v) computes chunk by chunk BEHIND the sweep (k_inv_diag: three workgroups per chunk, they
-// do not disturb the sweep), so that the doubling levels left for after the sweep start at 128 instead of 32.
-// Measured and rejected this round: B by blocked forward substitution on a side stream beside the
-// sweep.  Its short-k GEMMs are latency-bound (~4x the time of the single GEMM) and their workgroups take the CUs the
-// sweep's latency-critical launches need (a panel step went from 10.7 to 15-49 us): 1.12 ms per update against 0.97.
 template <typename T>
 static void update_impl(EkfEngine *e, int M, bool update_cov)
 {
-    hipStream_t s = e->stream, sv = e->stream_v;
+    hipStream_t s = e->stream;
     const int m = 2 * M, n = e->n, ld = e->ldP, ldS = e->ldS, ldw = e->ldW;
     const int m_pad = round_up(m, NB);
     const int n_pad = round_up(n, LD_ALIGN);
@@ -721,25 +702,18 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     T *A = (T *)e->d.A; // B = inv(L) G
     double *V = e->d.Dinv, *W = e->d.W;
     float *Wf = e->f32 ? e->d.Wf : nullptr;
-    const bool fix = update_cov && sizeof(T) == 4;
     {
         dim3 grid((n_pad / (int)(16 / sizeof(T)) + 255) / 256, m_pad);
-        const int avg = e->p_exact_sym ? 0 : 1; // an AVG downdate only exists on an unsharded engine: every row is local
         k_gather<T><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const T *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
-                                         e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc, (const T *)e->d.P, n, e->rm,
-                                         e->d.diag_save, fix ? e->d.cam_save : nullptr, avg);
+                                         e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc);
     }
     {
         dim3 grid((M + 15) / 16, (M + 15) / 16);
         k_assemble_S<T><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts);
     }
-    const int nbk = m_pad / NB; // panels = block rows
-    const int n_chunks = (nbk + INV_CH - 1) / INV_CH;
-    constexpr int CH = INV_CH * NB;
-    for (int k = 0; k < nbk; ++k) {
-        const int k0 = k * NB;
+    for (int k0 = 0; k0 < m; k0 += NB) {
         const int kb = min(NB, m - k0);
         const int k1 = k0 + kb;
         const int nrb = (m - k1 + NB - 1) / NB; // row blocks below the panel
@@ -747,27 +721,21 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const int n_rhs_blocks = max(1, (m - k1 + 255) / 256); // right-hand-side blocks, 256 rows each
         k_chol_step<<<n_stiles + n_rhs_blocks, 256, 0, s>>>(e->d.S, e->d.LL, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles, V, W, Wf,
                                                             ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr, e->d.zvec, e->d.Bc);
-        if (k % INV_CH != INV_CH - 1 && k != nbk - 1) continue;
-        // the chunk's panels are factorised (inv(L_kk) published one launch earlier, column k of L stored by launch k):
-        // its 128 x 128 diagonal block of L is inverted beside the sweep
-        const int c = k / INV_CH;
-        const int a_first = c * INV_CH, a_count = min(INV_CH, nbk - a_first);
-        if (a_count > 1) {
-            (void)hipEventRecord(e->chunk_event(c), s);
-            (void)hipStreamWaitEvent(sv, e->chunk_event(c), 0);
-            k_inv_diag<<<a_count - 1, 256, 0, sv>>>(e->d.LL, ldS, V, W, Wf, ldw, a_first, a_count);
+    }
+    // inv(L): the 128 x 128 diagonal chunks in one launch, then by doubling 128 -> 256 -> ... until one block covers all rows
+    {
+        const int nbk = m_pad / NB, n_chunks = (nbk + INV_CH - 1) / INV_CH;
+        if (nbk > 1) k_inv_diag<<<dim3(INV_CH - 1, n_chunks), 256, 0, s>>>(e->d.LL, ldS, V, W, Wf, ldw, nbk);
+    }
+    for (int sz = INV_CH * NB; sz < m_pad; sz *= 2) {
+        const int npairs = (m_pad - sz + 2 * sz - 1) / (2 * sz); // pairs whose second half has rows
+        {   // 32x32 output tiles on the fp64 MFMA at every level: these products are small (m^3/3 flop in total) and
+            // need many workgroups with short k-loops rather than big tiles (64x64 tiles left 3/4 of the CUs idle)
+            const int tiles = (sz / NB) * (sz / NB);
+            k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.LL, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 0);
+            k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.LL, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 1);
         }
     }
-    (void)hipEventRecord(e->ev_b_done, sv);
-    (void)hipStreamWaitEvent(s, e->ev_b_done, 0);
-    // inv(L) by doubling from the 128-chunks: 128 -> 256 -> ... until one block covers all rows
-    for (int sz = CH; sz < m_pad; sz *= 2) {
-        const int npairs = (m_pad - sz + 2 * sz - 1) / (2 * sz); // pairs whose second half has rows
-        const int tiles = (sz / NB) * (sz / NB);
-        k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.LL, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 0);
-        k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.LL, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 1);
-    }
-    (void)n_chunks;
     {   // B = inv(L) G = W' G : one GEMM, k <= row (W upper triangular)
         const int TM = sizeof(T) == 4 ? 128 : 64;
         XtyArgs g{};
@@ -778,10 +746,12 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         g.row0_first = 0; g.row0_stride = 0; g.m_lim = m_pad;
         g.tri = 2; g.tiles_i = (m_pad + TM - 1) / TM; g.tiles_j = (n_pad + TM - 1) / TM; g.alpha = 1.0;
         g.n_split = g.tiles_i / 2; // k-depth of row tile i is ~(i+1) TM: halve the units of the longer half
-        g.deep = e->xty_deep ? 1 : 0;
         launch_xty(e, g, 1, e->f32, s);
     }
     {
+        dim3 grid((n + 255) / 256, DX_SPLIT);
+        const bool fix = update_cov && sizeof(T) == 4;
+        const int avg = e->p_exact_sym ? 0 : 1; // an AVG downdate only exists on an unsharded engine: every row is local
         const double *Bc = nullptr;
         const T *Gy = nullptr;
         if (sizeof(T) == 4) {
@@ -789,16 +759,17 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             k_yvec<<<(m + 3) / 4, 256, 0, s>>>(W, ldw, m, e->d.zvec, e->d.yvec);
             Gy = G;
         }
-        dim3 grid((n + 255) / 256, DX_SPLIT);
-        k_dx_partial<T, 3><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, fix ? e->d.sq_part : nullptr,
-                                                fix ? e->d.cam_part : nullptr, Bc, Gy, e->d.yvec);
+        k_dx_partial<T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld,
+                                             fix ? e->d.sq_part : nullptr, fix ? e->d.cam_part : nullptr, Bc, (const T *)e->d.P,
+                                             e->rm, e->d.diag_save, fix ? e->d.cam_save : nullptr, avg, Gy, e->d.yvec);
         const int nt = max(e->N * 6, 1);
         k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
                                                        e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
     }
     if (!update_cov) return;
+    const bool fix_diag = sizeof(T) == 4;
     launch_p_update(e, m_pad);
-    if (fix) k_diag_fix<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save, e->d.cam_part, ld);
+    if (fix_diag) k_diag_fix<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save, e->d.cam_part, ld);
     const int nb = 1 + (n > 7 ? (n - 7 + 255) / 256 : 0);
     k_normalize_cov<T><<<nb, 256, 0, s>>>((T *)e->d.P, ld, n, e->d.state, e->rm);
 }

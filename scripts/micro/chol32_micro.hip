@@ -26,26 +26,12 @@ __global__ void __launch_bounds__(256) k_run(const double *A, double *Linv, long
         const long long c0 = clock64(), w0 = wall_clock64();
         if (V == 0) ok = block_chol_inv32(sa, sx, srs) && ok;
         else if (V == 1) ok = block_chol_inv32_bp(sa, sx) && ok;
-        else if (V == 2) ok = block_chol_inv32_mf(sa, sx) && ok;
-        else ok = block_chol_inv32_adj(sa, sx) && ok;
+        else ok = block_chol_inv32_mf(sa, sx) && ok;
         c_acc += clock64() - c0;
         w_acc += wall_clock64() - w0;
     }
     for (int i = threadIdx.x; i < CH_NB * CH_NB; i += 256) Linv[i] = sx[i / CH_NB][i % CH_NB];
     if (threadIdx.x == 0) { ticks[0] = c_acc; ticks[1] = w_acc; ticks[2] = ok; }
-}
-
-__global__ void __launch_bounds__(256) k_trace(const double *A, long long *tr)
-{
-    __shared__ double sa[CH_NB][CH_NB + 1], sx[CH_NB][CH_NB + 1];
-    for (int it = 0; it < 3; ++it) {
-        for (int i = threadIdx.x; i < CH_NB * CH_NB; i += 256) {
-            const int r = i / CH_NB, c = i % CH_NB;
-            sa[r][c] = c <= r ? A[r * CH_NB + c] : 0.0;
-        }
-        __syncthreads();
-        block_chol_inv32_adj<true>(sa, sx, tr);
-    }
 }
 
 int main()
@@ -64,7 +50,7 @@ int main()
     long long *dT;
     hipMalloc(&dA, n * n * 8); hipMalloc(&dL, n * n * 8); hipMalloc(&dT, 64);
     hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < 3; ++v) {
         const int reps = 50;
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
@@ -72,8 +58,7 @@ int main()
             hipEventRecord(e0);
             if (v == 0) k_run<0><<<1, 256>>>(dA, dL, dT, reps);
             else if (v == 1) k_run<1><<<1, 256>>>(dA, dL, dT, reps);
-            else if (v == 2) k_run<2><<<1, 256>>>(dA, dL, dT, reps);
-            else k_run<3><<<1, 256>>>(dA, dL, dT, reps);
+            else k_run<2><<<1, 256>>>(dA, dL, dT, reps);
             hipEventRecord(e1);
             hipDeviceSynchronize();
         }
@@ -103,20 +88,6 @@ int main()
             for (int j = i + 1; j < n; ++j) upper = std::fmax(upper, std::fabs(L[i * n + j]));
         std::printf("variant %d: ok=%lld  cycles/call %.0f  wall us/call %.2f  (kernel %.1f us / %d reps = %.2f us)  |LinvALinv'-I| %.2e  upper %.1e\n",
                     v, t[2], (double)t[0] / reps, (double)t[1] / reps / 100.0, ms * 1e3, reps, ms * 1e3 / reps, err, upper);
-    }
-    {   // where a pivot step of the cofactor variant spends its cycles (thread 0, each point behind s_waitcnt 0)
-        long long *dTr;
-        hipMalloc(&dTr, 128 * 8);
-        hipMemset(dTr, 0, 128 * 8);
-        k_trace<<<1, 256>>>(dA, dTr);
-        hipDeviceSynchronize();
-        long long tr[128];
-        hipMemcpy(tr, dTr, 128 * 8, hipMemcpyDeviceToHost);
-        std::printf("step: publish->barrier | barrier | block loads | cofactors+rcp | w, pivot-row loads | mfma | to next publish\n");
-        for (int J = 0; J < 8; ++J) {
-            const long long *q = tr + 6 * J;
-            std::printf("%d: %lld %lld %lld %lld %lld %lld\n", J, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], J < 7 ? q[6] - q[5] : 0LL);
-        }
     }
     return 0;
 }
