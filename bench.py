@@ -172,6 +172,48 @@ def cpu_baseline(seq, workload, eng=None, tol=1e-5):
     }
 
 
+def all_matched_line(eng, seq, dtype, updates=8):
+    """Secondary line: one update with EVERY feature matched (M = N, m = 2N: the size BASELINE.md's
+    1.53 ms budget is computed on), which the 2-best list rule never produces on the synthetic keypoints.  Stage calls
+    through the same ABI: predict, predictCameraMeasurements, update with a match per prediction (prediction + 0.3 px)."""
+    import torch
+    from openekfmonoslam_amd.ekftypes import MATCH_DTYPE
+
+    rng = np.random.default_rng(7)
+    eng.timing(False)
+    eng.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    times, m_rows = [], 0
+    for it in range(updates + 2):
+        eng.predict()
+        preds, _, _ = eng.predict_measurements()
+        mt = np.zeros(len(preds), dtype=MATCH_DTYPE)
+        mt["featureIndex"] = preds["featureIndex"]
+        mt["keypointIndex"] = -1
+        mt["imagePos"] = preds["imagePos"] + rng.normal(0.0, 0.3, preds["imagePos"].shape)
+        if it == 2:
+            eng.timing(True)
+            eng.timing_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.update(mt)
+        eng.synchronize()
+        if it >= 2:
+            times.append(time.perf_counter() - t0)
+        m_rows = 2 * len(mt)
+    tm = eng.timing_get()
+    eng.timing(False)
+    n = seq.state_dim
+    out = {"matches": m_rows // 2, "m": m_rows, "updates_timed": len(times), "ms_per_update": 1e3 * float(np.mean(times)),
+           "note": "ekf_update alone (host uploads the match list, returns after the stream drained); map as seeded, "
+                   "predict + predictCameraMeasurements between updates untimed"}
+    if tm.p_update_launches > 0:
+        ms = tm.p_update_kernel_ms / tm.p_update_launches
+        ach = float(n) * n * m_rows / (ms * 1e-3) / 1e12
+        out["p_update"] = {"avg_launch_ms": ms, "achieved_tflops": ach, "frac": ach / PEAK_TFLOPS[dtype],
+                           "algorithmic_flops_per_launch": float(n) * n * m_rows}
+    return out
+
+
 def committed_pmc_traffic(workload):
     """HBM bytes per k_p_update launch from the committed rocprofv3 PMC summary of this workload (FETCH_SIZE and
     WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950 -- scripts/profile_summary.py); counters cannot be read
@@ -210,6 +252,7 @@ def main():
                          "matcher downstream of its detector); ncc: mode B, rendered frames staged in HBM, gray "
                          "pyramid + template NCC per frame (BASELINE configs[3-4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-all-matched", action="store_true", help="skip the secondary all-matched update line (N = 1000)")
     ap.add_argument("--no-roofline-pass", action="store_true")
     args = ap.parse_args()
 
@@ -405,6 +448,8 @@ def main():
     }
     if single_ref is not None:
         out["single_gpu_same_workload"] = single_ref
+    if world == 1 and not group and not ncc and args.workload.startswith("n1000") and not args.no_all_matched:
+        out["all_matched"] = all_matched_line(eng, seq, dtype)
     if world == 1 and not group and not ncc and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(seq, args.workload, eng, 1e-5 if precision else 1e-9)
     else:

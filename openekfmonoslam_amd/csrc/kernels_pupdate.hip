@@ -239,10 +239,17 @@ static void build_units(EkfEngine *e, int nt, int nrt, bool rect, bool halves_fi
         // resident workgroups would otherwise run in lockstep and all hit their HBM-bound epilogue at once; starting a
         // third of them on half-length units spreads the epilogues under the others' MFMA phases (measured: 0.384 ->
         // 0.368 ms at m = 1056).  Short k-loops: half units LAST, where they shorten the tail.
-        const int hoff = halves_first ? 0 : fchunk, foff = halves_first ? hchunk : 0;
-        for (int k = 0; k < hchunk && x * hchunk + k < (int)halves.size(); ++k)
-            table[(size_t)x * per + hoff + k] = halves[x * hchunk + k];
-        for (int k = 0; k < fchunk && x * fchunk + k < n_full; ++k) table[(size_t)x * per + foff + k] = tiles[x * fchunk + k];
+        // pu_order (EKF_PU_ORDER, experiment): 1 = a third of the half units first (de-phasing), the rest LAST (a finer tail);
+        // 2 = all half units last whatever the k-depth
+        const int order = e->pu_order;
+        const int h_first = order == 2 ? 0 : (order == 1 && halves_first ? hchunk / 3 : (halves_first ? hchunk : 0));
+        int pos = 0;
+        for (int k = 0; k < h_first; ++k, ++pos)
+            if (x * hchunk + k < (int)halves.size()) table[(size_t)x * per + pos] = halves[x * hchunk + k];
+        for (int k = 0; k < fchunk; ++k, ++pos)
+            if (x * fchunk + k < n_full) table[(size_t)x * per + pos] = tiles[x * fchunk + k];
+        for (int k = h_first; k < hchunk; ++k, ++pos)
+            if (x * hchunk + k < (int)halves.size()) table[(size_t)x * per + pos] = halves[x * hchunk + k];
     }
     e->d.pu_tilemap = nullptr;
     (void)hipMalloc((void **)&e->d.pu_tilemap, table.size() * sizeof(int4));
@@ -267,7 +274,7 @@ static void launch_p_update_t(EkfEngine *e, int m_pad, int grid, const int4 *tm,
         k_p_update<T, false, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, (m_pad < 512 && grid >= 768) ? 80 : 0);
 }
 
-void launch_p_update(EkfEngine *e, int m_pad)
+void launch_p_update(EkfEngine *e, int m_pad, int m)
 {
     hipStream_t s = e->stream;
     const int n = e->n;
@@ -292,8 +299,9 @@ void launch_p_update(EkfEngine *e, int m_pad)
         (void)hipEventRecord(e1, s);
         e->pu_events.emplace_back(e0, e1);
         // flops of this launch / 1 (n^2 m counts the symmetric downdate; a rank computes owned x n x m x 2 / 2)
-        e->pu_work.push_back(rect ? (double)(owned + 13) * (double)n * (double)m_pad * 2.0 : (double)n * (double)n * (double)m_pad);
-        e->pu_m.push_back(m_pad);
+        // algorithmic work of the launch from the UN-padded m (the kernel runs m rounded up to 32 rows of B, the rest zero)
+        e->pu_work.push_back(rect ? (double)(owned + 13) * (double)n * (double)m * 2.0 : (double)n * (double)n * (double)m);
+        e->pu_m.push_back(m);
     }
     e->p_exact_sym = true;
 }

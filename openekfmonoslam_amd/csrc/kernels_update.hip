@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, cons
 }
 
 // P-update launcher lives in kernels_pupdate.hip
-void launch_p_update(EkfEngine *e, int m_pad);
+void launch_p_update(EkfEngine *e, int m_pad, int m);
 
 template <typename T>
 static void update_impl(EkfEngine *e, int M, bool update_cov)
@@ -768,7 +768,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     }
     if (!update_cov) return;
     const bool fix_diag = sizeof(T) == 4;
-    launch_p_update(e, m_pad);
+    launch_p_update(e, m_pad, m);
     if (fix_diag) k_diag_fix<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save, e->d.cam_part, ld);
     const int nb = 1 + (n > 7 ? (n - 7 + 255) / 256 : 0);
     k_normalize_cov<T><<<nb, 256, 0, s>>>((T *)e->d.P, ld, n, e->d.state, e->rm);
