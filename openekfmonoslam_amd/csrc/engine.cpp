@@ -158,7 +158,6 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
         e->desc_f32 = true;
         e->desc_bytes = 4 * cols;
     } else if ((cfg->flags & 0xff) != 0) { delete e; return EKF_ERR_INVALID_ARG; }
-    if (const char *v = std::getenv("EKF_PU_ORDER")) e->pu_order = std::atoi(v);
     e->shard_rank = rank;
     e->shard_world = world;
     e->cap = cfg->max_features;

@@ -178,7 +178,6 @@ struct EkfEngine {
     int pu_tilemap_nt = -1;
     std::map<int, std::pair<void *, int>> pu_tables; // built work lists of the downdate: key -> (device list, units per XCD)
     int pu_per_xcd = 0;
-    int pu_order = 0; // work-list order of the downdate (EKF_PU_ORDER, experiment)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // image-only work of the next frame, overlapped with the update
     hipEvent_t ev_main = nullptr, ev_prefetch = nullptr;

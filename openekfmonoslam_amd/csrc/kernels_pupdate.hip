@@ -239,17 +239,10 @@ static void build_units(EkfEngine *e, int nt, int nrt, bool rect, bool halves_fi
         // resident workgroups would otherwise run in lockstep and all hit their HBM-bound epilogue at once; starting a
         // third of them on half-length units spreads the epilogues under the others' MFMA phases (measured: 0.384 ->
         // 0.368 ms at m = 1056).  Short k-loops: half units LAST, where they shorten the tail.
-        // pu_order (EKF_PU_ORDER, experiment): 1 = a third of the half units first (de-phasing), the rest LAST (a finer tail);
-        // 2 = all half units last whatever the k-depth
-        const int order = e->pu_order;
-        const int h_first = order == 2 ? 0 : (order == 1 && halves_first ? hchunk / 3 : (halves_first ? hchunk : 0));
-        int pos = 0;
-        for (int k = 0; k < h_first; ++k, ++pos)
-            if (x * hchunk + k < (int)halves.size()) table[(size_t)x * per + pos] = halves[x * hchunk + k];
-        for (int k = 0; k < fchunk; ++k, ++pos)
-            if (x * fchunk + k < n_full) table[(size_t)x * per + pos] = tiles[x * fchunk + k];
-        for (int k = h_first; k < hchunk; ++k, ++pos)
-            if (x * hchunk + k < (int)halves.size()) table[(size_t)x * per + pos] = halves[x * hchunk + k];
+        const int hoff = halves_first ? 0 : fchunk, foff = halves_first ? hchunk : 0;
+        for (int k = 0; k < hchunk && x * hchunk + k < (int)halves.size(); ++k)
+            table[(size_t)x * per + hoff + k] = halves[x * hchunk + k];
+        for (int k = 0; k < fchunk && x * fchunk + k < n_full; ++k) table[(size_t)x * per + foff + k] = tiles[x * fchunk + k];
     }
     e->d.pu_tilemap = nullptr;
     (void)hipMalloc((void **)&e->d.pu_tilemap, table.size() * sizeof(int4));

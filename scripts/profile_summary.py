@@ -20,8 +20,43 @@ def pmc(db_path, counter, like="%k_p_update%"):
     return rows
 
 
+def pmc_sq(db_paths, out_path, like="%k_p_update%"):
+    """SQ / GRBM counters of the downdate kernel from several single-purpose PMC passes: mean per launch, for all
+    launches and for the longer / shorter half (the low- and high-innovation updates), plus the derived ratios."""
+    import statistics as st
+    rows_out, means = [], {}
+    for db in db_paths:
+        cur = sqlite3.connect(db).cursor()
+        by = {}
+        for name, val, dur in cur.execute(
+                "select counter_name, value, duration from counters_collection where kernel_name like ?", (like,)):
+            by.setdefault(name, []).append((val, dur))
+        for name, v in by.items():
+            v.sort(key=lambda x: x[1])
+            lo, hi = v[: len(v) // 2], v[len(v) // 2:]
+            means[name] = (st.mean(x[0] for x in v), st.mean(x[0] for x in hi), st.mean(x[0] for x in lo),
+                           st.mean(x[1] for x in hi) / 1e3, st.mean(x[1] for x in lo) / 1e3, len(v))
+    with open(out_path, "w") as f:
+        f.write("# k_p_update, rocprofv3 --pmc (one pass per counter group, counters only); per launch means; 'long' = the longer half of\n")
+        f.write("# the launches (low-innovation updates), 'short' = the shorter half (high-innovation updates)\n")
+        f.write("counter,launches,mean,mean_long,mean_short,duration_long_us,duration_short_us\n")
+        for name, (m, hi, lo, dh, dl, n) in means.items():
+            f.write(f"{name},{n},{m:.6g},{hi:.6g},{lo:.6g},{dh:.1f},{dl:.1f}\n")
+        g = means.get("GRBM_GUI_ACTIVE")
+        if g and "SQ_VALU_MFMA_BUSY_CYCLES" in means and "SQ_BUSY_CU_CYCLES" in means:
+            for k, idx in (("long", 1), ("short", 2)):
+                cyc = g[idx] / 8.0  # summed over the 8 XCDs
+                mf = means["SQ_VALU_MFMA_BUSY_CYCLES"][idx] / 1024.0 / cyc  # 1024 SIMDs
+                cu = means["SQ_BUSY_CU_CYCLES"][idx] / 256.0 / cyc
+                f.write(f"# {k}: {cyc:.0f} cycles per XCD ({cyc / g[3 if idx == 1 else 4] / 1e3:.2f} GHz), MFMA pipe busy {mf:.3f} of the kernel time, "
+                        f"CUs with a resident wavefront {cu:.3f}; LDS bank conflicts {means.get('SQ_LDS_BANK_CONFLICT', (0,) * 6)[idx]:.0f}\n")
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
+    if mode == "pmc_sq":
+        pmc_sq(sys.argv[3:], sys.argv[2])
+        sys.exit(0)
     if mode == "stats":
         kernel_stats(sys.argv[2], sys.argv[3])
     elif mode == "pmc":
