@@ -239,7 +239,7 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "replicas", "sharded"],
                     help="G > 1: ONE filter row-sharded over the ranks (auto / sharded; SURVEY 8(e)) or G independent "
                          "replicas (replicas: what the path is at N <= 1000)")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "callback"],
+    ap.add_argument("--transport", default=None, choices=["rccl", "callback"],
                     help="sharded exchange: RCCL send/recv inside the engine on its stream (default) or the host callback "
                          "over torch.distributed (the round-1 path, kept for comparison)")
     ap.add_argument("--no-single-gpu-reference", action="store_true",
@@ -272,6 +272,8 @@ def main():
         args.workload = "n1000_f32" if (world == 1 or args.mode == "replicas") else ("n5000_f32" if world >= 8 else "n2000_f32")
     if args.mode == "auto":
         args.mode = "sharded" if world > 1 else "replicas"
+    if args.transport is None:  # ranks that share one GPU (gloo, functional checks) cannot form an RCCL communicator
+        args.transport = "rccl" if (ranks.dist is None or ranks.dist.get_backend() == "nccl") else "callback"
     N, W, H, precision, dtype = WORKLOADS[args.workload]
     n_frames = args.warmup + args.steps
     seq = SyntheticSequence(N, n_frames, width=W, height=H)

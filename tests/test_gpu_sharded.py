@@ -139,3 +139,23 @@ def test_engine_owned_rccl_communicator_loads_and_runs(eng_mod):
     np.testing.assert_array_equal(xa, xb)
     np.testing.assert_array_equal(Pa, Pb)
     e.close()
+
+
+def test_n2000_four_ranks_match_unsharded(eng_mod):
+    """BASELINE configs[3] shape (N = 2000, 1280x720, fp32, four ranks) with the ranks emulated on one GPU: one frame
+    against the unsharded engine -- same decisions, state and every row of P within 1e-6, P symmetric across ranks."""
+    seq = SyntheticSequence(2000, 1, width=1280, height=720)
+    grp, infos = _run_group(seq, 4, 1, 1)
+    ref = eng_mod.EkfEngine(seq.cam, seq.par, 2000, max_keypoints=len(seq.frames[0][0]) + 64, precision=1)
+    ref.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, _sym(seq.P0))
+    ri = ref.step(*seq.frames[0])
+    for r in range(4):
+        for f in INFO_FIELDS:
+            assert getattr(infos[r][0], f) == getattr(ri, f), (r, f)
+    x, fp, P = grp.get_state()
+    xr, fpr, Pr = ref.get_state()
+    assert not np.isnan(P).any()
+    assert state_err(x, fp, xr, fpr) <= 1e-6 and rel_max(P, Pr) <= 1e-6
+    np.testing.assert_array_equal(P, P.T)
+    grp.close()
+    ref.close()

@@ -91,8 +91,9 @@ def test_two_processes_one_filter(tmp_path, precision):
 
 
 def test_bench_sharded_mode_two_ranks_one_gpu(tmp_path):
-    """bench.py --mode sharded end to end with two ranks on cuda:0 (gloo transport): one JSON line from rank 0,
-    scaling "strong", the same decisions as the unsharded run"""
+    """bench.py --mode sharded end to end with two ranks on cuda:0 (gloo process group, so the host-callback transport:
+    RCCL refuses two ranks on one device): one JSON line from rank 0, scaling "strong", the same decisions as the
+    unsharded run, and the one-GPU reference of the same workload"""
     import json
 
     port = _free_port()
@@ -109,7 +110,8 @@ def test_bench_sharded_mode_two_ranks_one_gpu(tmp_path):
     line = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
-    assert "row-sharded" in d["config"]["parallelism"]
+    assert "row-sharded" in d["config"]["parallelism"] and "host callback" in d["config"]["parallelism"]
+    assert d["single_gpu_same_workload"]["value"] > 0
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]  # only rank 0 prints
     ref = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "n200_f64", "--steps", "4",
                           "--warmup", "2", "--no-roofline-pass", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
