@@ -188,6 +188,10 @@ int ekf_step(EkfEngine *e, const EkfKeypoint *kps, const uint8_t *desc32, int n_
 int ekf_frames_upload(EkfEngine *e, int n_frames, const int32_t *kp_counts, const EkfKeypoint *kps_concat,
                       const uint8_t *desc_concat);
 int ekf_step_frame(EkfEngine *e, int frame, EkfStepInfo *info);
+/* on: ekf_step / ekf_step_frame return without the final read-back of the error flag (they then return as soon as the
+ * second update is ENQUEUED).  A failed factorisation of that update (EKF_ERR_NOT_POSITIVE_DEFINITE) is reported by the
+ * next ekf_step* instead -- the reference reports nothing at all (cv::invert returns zeros).  Default off. */
+int ekf_set_async_errors(EkfEngine *e, int on);
 
 /* -- matcher mode B: image in, no detector ----------------------------------------------------------------
  * matchPredictedFeatures(const cv::Mat &image, ...)  EKF/Matching.h:66 and EKF::step(const cv::Mat &image)

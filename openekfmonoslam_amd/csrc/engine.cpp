@@ -1135,9 +1135,12 @@ struct StageTimer {
 // EKF::step (EKF.cpp:242-556) with keypoints already on the device
 static int match_ncc_dev(EkfEngine *e, int *n_matches);
 
+static int step_dev_fast(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_desc, int n_kp, EkfStepInfo *info);
+
 static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_desc, int n_kp, EkfStepInfo *info,
                     bool use_ncc = false)
 {
+    if (!use_ncc && !e->img.valid && !e->keep_step_preds && e->shard_world == 1) return step_dev_fast(e, d_kps, d_desc, n_kp, info);
     EkfStepInfo li;
     std::memset(&li, 0, sizeof(li));
     int status = EKF_OK, rc;
@@ -1202,6 +1205,112 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
     li.status = status;
     if (info) *info = li;
     return status;
+}
+
+// EKF::step for the common case (descriptor matcher, whole filter on this GPU, nothing asked to be kept for the host)
+// with HALF the host round trips of step_dev: how many features were predicted, how many matches there are and how many
+// outliers were re-predicted only decide launch sizes, so the launches use upper bounds (N, N, the outlier count) and
+// the kernels read the counts on the device.  What the host still needs to know -- the RANSAC result (loop state and
+// inlier count: the size of the first update), the rescued count (the size of the second), the error flag -- comes from
+// three read-backs instead of six (two with ekf_set_async_errors); each one used to idle the GPU for ~10-15 us.
+static int step_dev_fast(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_desc, int n_kp, EkfStepInfo *info)
+{
+    EkfStepInfo li;
+    std::memset(&li, 0, sizeof(li));
+    int status = EKF_OK, rc;
+    StageTimer tm(e);
+    tm.mark();
+    const int N = e->N;
+    int *cnt = e->d.counts;
+    auto take_error = [&]() {
+        if (e->h_counts[CNT_ERR]) {
+            status = e->h_counts[CNT_ERR];
+            (void)hipMemsetAsync(cnt + CNT_ERR, 0, sizeof(int), e->stream);
+            e->err = "S = H P H' + R is not positive definite";
+        }
+    };
+    // 1-2. prediction (:273-284), timesPredicted++ (EKF.cpp:572)
+    launch_predict(e);
+    launch_predict_features(e, nullptr, N, false);
+    launch_hp_rows(e, e->d.plist, N, true, cnt + CNT_NPRED);
+    tm.mark();
+    // 4. matching (:337)
+    {
+        EkfKeypoint *save_k = e->d.kps;
+        uint8_t *save_d = e->d.kdesc;
+        e->d.kps = const_cast<EkfKeypoint *>(d_kps);
+        e->d.kdesc = const_cast<uint8_t *>(d_desc);
+        launch_match(e, N, n_kp, cnt + CNT_NPRED);
+        e->d.kps = save_k;
+        e->d.kdesc = save_d;
+    }
+    tm.mark();
+    // 6. 1-point RANSAC (:402): the first batch is launched before anything is known on the host
+    const int batch = e->cfg.ransac_batch;
+    launch_match_index(e, N, cnt + CNT_NMATCH);
+    launch_ransac_init(e, N);
+    launch_ransac_batch(e, N, 0, batch, cnt + CNT_NMATCH);
+    if ((rc = read_counts(e))) return rc;
+    take_error(); // a failure of the previous step's last update, when its final read-back was skipped
+    const int np = e->h_counts[CNT_NPRED], M = e->h_counts[CNT_NMATCH];
+    e->n_pred = np;
+    li.n_predicted = np;
+    li.n_matches = M;
+    for (int h0 = batch; !e->h_counts[CNT_RS_DONE] && h0 < M; h0 += batch) {
+        launch_ransac_batch(e, M, h0, batch);
+        if ((rc = read_counts(e))) return rc;
+    }
+    int ni = 0, no = 0;
+    if (M > 0) {
+        li.n_hypotheses = e->h_counts[CNT_RS_NEXT];
+        ni = e->h_counts[CNT_RS_BEST];
+        no = M - ni;
+        // + updateMapFeatures for the low-innovation inliers (MapManagement.cpp:88-113), same launch
+        launch_partition(e, e->d.matches, M, e->d.best_flags, e->d.msel, e->d.mout, nullptr, true, d_desc);
+    }
+    li.n_inliers = ni;
+    li.n_outliers = no;
+    tm.mark();
+    // 7. low-innovation update (:430)
+    if ((rc = update_dev(e, ni, true))) return rc;
+    tm.mark();
+    // 8-9. re-predict the outliers with the updated state / covariance, rescue (:473-506).  An outlier that is not
+    // re-predicted has pred_vis = 0 and is not rescued; with none re-predicted nothing is (the reference's case is
+    // undefined behaviour, see step_dev).
+    int nr = 0;
+    if (no > 0) {
+        launch_outlier_idx(e, e->d.mout, no, e->d.work_idx);
+        launch_predict_features(e, e->d.work_idx, no, false);
+        launch_hp_rows(e, e->d.plist_sub, no, false, cnt + CNT_NPRED_SUB);
+        EkfMatch *save = e->d.matches;
+        e->d.matches = e->d.mout;
+        launch_rescue(e, no);
+        e->d.matches = save;
+        launch_partition(e, e->d.mout, no, e->d.mask, e->d.msel, nullptr, cnt + CNT_NRESC, true, d_desc); // rescued matches join the inliers (EKF.cpp:552-556)
+        if ((rc = read_counts(e))) return rc;
+        take_error();
+        nr = e->h_counts[CNT_NRESC];
+    }
+    li.n_rescued = nr;
+    tm.mark();
+    // 10. high-innovation update (:529-532)
+    if ((rc = update_dev(e, nr, true))) return rc;
+    tm.mark();
+    if (!e->async_errors) {
+        if ((rc = read_counts(e))) return rc;
+        take_error();
+    }
+    tm.finish();
+    li.status = status;
+    if (info) *info = li;
+    return status;
+}
+
+int ekf_set_async_errors(EkfEngine *e, int on)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    e->async_errors = on != 0;
+    return EKF_OK;
 }
 
 int ekf_step(EkfEngine *e, const EkfKeypoint *kps, const uint8_t *desc32, int n_kp, EkfStepInfo *info)

@@ -168,6 +168,7 @@ struct EkfEngine {
     EkfExchangeFn xchg = nullptr;        // all-gather of per-feature row blocks between the ranks
     void *comm = nullptr;                // ncclComm_t of the in-engine transport (ekf_comm_init), or null
     void *xchg_user = nullptr;
+    bool async_errors = false; // ekf_set_async_errors: no read-back at the end of a step
     bool p_exact_sym = false; // P known to be bitwise symmetric (engine-maintained invariant)
     int n_pred = 0;           // predictions of the last full prediction
     int n_gates = 0;          // gates snapshotted for the new-feature detector
@@ -226,10 +227,13 @@ void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32, hipStream_t
 void launch_predict(EkfEngine *e);
 // full (idx == nullptr) or subset prediction; fills tables, compacted list and CNT_NPRED / CNT_NPRED_SUB
 void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool tables_only_state);
-void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_predicted = false);
-void launch_match(EkfEngine *e, int n_pred, int n_kp);
-void launch_match_index(EkfEngine *e, int M);
-void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch);
+// d_count != nullptr: n_list is an upper bound, the list's length is read on the device
+void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_predicted = false, const int *d_count = nullptr);
+// d_npred != nullptr: n_pred is an upper bound, the number of predictions is read on the device
+void launch_match(EkfEngine *e, int n_pred, int n_kp, const int *d_npred = nullptr);
+// d_M != nullptr (RANSAC launchers): M is an upper bound, the number of matches is read on the device
+void launch_match_index(EkfEngine *e, int M, const int *d_M = nullptr);
+void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M = nullptr);
 void launch_ransac_init(EkfEngine *e, int M);
 void launch_update(EkfEngine *e, int M, bool update_cov);
 void launch_rescue(EkfEngine *e, int M);

@@ -13,8 +13,9 @@ namespace ekf {
 __global__ void __launch_bounds__(256)
 k_match(const int *plist, const double *uv_tab, const double *S_tab, const uint8_t *feat_desc,
         const EkfKeypoint *kps, const uint8_t *kdesc, int n_kp, double coef, int *mt_valid, int *mt_kp,
-        float *mt_dist, int desc_bytes, int desc_f32)
+        float *mt_dist, int desc_bytes, int desc_f32, const int *d_npred)
 {
+    if (d_npred && (int)blockIdx.x >= *d_npred) return; // grid = upper bound, count on the device
     __shared__ Gate g;
     __shared__ uint32_t qd[1024]; // the map feature's descriptor: 8 words (CV_8U) or up to 1024 floats (CV_32F)
     __shared__ int c_idx[256];
@@ -104,8 +105,9 @@ k_match(const int *plist, const double *uv_tab, const double *S_tab, const uint8
 // compacted match list in prediction order (matches.push_back order, Matching.cpp:247-262)
 __global__ void __launch_bounds__(1024)
 k_match_compact(const int *plist, int n_pred, const int *mt_valid, const int *mt_kp, const float *mt_dist,
-                const EkfKeypoint *kps, int by_slot, EkfMatch *out, int *out_count)
+                const EkfKeypoint *kps, int by_slot, EkfMatch *out, int *out_count, const int *d_npred)
 {
+    if (d_npred) n_pred = *d_npred;
     __shared__ int part[1024];
     const int tid = threadIdx.x;
     const int per = (n_pred + 1023) / 1024;
@@ -137,7 +139,7 @@ k_match_compact(const int *plist, int n_pred, const int *mt_valid, const int *mt
     if (tid == 1023) *out_count = part[1023];
 }
 
-void launch_match(EkfEngine *e, int n_pred, int n_kp)
+void launch_match(EkfEngine *e, int n_pred, int n_kp, const int *d_npred)
 {
     if (n_pred <= 0) {
         (void)hipMemsetAsync(e->d.counts + CNT_NMATCH, 0, sizeof(int), e->stream);
@@ -145,21 +147,22 @@ void launch_match(EkfEngine *e, int n_pred, int n_kp)
     }
     k_match<<<n_pred, 256, 0, e->stream>>>(e->d.plist, e->d.pred_uv, e->d.pred_S, e->d.feat_desc, e->d.kps,
                                            e->d.kdesc, n_kp, e->cfg.par.matchingCompCoefSecondBestVSFirst,
-                                           e->d.mt_valid, e->d.mt_kp, e->d.mt_dist, e->desc_bytes, e->desc_f32 ? 1 : 0);
+                                           e->d.mt_valid, e->d.mt_kp, e->d.mt_dist, e->desc_bytes, e->desc_f32 ? 1 : 0, d_npred);
     k_match_compact<<<1, 1024, 0, e->stream>>>(e->d.plist, n_pred, e->d.mt_valid, e->d.mt_kp, e->d.mt_dist,
-                                               e->d.kps, 0, e->d.matches, e->d.counts + CNT_NMATCH);
+                                               e->d.kps, 0, e->d.matches, e->d.counts + CNT_NMATCH, d_npred);
 }
 
 void launch_match_compact_slots(EkfEngine *e, int n_pred, const EkfKeypoint *d_slot_xy)
 {
     k_match_compact<<<1, 1024, 0, e->stream>>>(e->d.plist, n_pred, e->d.mt_valid, e->d.mt_kp, e->d.mt_dist, d_slot_xy,
-                                               1, e->d.matches, e->d.counts + CNT_NMATCH);
+                                               1, e->d.matches, e->d.counts + CNT_NMATCH, nullptr);
 }
 
 // match_of_feat[f] = smallest match index whose featureIndex is f, or -1 (the linear searches of
 // 1PointRansac.cpp:58-82 stop at the first hit)
-__global__ void __launch_bounds__(256) k_match_index(const EkfMatch *m, int M, int *match_of_feat, int N)
+__global__ void __launch_bounds__(256) k_match_index(const EkfMatch *m, int M, int *match_of_feat, int N, const int *d_M)
 {
+    if (d_M) M = *d_M;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
     const int f = m[i].featureIndex;
@@ -172,11 +175,11 @@ __global__ void __launch_bounds__(256) k_fill_int(int *p, int n, int v)
     if (i < n) p[i] = v;
 }
 
-void launch_match_index(EkfEngine *e, int M)
+void launch_match_index(EkfEngine *e, int M, const int *d_M)
 {
     if (e->N <= 0) return;
     k_fill_int<<<(e->N + 255) / 256, 256, 0, e->stream>>>(e->d.match_of_feat, e->N, 0x7fffffff);
-    if (M > 0) k_match_index<<<(M + 255) / 256, 256, 0, e->stream>>>(e->d.matches, M, e->d.match_of_feat, e->N);
+    if (M > 0) k_match_index<<<(M + 255) / 256, 256, 0, e->stream>>>(e->d.matches, M, e->d.match_of_feat, e->N, d_M);
 }
 
 // Stable partition of src[0..M) by flags: dst1 receives the flagged matches, dst0 (optional) the others, both in

@@ -250,8 +250,11 @@ void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool sta
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, const int *feat_covpos,
-          const double *Hs_tab, const double *Hf_tab, T *HP, double *S_tab, RowMap rm, double *HPc, unsigned *times_predicted)
+          const double *Hs_tab, const double *Hf_tab, T *HP, double *S_tab, RowMap rm, double *HPc, unsigned *times_predicted,
+          const int *d_count)
 {
+    // the grid is an upper bound when the length of the list is only known on the device (step path: no read-back)
+    if (d_count && (int)blockIdx.x >= *d_count) return;
     __shared__ double sH[26];     // Hs (2x7) then Hf (2x6)
     __shared__ double sHP[2][13]; // fp64 H P at columns 0..6 and pos..pos+d-1
     const int fi = list[blockIdx.x];
@@ -334,18 +337,18 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
     }
 }
 
-void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_predicted)
+void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_predicted, const int *d_count)
 {
     unsigned *tp = count_predicted ? e->d.feat_times_predicted : nullptr;
     if (n_list <= 0) return;
     if (e->f32)
         k_hp_rows<float><<<n_list, 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
                                                         e->d.feat_covpos, e->d.Hs, e->d.Hf, (float *)e->d.HP,
-                                                        e->d.pred_S, e->rm, e->d.HPc, tp);
+                                                        e->d.pred_S, e->rm, e->d.HPc, tp, d_count);
     else
         k_hp_rows<double><<<n_list, 256, 0, e->stream>>>((const double *)e->d.P, e->ldP, e->n, d_list,
                                                          e->d.feat_type, e->d.feat_covpos, e->d.Hs, e->d.Hf,
-                                                         (double *)e->d.HP, e->d.pred_S, e->rm, e->d.HPc, tp);
+                                                         (double *)e->d.HP, e->d.pred_S, e->rm, e->d.HPc, tp, d_count);
 }
 
 // predictMeasurementState on the current state into an EkfPrediction array (device), all features.

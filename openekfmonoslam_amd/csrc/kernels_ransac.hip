@@ -17,10 +17,11 @@ __global__ void __launch_bounds__(256)
 k_ransac_hyp(const double *st, CamD cam, double thr, const double *feat_pos, const int *feat_type,
              const int *feat_covpos, int N, const T *HP, int ld, const double *uv_tab, const double *S_tab,
              const EkfMatch *matches, int M, const int *match_of_feat, int h0, int *hyp_count, uint8_t *hyp_flags,
-             int mcap)
+             int mcap, const int *d_M)
 {
     __shared__ double sx[13], sRt[9], sRinv[9], sw[2];
     __shared__ int s_cnt[4];
+    if (d_M) M = *d_M; // the number of matches is only known on the device (step path without read-backs)
     const int h = h0 + blockIdx.x;
     if (h >= M) return;
     const int tid = threadIdx.x;
@@ -86,9 +87,10 @@ k_ransac_hyp(const double *st, CamD cam, double thr, const double *feat_pos, con
 // Sequential bookkeeping of the hypothesis loop (1PointRansac.cpp:125,164-178) over one batch.
 __global__ void __launch_bounds__(256)
 k_ransac_select(int *counts, const int *hyp_count, const uint8_t *hyp_flags, uint8_t *best_flags, int M, int h0,
-                int batch, int mcap, double prob)
+                int batch, int mcap, double prob, const int *d_M)
 {
     __shared__ int improved, stop;
+    if (d_M) M = *d_M;
     const int tid = threadIdx.x;
     for (int b = 0; b < batch; ++b) {
         const int i = h0 + b;
@@ -138,7 +140,7 @@ void launch_ransac_init(EkfEngine *e, int M)
     if (M > 0) (void)hipMemsetAsync(e->d.best_flags, 0, (size_t)M, e->stream);
 }
 
-void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch)
+void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M)
 {
     const int nb = batch;
     (void)hipMemsetAsync(e->d.hyp_flags, 0, (size_t)nb * e->mcap, e->stream);
@@ -149,15 +151,15 @@ void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch)
                                                        e->d.feat_covpos, e->N, (const float *)e->d.HP, e->ldP,
                                                        e->d.pred_uv, e->d.pred_S, e->d.matches, M,
                                                        e->d.match_of_feat, h0, e->d.hyp_count, e->d.hyp_flags,
-                                                       e->mcap);
+                                                       e->mcap, d_M);
     else
         k_ransac_hyp<double><<<nb, 256, 0, e->stream>>>(e->d.state, e->cam, thr, e->d.feat_pos, e->d.feat_type,
                                                         e->d.feat_covpos, e->N, (const double *)e->d.HP, e->ldP,
                                                         e->d.pred_uv, e->d.pred_S, e->d.matches, M,
                                                         e->d.match_of_feat, h0, e->d.hyp_count, e->d.hyp_flags,
-                                                        e->mcap);
+                                                        e->mcap, d_M);
     k_ransac_select<<<1, 256, 0, e->stream>>>(e->d.counts, e->d.hyp_count, e->d.hyp_flags, e->d.best_flags, M, h0,
-                                              batch, e->mcap, e->cfg.par.ransacAllInliersProbability);
+                                              batch, e->mcap, e->cfg.par.ransacAllInliersProbability, d_M);
 }
 
 // ------------------------------------------------------------------------------------------------------ A9

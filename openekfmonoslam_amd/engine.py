@@ -83,6 +83,7 @@ ABI = {
     "ekf_step": (_i, [_vp, _vp, _vp, _i, C.POINTER(EkfStepInfo)]),
     "ekf_frames_upload": (_i, [_vp, _i, _vp, _vp, _vp]),
     "ekf_step_frame": (_i, [_vp, _i, C.POINTER(EkfStepInfo)]),
+    "ekf_set_async_errors": (_i, [_vp, _i]),
     "ekf_image_upload": (_i, [_vp, _vp, _i, _i, _i, _i]),
     "ekf_get_image_level": (_i, [_vp, _i, _vp, C.POINTER(_i), C.POINTER(_i)]),
     "ekf_capture_templates": (_i, [_vp, _vp, _vp, _i]),
@@ -280,6 +281,11 @@ class EkfEngine:
         n = C.c_int(0)
         self._chk(self.L.ekf_get_unseen_features(self.h, _p(idx), C.byref(n)))
         return idx[: n.value].copy()
+
+    def set_async_errors(self, on=True):
+        """no read-back at the end of step(): a failed second update is reported by the next step instead"""
+        if hasattr(self.L, "ekf_set_async_errors"):
+            self._chk(self.L.ekf_set_async_errors(self.h, 1 if on else 0))
 
     def keep_step_predictions(self, on=True):
         self._chk(self.L.ekf_keep_step_predictions(self.h, 1 if on else 0))
