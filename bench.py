@@ -302,6 +302,8 @@ def main():
 
             eng.set_exchange(DistributedExchange(ranks.dist, ranks.device))
         eng.upload_frames(seq.frames)
+    for e in (group.engines if group else [eng]):
+        e.set_async_errors(True)  # no read-back after a frame's last update: a failed factorisation surfaces at the next step
     P0 = 0.5 * (seq.P0 + seq.P0.T) if (sharded or group) else seq.P0
     ncc = args.matcher == "ncc"
     if ncc:  # frames 1..n rendered on the host, staged in HBM; templates cut from frame 0

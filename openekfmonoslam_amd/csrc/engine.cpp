@@ -17,7 +17,7 @@ using namespace ekf;
 
 namespace ekf {
 void launch_partition(EkfEngine *e, const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0,
-                      int *cnt1, bool map_update = false, const uint8_t *d_kdesc = nullptr);
+                      int *cnt1, bool map_update = false, const uint8_t *d_kdesc = nullptr, int *d_idx0 = nullptr);
 void launch_outlier_idx(EkfEngine *e, const EkfMatch *src, int M, int *idx);
 } // namespace ekf
 
@@ -970,8 +970,8 @@ int ekf_match(EkfEngine *e, const EkfKeypoint *kps, const uint8_t *desc32, int n
 // RANSAC over e->d.matches[0..M); on return best_flags holds the inlier mask, h_counts the loop state
 static int ransac_dev(EkfEngine *e, int M)
 {
-    launch_match_index(e, M);
     launch_ransac_init(e, M);
+    launch_match_index(e, M);
     const int batch = e->cfg.ransac_batch;
     for (int h0 = 0; h0 < M; h0 += batch) {
         launch_ransac_batch(e, M, h0, batch);
@@ -1165,7 +1165,7 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
         ni = e->h_counts[CNT_RS_BEST];
         no = M - ni;
         // + updateMapFeatures for the low-innovation inliers (MapManagement.cpp:88-113), same launch
-        launch_partition(e, e->d.matches, M, e->d.best_flags, e->d.msel, e->d.mout, nullptr, true, d_desc);
+        launch_partition(e, e->d.matches, M, e->d.best_flags, e->d.msel, e->d.mout, nullptr, true, d_desc, e->d.work_idx);
     }
     li.n_inliers = ni;
     li.n_outliers = no;
@@ -1176,7 +1176,6 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
     // 8-9. re-predict the outliers with the updated state / covariance, rescue (:473-506)
     int nr = 0;
     if (no > 0) {
-        launch_outlier_idx(e, e->d.mout, no, e->d.work_idx);
         int nop = 0;
         if ((rc = predict_measurements_dev(e, e->d.work_idx, no, &nop))) return rc;
         if (e->h_counts[CNT_ERR]) status = e->h_counts[CNT_ERR];
@@ -1247,8 +1246,8 @@ static int step_dev_fast(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *
     tm.mark();
     // 6. 1-point RANSAC (:402): the first batch is launched before anything is known on the host
     const int batch = e->cfg.ransac_batch;
-    launch_match_index(e, N, cnt + CNT_NMATCH);
     launch_ransac_init(e, N);
+    launch_match_index(e, N, cnt + CNT_NMATCH);
     launch_ransac_batch(e, N, 0, batch, cnt + CNT_NMATCH);
     if ((rc = read_counts(e))) return rc;
     take_error(); // a failure of the previous step's last update, when its final read-back was skipped
@@ -1266,7 +1265,7 @@ static int step_dev_fast(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *
         ni = e->h_counts[CNT_RS_BEST];
         no = M - ni;
         // + updateMapFeatures for the low-innovation inliers (MapManagement.cpp:88-113), same launch
-        launch_partition(e, e->d.matches, M, e->d.best_flags, e->d.msel, e->d.mout, nullptr, true, d_desc);
+        launch_partition(e, e->d.matches, M, e->d.best_flags, e->d.msel, e->d.mout, nullptr, true, d_desc, e->d.work_idx);
     }
     li.n_inliers = ni;
     li.n_outliers = no;
@@ -1279,7 +1278,6 @@ static int step_dev_fast(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *
     // undefined behaviour, see step_dev).
     int nr = 0;
     if (no > 0) {
-        launch_outlier_idx(e, e->d.mout, no, e->d.work_idx);
         launch_predict_features(e, e->d.work_idx, no, false);
         launch_hp_rows(e, e->d.plist_sub, no, false, cnt + CNT_NPRED_SUB);
         EkfMatch *save = e->d.matches;

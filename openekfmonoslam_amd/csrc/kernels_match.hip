@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) k_fill_int(int *p, int n, int v)
 void launch_match_index(EkfEngine *e, int M, const int *d_M)
 {
     if (e->N <= 0) return;
-    k_fill_int<<<(e->N + 255) / 256, 256, 0, e->stream>>>(e->d.match_of_feat, e->N, 0x7fffffff);
+    // match_of_feat was set to "none" by launch_ransac_init, which precedes this launch
     if (M > 0) k_match_index<<<(M + 255) / 256, 256, 0, e->stream>>>(e->d.matches, M, e->d.match_of_feat, e->N, d_M);
 }
 
@@ -186,7 +186,7 @@ void launch_match_index(EkfEngine *e, int M, const int *d_M)
 // the original order (1PointRansac.cpp:213-227, EKF.cpp:110-117).
 __global__ void __launch_bounds__(1024)
 k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0, int *cnt1, const uint8_t *kdesc,
-            uint8_t *feat_desc, unsigned *times_matched, int desc_bytes)
+            uint8_t *feat_desc, unsigned *times_matched, int desc_bytes, int *idx0)
 {
     __shared__ int part[1024];
     const int tid = threadIdx.x;
@@ -206,7 +206,10 @@ k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, Ek
     int p0 = b - p1;
     for (int i = b; i < e; ++i) {
         if (flags[i]) dst1[p1++] = src[i];
-        else if (dst0) dst0[p0++] = src[i];
+        else if (dst0) {
+            if (idx0) idx0[p0] = src[i].featureIndex; // the work list of the outlier re-prediction (EKF.cpp:473)
+            dst0[p0++] = src[i];
+        }
     }
     if (tid == 1023 && cnt1) *cnt1 = part[1023];
     if (!times_matched) return;
@@ -226,14 +229,14 @@ k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, Ek
 }
 
 void launch_partition(EkfEngine *e, const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0,
-                      int *cnt1, bool map_update, const uint8_t *d_kdesc)
+                      int *cnt1, bool map_update, const uint8_t *d_kdesc, int *d_idx0)
 {
     if (M <= 0) {
         if (cnt1) (void)hipMemsetAsync(cnt1, 0, sizeof(int), e->stream);
         return;
     }
     k_partition<<<1, 1024, 0, e->stream>>>(src, M, flags, dst1, dst0, cnt1, d_kdesc, e->d.feat_desc,
-                                           map_update ? e->d.feat_times_matched : nullptr, e->desc_bytes);
+                                           map_update ? e->d.feat_times_matched : nullptr, e->desc_bytes, d_idx0);
 }
 
 

@@ -57,6 +57,8 @@ k_ransac_hyp(const double *st, CamD cam, double thr, const double *feat_pos, con
     __syncthreads();
     const double w0 = sw[0], w1 = sw[1];
     uint8_t *flags = hyp_flags + (size_t)blockIdx.x * mcap;
+    for (int k = tid; k < M; k += 256) flags[k] = 0; // this hypothesis' support mask (only matched features are written below)
+    __syncthreads();
     int cnt = 0;
     for (int f = tid; f < N; f += 256) {
         const int mi = match_of_feat[f];
@@ -125,26 +127,30 @@ k_ransac_select(int *counts, const int *hyp_count, const uint8_t *hyp_flags, uin
     }
 }
 
-__global__ void k_ransac_init(int *counts)
+// loop state of the hypothesis loop, "no match" in match_of_feat (N entries), zeroed best mask (M entries, M <= N)
+__global__ void __launch_bounds__(256) k_ransac_init(int *counts, int *match_of_feat, uint8_t *best_flags, int N, int M)
 {
-    counts[CNT_RS_BEST] = 0;
-    counts[CNT_RS_BESTH] = -1;
-    counts[CNT_RS_NHYP] = 1000; // numberOfHipotesis, 1PointRansac.cpp:116
-    counts[CNT_RS_NEXT] = 0;
-    counts[CNT_RS_DONE] = 0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {
+        counts[CNT_RS_BEST] = 0;
+        counts[CNT_RS_BESTH] = -1;
+        counts[CNT_RS_NHYP] = 1000; // numberOfHipotesis, 1PointRansac.cpp:116
+        counts[CNT_RS_NEXT] = 0;
+        counts[CNT_RS_DONE] = 0;
+    }
+    if (i < N) match_of_feat[i] = 0x7fffffff;
+    if (i < M) best_flags[i] = 0;
 }
 
 void launch_ransac_init(EkfEngine *e, int M)
 {
-    k_ransac_init<<<1, 1, 0, e->stream>>>(e->d.counts);
-    if (M > 0) (void)hipMemsetAsync(e->d.best_flags, 0, (size_t)M, e->stream);
+    const int n = max(max(e->N, M), 1);
+    k_ransac_init<<<(n + 255) / 256, 256, 0, e->stream>>>(e->d.counts, e->d.match_of_feat, e->d.best_flags, e->N, M);
 }
 
 void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M)
 {
-    const int nb = batch;
-    (void)hipMemsetAsync(e->d.hyp_flags, 0, (size_t)nb * e->mcap, e->stream);
-    (void)hipMemsetAsync(e->d.hyp_count, 0, (size_t)nb * sizeof(int), e->stream);
+    const int nb = batch; // hyp_flags rows are zeroed by their workgroups, hyp_count[b] is only read for launched hypotheses
     const double thr = e->cfg.par.ransacThresholdPredictDistance;
     if (e->f32)
         k_ransac_hyp<float><<<nb, 256, 0, e->stream>>>(e->d.state, e->cam, thr, e->d.feat_pos, e->d.feat_type,

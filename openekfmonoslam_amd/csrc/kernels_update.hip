@@ -688,6 +688,91 @@ __global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, cons
     }
 }
 
+// k_diag_fix + k_normalize_cov in one launch (fp32 covariance, covariance updates): both own the same elements -- the
+// thread of column j writes the fp64-accumulated camera rows of its column (and, for owned rows, their mirror) and then
+// applies the quaternion-normalisation Jacobian to rows / columns 3..6 of it, from the values it has just rounded to T,
+// so nothing is written twice or re-read.  The 13 x 13 camera block needs all of its own values: block 0 assembles it in
+// LDS, transforms it there (upper triangle, mirrored: P stays bitwise symmetric) and writes it once.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_fix_normalize(T *P, int ld, int n, RowMap rm, const double *dsave, const double *sq_part, const double *csave,
+                const double *cam_part, int ldpart, const double *st)
+{
+    __shared__ double J[16];
+    __shared__ double C[13][13], Cn[13][13];
+    const int tid = threadIdx.x;
+    if (tid < 16) J[tid] = st[ST_JN + tid];
+    const int j = blockIdx.x * 256 + tid;
+    const bool live = j < n;
+    const bool mine = live && owns_row(rm, j);
+    T *prow = P + (size_t)local_row(rm, live ? j : 0) * ld;
+    double v[13];
+    if (live) {
+#pragma unroll
+        for (int a = 0; a < 13; ++a) {
+            double q = 0.0;
+#pragma unroll
+            for (int ks = 0; ks < DX_SPLIT; ++ks) q += cam_part[((size_t)ks * 13 + a) * ldpart + j];
+            v[a] = (double)(T)(csave[(size_t)a * ldpart + j] - q); // rounded to T once, as k_diag_fix stores it
+        }
+        if (mine && j >= 13) {
+            double q = 0.0;
+#pragma unroll
+            for (int ks = 0; ks < DX_SPLIT; ++ks) q += sq_part[(size_t)ks * ldpart + j];
+            prow[j] = (T)(dsave[j] - q);
+        }
+    }
+    if (blockIdx.x == 0 && tid < 13) {
+#pragma unroll
+        for (int a = 0; a < 13; ++a) C[a][tid] = v[a];
+    }
+    __syncthreads();
+    if (live && j >= 13) {
+        // column j of the camera rows (and row j of the camera columns): rows 3..6 <- J rows 3..6
+        double w[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += J[a * 4 + k] * v[3 + k];
+            w[a] = s;
+        }
+#pragma unroll
+        for (int a = 0; a < 13; ++a) {
+            const T out = (T)((a >= 3 && a < 7) ? w[a - 3] : v[a]);
+            P[(size_t)a * ld + j] = out;
+            if (mine) prow[a] = out;
+        }
+    }
+    if (blockIdx.x != 0) return; // uniform: every thread of block 0 reaches the barrier below
+    // the 13 x 13 block: Cn = D C D', D = diag(I3, J, I6), on the upper triangle
+    for (int i = tid; i < 169; i += 256) {
+        const int a = i / 13, b = i % 13;
+        if (a > b) continue;
+        const bool ra = a >= 3 && a < 7, rb = b >= 3 && b < 7;
+        double s;
+        if (!ra && !rb) s = C[a][b];
+        else if (ra && !rb) { // J C[3:7, b]
+            s = 0.0;
+            for (int k = 0; k < 4; ++k) s += J[(a - 3) * 4 + k] * C[3 + k][b];
+        } else if (!ra && rb) { // C[a, 3:7] J'
+            s = 0.0;
+            for (int k = 0; k < 4; ++k) s += C[a][3 + k] * J[(b - 3) * 4 + k];
+        } else { // J C[3:7,3:7] J'
+            s = 0.0;
+            for (int l = 0; l < 4; ++l) {
+                double u = 0.0;
+                for (int k = 0; k < 4; ++k) u += J[(a - 3) * 4 + k] * C[3 + k][3 + l];
+                s += u * J[(b - 3) * 4 + l];
+            }
+        }
+        Cn[a][b] = s;
+        Cn[b][a] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < 169; i += 256) P[(size_t)(i / 13) * ld + i % 13] = (T)Cn[i / 13][i % 13];
+}
+
 // P-update launcher lives in kernels_pupdate.hip
 void launch_p_update(EkfEngine *e, int m_pad, int m);
 
@@ -769,7 +854,11 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     if (!update_cov) return;
     const bool fix_diag = sizeof(T) == 4;
     launch_p_update(e, m_pad, m);
-    if (fix_diag) k_diag_fix<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save, e->d.cam_part, ld);
+    if (fix_diag) {
+        k_fix_normalize<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save,
+                                                           e->d.cam_part, ld, e->d.state);
+        return;
+    }
     const int nb = 1 + (n > 7 ? (n - 7 + 255) / 256 : 0);
     k_normalize_cov<T><<<nb, 256, 0, s>>>((T *)e->d.P, ld, n, e->d.state, e->rm);
 }
