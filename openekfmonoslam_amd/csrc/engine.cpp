@@ -17,7 +17,8 @@ using namespace ekf;
 
 namespace ekf {
 void launch_partition(EkfEngine *e, const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0,
-                      int *cnt1, bool map_update = false, const uint8_t *d_kdesc = nullptr, int *d_idx0 = nullptr);
+                      int *cnt1, bool map_update = false, const uint8_t *d_kdesc = nullptr, int *d_idx0 = nullptr,
+                      int publish_seq = 0);
 void launch_outlier_idx(EkfEngine *e, const EkfMatch *src, int M, int *idx);
 } // namespace ekf
 
@@ -817,6 +818,25 @@ static int read_counts(EkfEngine *e)
     return EKF_OK;
 }
 
+// read_counts for a stage whose last kernel published the counter block itself (publish_counts_block, sequence number
+// taken with next_publish_seq before that launch): poll only
+static int next_publish_seq(EkfEngine *e) { return e->h_mirror ? ++e->mirror_seq : 0; }
+
+static int wait_counts(EkfEngine *e, int seq)
+{
+    if (seq <= 0) return read_counts(e);
+    volatile int *m = e->h_mirror;
+    for (long spin = 0; spin < 400000000L; ++spin) {
+        if (m[CNT_COUNT] == seq) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            for (int i = 0; i < CNT_COUNT; ++i) e->h_counts[i] = m[i];
+            return EKF_OK;
+        }
+        if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(e->stream) == hipSuccess && m[CNT_COUNT] != seq) break;
+    }
+    return read_counts(e); // the stream drained without the write (or the poll gave up): the plain path
+}
+
 static int check_async(EkfEngine *e)
 {
     HIPCHK(hipGetLastError());
@@ -1248,8 +1268,9 @@ static int step_dev_fast(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *
     const int batch = e->cfg.ransac_batch;
     launch_ransac_init(e, N);
     launch_match_index(e, N, cnt + CNT_NMATCH);
-    launch_ransac_batch(e, N, 0, batch, cnt + CNT_NMATCH);
-    if ((rc = read_counts(e))) return rc;
+    const int seq_r = next_publish_seq(e);
+    launch_ransac_batch(e, N, 0, batch, cnt + CNT_NMATCH, seq_r);
+    if ((rc = wait_counts(e, seq_r))) return rc;
     take_error(); // a failure of the previous step's last update, when its final read-back was skipped
     const int np = e->h_counts[CNT_NPRED], M = e->h_counts[CNT_NMATCH];
     e->n_pred = np;
@@ -1284,8 +1305,9 @@ static int step_dev_fast(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *
         e->d.matches = e->d.mout;
         launch_rescue(e, no);
         e->d.matches = save;
-        launch_partition(e, e->d.mout, no, e->d.mask, e->d.msel, nullptr, cnt + CNT_NRESC, true, d_desc); // rescued matches join the inliers (EKF.cpp:552-556)
-        if ((rc = read_counts(e))) return rc;
+        const int seq_p = next_publish_seq(e);
+        launch_partition(e, e->d.mout, no, e->d.mask, e->d.msel, nullptr, cnt + CNT_NRESC, true, d_desc, nullptr, seq_p); // rescued matches join the inliers (EKF.cpp:552-556)
+        if ((rc = wait_counts(e, seq_p))) return rc;
         take_error();
         nr = e->h_counts[CNT_NRESC];
     }

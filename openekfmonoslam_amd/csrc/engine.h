@@ -233,7 +233,8 @@ void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_pred
 void launch_match(EkfEngine *e, int n_pred, int n_kp, const int *d_npred = nullptr);
 // d_M != nullptr (RANSAC launchers): M is an upper bound, the number of matches is read on the device
 void launch_match_index(EkfEngine *e, int M, const int *d_M = nullptr);
-void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M = nullptr);
+// publish_seq > 0: the batch's bookkeeping kernel also publishes the counter block (see publish_counts_block)
+void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M = nullptr, int publish_seq = 0);
 void launch_ransac_init(EkfEngine *e, int M);
 void launch_update(EkfEngine *e, int M, bool update_cov);
 void launch_rescue(EkfEngine *e, int M);
@@ -249,6 +250,23 @@ void launch_match_ncc(EkfEngine *e, int n_pred);
 void launch_gate_snapshot(EkfEngine *e, int n_pred);
 void launch_detect_cells(EkfEngine *e, int n_gates, int cells_x, int cells_y, long long *d_resp, int *d_xy);
 void launch_publish_counts(EkfEngine *e, int *d_mirror, int seq);
+// The same publication from inside a kernel that ends a stage (saves the separate launch): called by EVERY thread of a
+// block after the block's last write to `counts`; lanes 0..15 copy the counters to the GPU-writable host page, lane 0
+// then releases the sequence number the host polls.
+__device__ __forceinline__ void publish_counts_block(const int *counts, int *mirror, int seq)
+{
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 64) { // first wavefront
+        if (t < CNT_COUNT) __hip_atomic_store(&mirror[t], counts[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __builtin_amdgcn_wave_barrier();
+        if (t == 0) {
+            __threadfence_system();
+            __hip_atomic_store(&mirror[CNT_COUNT], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 void launch_pack_predictions(EkfEngine *e, const int *d_list, int n, EkfPrediction *d_out);
 
 } // namespace ekf

@@ -186,7 +186,8 @@ void launch_match_index(EkfEngine *e, int M, const int *d_M)
 // the original order (1PointRansac.cpp:213-227, EKF.cpp:110-117).
 __global__ void __launch_bounds__(1024)
 k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0, int *cnt1, const uint8_t *kdesc,
-            uint8_t *feat_desc, unsigned *times_matched, int desc_bytes, int *idx0)
+            uint8_t *feat_desc, unsigned *times_matched, int desc_bytes, int *idx0, const int *counts, int *mirror,
+            int publish_seq)
 {
     __shared__ int part[1024];
     const int tid = threadIdx.x;
@@ -212,6 +213,7 @@ k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, Ek
         }
     }
     if (tid == 1023 && cnt1) *cnt1 = part[1023];
+    if (publish_seq > 0) publish_counts_block(counts, mirror, publish_seq); // the count above is part of the block
     if (!times_matched) return;
     // updateMapFeatures for the selected matches (MapManagement.cpp:88-113), fused: timesMatched++ and the map descriptor
     // replaced by the matched keypoint's (matcher mode B has no keypoint: keypointIndex < 0)
@@ -229,14 +231,15 @@ k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, Ek
 }
 
 void launch_partition(EkfEngine *e, const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0,
-                      int *cnt1, bool map_update, const uint8_t *d_kdesc, int *d_idx0)
+                      int *cnt1, bool map_update, const uint8_t *d_kdesc, int *d_idx0, int publish_seq)
 {
     if (M <= 0) {
         if (cnt1) (void)hipMemsetAsync(cnt1, 0, sizeof(int), e->stream);
         return;
     }
     k_partition<<<1, 1024, 0, e->stream>>>(src, M, flags, dst1, dst0, cnt1, d_kdesc, e->d.feat_desc,
-                                           map_update ? e->d.feat_times_matched : nullptr, e->desc_bytes, d_idx0);
+                                           map_update ? e->d.feat_times_matched : nullptr, e->desc_bytes, d_idx0, e->d.counts,
+                                           e->d_mirror, e->d_mirror ? publish_seq : 0);
 }
 
 

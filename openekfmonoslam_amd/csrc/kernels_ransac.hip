@@ -89,7 +89,7 @@ k_ransac_hyp(const double *st, CamD cam, double thr, const double *feat_pos, con
 // Sequential bookkeeping of the hypothesis loop (1PointRansac.cpp:125,164-178) over one batch.
 __global__ void __launch_bounds__(256)
 k_ransac_select(int *counts, const int *hyp_count, const uint8_t *hyp_flags, uint8_t *best_flags, int M, int h0,
-                int batch, int mcap, double prob, const int *d_M)
+                int batch, int mcap, double prob, const int *d_M, int *mirror, int publish_seq)
 {
     __shared__ int improved, stop;
     if (d_M) M = *d_M;
@@ -116,15 +116,16 @@ k_ransac_select(int *counts, const int *hyp_count, const uint8_t *hyp_flags, uin
             }
         }
         __syncthreads();
-        if (stop) return;
+        if (stop) break;
         if (improved)
             for (int k = tid; k < M; k += 256) best_flags[k] = hyp_flags[(size_t)b * mcap + k];
         __syncthreads();
     }
-    if (tid == 0) {
+    if (tid == 0 && !stop) {
         const int i = h0 + batch;
         if (!((unsigned)i < (unsigned)counts[CNT_RS_NHYP] && i < M)) counts[CNT_RS_DONE] = 1;
     }
+    if (publish_seq > 0) publish_counts_block(counts, mirror, publish_seq);
 }
 
 // loop state of the hypothesis loop, "no match" in match_of_feat (N entries), zeroed best mask (M entries, M <= N)
@@ -148,7 +149,7 @@ void launch_ransac_init(EkfEngine *e, int M)
     k_ransac_init<<<(n + 255) / 256, 256, 0, e->stream>>>(e->d.counts, e->d.match_of_feat, e->d.best_flags, e->N, M);
 }
 
-void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M)
+void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M, int publish_seq)
 {
     const int nb = batch; // hyp_flags rows are zeroed by their workgroups, hyp_count[b] is only read for launched hypotheses
     const double thr = e->cfg.par.ransacThresholdPredictDistance;
@@ -165,7 +166,8 @@ void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M)
                                                         e->d.match_of_feat, h0, e->d.hyp_count, e->d.hyp_flags,
                                                         e->mcap, d_M);
     k_ransac_select<<<1, 256, 0, e->stream>>>(e->d.counts, e->d.hyp_count, e->d.hyp_flags, e->d.best_flags, M, h0,
-                                              batch, e->mcap, e->cfg.par.ransacAllInliersProbability, d_M);
+                                              batch, e->mcap, e->cfg.par.ransacAllInliersProbability, d_M, e->d_mirror,
+                                              e->d_mirror ? publish_seq : 0);
 }
 
 // ------------------------------------------------------------------------------------------------------ A9
