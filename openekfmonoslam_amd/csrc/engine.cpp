@@ -112,7 +112,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,
                     d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
-                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.W, d.Wf, d.G, d.LL, d.Tbuf, d.xty_queue, d.gates, d.cell_resp, d.cell_xy,
+                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.W, d.Wf, d.G, d.LL, d.Tbuf, d.gates, d.cell_resp, d.cell_xy,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.sq_part, d.diag_save, d.cam_part, d.cam_save, d.HPc, d.Gc, d.Bc, d.zvec, d.yvec,
                     e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq};
     for (void *p : ptrs)
@@ -246,7 +246,6 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     ALLOC(d.Dinv, mw * e->ldW);
     ALLOC(d.W, mw * e->ldW);
     ALLOC(d.Tbuf, mw * e->ldW);
-    ALLOC(d.xty_queue, 4);
     if (e->f32) ALLOC(d.Wf, mw * e->ldW);
     ALLOC(d.mHs, 14 * cap);
     ALLOC(d.mHf, 12 * cap);

@@ -104,7 +104,6 @@ struct DeviceArrays {
     double *S = nullptr;  // (mcap + slack) x ldS: lower triangle of S, updated in place by the sweep
     double *LL = nullptr; // same shape: L below the 32x32 diagonal blocks and L' mirrored above them
     double *Tbuf = nullptr; // [mw x ldW] scratch of the doubling steps (T = L21 X11)
-    unsigned *xty_queue = nullptr; // ticket counter of k_xty_queue (never reset; the host carries the base)
     double *nu = nullptr;
     double *Dinv = nullptr; // V = inv(L), row-major [mw x ldW], built up from 32x32 diagonal blocks by doubling
     double *W = nullptr;    // W = inv(L)' (upper triangular), row-major [mw x ldW]: the k-major operand of B = W' G
@@ -180,7 +179,6 @@ struct EkfEngine {
     int pu_tilemap_nt = -1;
     std::map<int, std::pair<void *, int>> pu_tables; // built work lists of the downdate: key -> (device list, units per XCD)
     int pu_per_xcd = 0;
-    unsigned xty_base = 0; // tickets drawn from xty_queue so far
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // image-only work of the next frame, overlapped with the update
     hipEvent_t ev_main = nullptr, ev_prefetch = nullptr;
@@ -219,7 +217,6 @@ struct XtyArgs {
     int ti_first;                         // first row tile (a launch may cover a row range of the product)
     int k_first;                          // first k (tri != 1): the k-range is [k_first, K), cut at I0 + TM when tri == 2
     int accumulate;                       // C += alpha X'Y instead of C = alpha X'Y
-    int queued;                           // run the units through a work queue on resident workgroups (large single-batch launches)
     int deep;                             // fp32: 32-deep k-slabs (short k-ranges are bound by the load round trip per slab)
     int n_split;                          // bottom row tiles cut into two half units (tri == 2, batch 1 only)
     double alpha;

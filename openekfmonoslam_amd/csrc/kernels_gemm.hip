@@ -14,12 +14,13 @@ namespace ekf {
 // BK: k-slab depth.  The fp64 instances are small, latency-bound GEMMs (a 64x64 tile's MFMAs of one 16-deep slab take
 // 0.2 us, a global load round trip over 1 us), so they run with 32-deep slabs: half as many round trips.
 template <typename T, int BK>
-__device__ __forceinline__ void xty_unit(const XtyArgs &a, int unit, T *smem)
+__global__ void __launch_bounds__(256, BK * sizeof(T) >= 128 ? 2 : 3) k_xty(XtyArgs a)
 {
     using M = Mma<T>;
     constexpr int MB = M::MB, TM = 4 * MB, VEC = M::VEC;
     constexpr int LOADS = BK * TM / (256 * VEC);
     static_assert(LOADS == 2 || LOADS == 4, "two or four 16-byte pieces per thread and slab");
+    __shared__ __attribute__((aligned(16))) T smem[4 * BK * TM];
     T(*sI)[BK][TM] = reinterpret_cast<T(*)[BK][TM]>(smem);
     T(*sJ)[BK][TM] = reinterpret_cast<T(*)[BK][TM]>(smem + 2 * BK * TM);
 
@@ -27,8 +28,8 @@ __device__ __forceinline__ void xty_unit(const XtyArgs &a, int unit, T *smem)
     // a.n_split bottom row tiles are cut into two HALF units (64 of the 128 / 32 of the 64 tile rows each) so that the
     // longest unit, which bounds the launch when every unit is resident at once, is half as long.
     const int per = (a.tiles_i + a.n_split) * a.tiles_j;
-    const int b = unit / per;
-    int t = unit % per, ti, tj, half = -1;
+    const int b = blockIdx.x / per;
+    int t = blockIdx.x % per, ti, tj, half = -1;
     if (t < 2 * a.n_split * a.tiles_j) {
         ti = a.tiles_i - 1 - t / (2 * a.tiles_j);
         tj = (t % (2 * a.tiles_j)) >> 1;
@@ -132,44 +133,11 @@ __device__ __forceinline__ void xty_unit(const XtyArgs &a, int unit, T *smem)
         }
 }
 
-template <typename T, int BK>
-__global__ void __launch_bounds__(256, BK * sizeof(T) >= 128 ? 2 : 3) k_xty(XtyArgs a)
-{
-    __shared__ __attribute__((aligned(16))) T smem[4 * BK * Mma<T>::MB * 4];
-    xty_unit<T, BK>(a, blockIdx.x, smem);
-}
-
-// The same units pulled from a queue by resident workgroups (two per CU): the units of B = inv(L) G differ 8x in
-// k-depth, and with one workgroup per unit all of them run at once, three to a CU -- the launch lasts as long as the
-// deepest unit takes at a third of a CU.  In queue order (deepest first) a unit gets its half of a CU and the short ones
-// fill the end.  The counter is never reset: a launch of `total` units on `grid` workgroups advances it by total + grid
-// (every workgroup draws one ticket past the end), the host carries the base (unsigned arithmetic, wrap-safe).
-template <typename T, int BK>
-__global__ void __launch_bounds__(256, BK * sizeof(T) >= 128 ? 2 : 3) k_xty_queue(XtyArgs a, unsigned *queue, unsigned base, unsigned total)
-{
-    __shared__ __attribute__((aligned(16))) T smem[4 * BK * Mma<T>::MB * 4];
-    __shared__ unsigned s_unit;
-    for (;;) {
-        __syncthreads(); // the previous unit's LDS reads are over
-        if (threadIdx.x == 0) s_unit = atomicAdd(queue, 1u) - base;
-        __syncthreads();
-        const unsigned u = s_unit;
-        if (u >= total) return;
-        xty_unit<T, BK>(a, (int)u, smem);
-    }
-}
-
 void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32, hipStream_t stream)
 {
+    (void)e;
     const int grid = batch * (a.tiles_i + a.n_split) * a.tiles_j;
     if (grid <= 0) return;
-    if (a.queued && grid > 512 && e->d.xty_queue) { // resident workgroups + queue (see k_xty_queue)
-        const unsigned total = (unsigned)grid, wgs = 512;
-        if (f32) k_xty_queue<float, 16><<<wgs, 256, 0, stream>>>(a, e->d.xty_queue, e->xty_base, total);
-        else k_xty_queue<double, 32><<<wgs, 256, 0, stream>>>(a, e->d.xty_queue, e->xty_base, total);
-        e->xty_base += total + wgs;
-        return;
-    }
     if (f32 && a.deep) k_xty<float, 32><<<grid, 256, 0, stream>>>(a);
     else if (f32) k_xty<float, 16><<<grid, 256, 0, stream>>>(a);
     else k_xty<double, 32><<<grid, 256, 0, stream>>>(a);

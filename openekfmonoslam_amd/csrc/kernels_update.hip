@@ -13,8 +13,6 @@
 //
 // The reference forms K = P H' inv(S) with an LU inverse and multiplies the dense (I - K H) by P (2 n^3 flops);
 // both give the same x and P up to rounding (S is symmetric positive definite: R = pixelErrorX * I).
-#include <cstdlib>
-
 #include "engine.h"
 #include "chol32.h"
 
@@ -833,7 +831,6 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         g.row0_first = 0; g.row0_stride = 0; g.m_lim = m_pad;
         g.tri = 2; g.tiles_i = (m_pad + TM - 1) / TM; g.tiles_j = (n_pad + TM - 1) / TM; g.alpha = 1.0;
         g.n_split = g.tiles_i / 2; // k-depth of row tile i is ~(i+1) TM: halve the units of the longer half
-        g.queued = std::getenv("EKF_XTY_NOQUEUE") ? 0 : 1;
         launch_xty(e, g, 1, e->f32, s);
     }
     {
