@@ -292,12 +292,27 @@ def main():
         eng = engine.EkfEngine(seq.cam, seq.par, N, shard=(rank, world) if sharded else None, **kw)
         if sharded and args.transport == "rccl":
             # the engine's own communicator: rank 0 draws the id, torch.distributed only carries those 128 bytes
-            uid = torch.zeros(128, dtype=torch.uint8, device=ranks.device if ranks.dist.get_backend() == "nccl" else "cpu")
+            uid = torch.zeros(129, dtype=torch.uint8, device=ranks.device if ranks.dist.get_backend() == "nccl" else "cpu")
             if rank == 0:
-                uid.copy_(torch.from_numpy(engine.comm_unique_id()))
+                try:
+                    uid[:128].copy_(torch.from_numpy(engine.comm_unique_id()))
+                    uid[128] = 1
+                except Exception as ex:  # noqa: BLE001 -- uid[128] stays 0: every rank takes the callback transport
+                    print(f"[bench] no RCCL for the engine ({ex}); callback transport", file=sys.stderr)
             ranks.dist.broadcast(uid, src=0)
-            eng.comm_init(uid.cpu().numpy())
-        elif sharded:
+            ok = torch.ones(1, dtype=torch.int32, device=uid.device)
+            if int(uid[128].item()) == 1:
+                try:
+                    eng.comm_init(uid[:128].cpu().numpy())
+                except Exception as ex:  # noqa: BLE001 -- the transport is chosen by consensus below
+                    print(f"[bench] rank {rank}: engine communicator unavailable ({ex})", file=sys.stderr)
+                    ok.zero_()
+            else:
+                ok.zero_()
+            ranks.dist.all_reduce(ok, op=ranks.dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:  # same transport on every rank: the exchange is collective
+                args.transport = "callback"
+        if sharded and args.transport == "callback":
             from openekfmonoslam_amd.shard import DistributedExchange
 
             eng.set_exchange(DistributedExchange(ranks.dist, ranks.device))

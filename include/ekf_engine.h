@@ -192,6 +192,12 @@ int ekf_step_frame(EkfEngine *e, int frame, EkfStepInfo *info);
  * second update is ENQUEUED).  A failed factorisation of that update (EKF_ERR_NOT_POSITIVE_DEFINITE) is reported by the
  * next ekf_step* instead -- the reference reports nothing at all (cv::invert returns zeros).  Default off. */
 int ekf_set_async_errors(EkfEngine *e, int on);
+/* How an update forms B = inv(L) (H P), the factor of the covariance downdate (replaces K = P H' inv(S),
+ * EKF/Update.cpp:105-108): EKF_UPDATE_PATH_AUTO by the number of measurement rows (the default), EKF_UPDATE_PATH_SWEEP
+ * always inside the launches of the Cholesky sweep (forward substitution, no explicit inverse), EKF_UPDATE_PATH_GEMM
+ * always by inverting L and one GEMM.  Same result to rounding; a tuning / test knob. */
+enum { EKF_UPDATE_PATH_AUTO = 0, EKF_UPDATE_PATH_SWEEP = 1, EKF_UPDATE_PATH_GEMM = 2 };
+int ekf_set_update_path(EkfEngine *e, int path);
 
 /* -- matcher mode B: image in, no detector ----------------------------------------------------------------
  * matchPredictedFeatures(const cv::Mat &image, ...)  EKF/Matching.h:66 and EKF::step(const cv::Mat &image)
@@ -258,7 +264,8 @@ int ekf_set_exchange(EkfEngine *e, EkfExchangeFn fn, void *user);
  * rank's block travels over its own link to each peer), enqueued on the engine's stream -- no stream drain, no host
  * callback.  Rank 0 obtains the id, the host distributes it (any out-of-band channel), every rank calls
  * ekf_comm_init (collective).  RCCL is loaded at run time (librccl.so.1); EKF_ERR_COMM if it is not there.
- * A communicator takes precedence over a callback installed with ekf_set_exchange. */
+ * A callback installed with ekf_set_exchange takes precedence over the communicator (a host whose ranks could not all
+ * form one falls back to its own transport on every rank); ekf_set_exchange(e, NULL, NULL) hands it back. */
 #define EKF_COMM_ID_BYTES 128
 int ekf_comm_unique_id(uint8_t id[EKF_COMM_ID_BYTES]);
 int ekf_comm_init(EkfEngine *e, const uint8_t id[EKF_COMM_ID_BYTES]);

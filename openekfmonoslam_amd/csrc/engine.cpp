@@ -112,7 +112,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,
                     d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
-                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.W, d.Wf, d.G, d.LL, d.Tbuf, d.gates, d.cell_resp, d.cell_xy,
+                    d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.W, d.Wf, d.G, d.LL, d.LLf, d.Tbuf, d.gates, d.cell_resp, d.cell_xy,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.sq_part, d.diag_save, d.cam_part, d.cam_save, d.HPc, d.Gc, d.Bc, d.zvec, d.yvec,
                     e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq};
     for (void *p : ptrs)
@@ -242,6 +242,7 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     const size_t mw = (size_t)round_up((int)mcap, 128) + 128;
     ALLOC(d.S, mw * e->ldS);
     ALLOC(d.LL, mw * e->ldS);
+    if (e->f32) ALLOC(d.LLf, mw * e->ldS);
     ALLOC(d.nu, mcap);
     ALLOC(d.Dinv, mw * e->ldW);
     ALLOC(d.W, mw * e->ldW);
@@ -343,7 +344,7 @@ int ekf_comm_init(EkfEngine *e, const uint8_t id[EKF_COMM_ID_BYTES])
 static int exchange_rows(EkfEngine *e, int what, void *base, size_t row_bytes, const std::vector<int32_t> &rb, const char *name)
 {
     const int world = e->shard_world, me = e->shard_rank;
-    if (e->comm) {
+    if (e->comm && !e->xchg) { // a callback installed after ekf_comm_init takes over (ranks that fell back by consensus)
         RcclApi &api = rccl_api();
         ncclComm_t c = (ncclComm_t)e->comm;
         uint8_t *b = (uint8_t *)base;
@@ -1330,6 +1331,13 @@ int ekf_set_async_errors(EkfEngine *e, int on)
 {
     if (!e) return EKF_ERR_INVALID_ARG;
     e->async_errors = on != 0;
+    return EKF_OK;
+}
+
+int ekf_set_update_path(EkfEngine *e, int path)
+{
+    if (!e || path < EKF_UPDATE_PATH_AUTO || path > EKF_UPDATE_PATH_GEMM) return EKF_ERR_INVALID_ARG;
+    e->b_path = path;
     return EKF_OK;
 }
 

@@ -14,6 +14,7 @@ namespace ekf {
 
 constexpr int NB = 32;          // Cholesky panel width
 constexpr int LD_ALIGN = 128;   // leading dimensions are multiples of this many elements
+constexpr int B_SWEEP_MAX = 2048; // rows of S up to which B = inv(L) G is formed inside the sweep's launches
 constexpr int DX_SPLIT = 16;    // k-splits of the dx = B' z reduction
 
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -103,6 +104,7 @@ struct DeviceArrays {
     void *A = nullptr;   // T [(mcap + 1) x ldP] : B = inv(L) G  (k-major operand of the downdate)
     double *S = nullptr;  // (mcap + slack) x ldS: lower triangle of S, updated in place by the sweep
     double *LL = nullptr; // same shape: L below the 32x32 diagonal blocks and L' mirrored above them
+    float *LLf = nullptr; // fp32 covariance: the mirrored part (L') again in fp32, the A operand of the rows of B
     double *Tbuf = nullptr; // [mw x ldW] scratch of the doubling steps (T = L21 X11)
     double *nu = nullptr;
     double *Dinv = nullptr; // V = inv(L), row-major [mw x ldW], built up from 32x32 diagonal blocks by doubling
@@ -168,6 +170,7 @@ struct EkfEngine {
     EkfExchangeFn xchg = nullptr;        // all-gather of per-feature row blocks between the ranks
     void *comm = nullptr;                // ncclComm_t of the in-engine transport (ekf_comm_init), or null
     void *xchg_user = nullptr;
+    int b_path = 0;            // ekf_set_update_path: 0 by size (B_SWEEP_MAX), 1 B in the sweep, 2 inverse + GEMM
     bool async_errors = false; // ekf_set_async_errors: no read-back at the end of a step
     bool p_exact_sym = false; // P known to be bitwise symmetric (engine-maintained invariant)
     int n_pred = 0;           // predictions of the last full prediction

@@ -14,7 +14,10 @@
 // The reference forms K = P H' inv(S) with an LU inverse and multiplies the dense (I - K H) by P (2 n^3 flops);
 // both give the same x and P up to rounding (S is symmetric positive definite: R = pixelErrorX * I).
 #include "engine.h"
+#include <vector>
+#include <cstdio>
 #include "chol32.h"
+#include "mma_tile.h"
 
 namespace ekf {
 
@@ -146,16 +149,43 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 //   mirrored, L' above them: the operands of the inverse's doubling levels).  S itself is only read in column k, so
 //   nothing races.  Tile 0 = block (k+1, k+1): look-ahead factorisation, publishes Linv_{k+1}.
 //   nu block: z_k = Linv_k nu_k, then nu_i -= L_ik z_k = S_ik (Linv_k' z_k) for all rows below.
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, double *nu, int n_stiles, double *V,
-            double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc)
+k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0, int kb, double *nu, int n_stiles, double *V,
+            double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc, const T *G, T *Bout, int ld,
+            int n_bblocks, int n_rhs, unsigned long long *trace)
 {
-    __shared__ double sA[NB][NB + 1];
-    __shared__ double sB[NB][NB + 1];
-    __shared__ double sLi[NB][NB + 1]; // inv(L_kk)
+    const unsigned long long t_in = trace ? wall_clock64() : 0ull;
+#define SWEEP_TRACE(role)                                                                      \
+    if (trace && threadIdx.x == 0) {                                                           \
+        atomicMin(trace, t_in);                                                                \
+        atomicMax(trace + 1 + (role), (unsigned long long)wall_clock64());                     \
+        if ((role) == 2) atomicMax(trace + 6, t_in);                                           \
+        if ((role) == 3) atomicMax(trace + 7, t_in);                                           \
+    }
+    constexpr int NR = 14; // right-hand sides: nu + 13 camera columns
+    // tile role: S_ik, S_jk, L_ik, L_jk; B role: two partial sums, G_k - sum; right-hand sides: R, Z, W
+    __shared__ double pool[4][NB][NB + 1];
+    __shared__ double sLi[NB][NB + 1];       // inv(L_kk)
+    double(*sA)[NB + 1] = pool[0];
+    double(*sB)[NB + 1] = pool[1];
     const int tid = threadIdx.x;
     const int k1 = k0 + kb;
-    const int b = blockIdx.x;
+    // block order: the look-ahead workgroup, the row block of B (the longest units of a late panel; a column block keeps
+    // its place in the order, hence its XCD and the L2 that holds its rows of B), the right-hand sides, the other tiles
+    int b = blockIdx.x;
+    int bcol = -1;
+    {
+        const int f = n_stiles > 0 ? 1 : 0;
+        if (b >= f && b < f + n_bblocks) {
+            bcol = b - f;
+            b = n_stiles + 1; // not a tile: takes the loads of a right-hand-side block below
+        } else if (b >= f + n_bblocks && b < f + n_bblocks + n_rhs) {
+            b = n_stiles + (b - f - n_bblocks);
+        } else if (b >= f + n_bblocks + n_rhs) {
+            b -= n_bblocks + n_rhs;
+        }
+    }
     // every global load of the prologue is issued before the first LDS store waits on one of them (the look-ahead
     // workgroup's inputs are cold: they were written by the previous launch on other XCDs)
     double gv[4];
@@ -168,9 +198,103 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
 #pragma unroll
         for (int q = 0; q < 4; ++q) sLi[(tid + q * 256) / NB][(tid + q * 256) % NB] = gv[q];
     }
+    if (bcol >= 0) {
+        // Row block k of B = inv(L) G, columns 32 bcol ..: B_k = inv(L_kk) (G_k - sum_{j<k} L_kj B_j) -- every operand
+        // is final when this launch starts (L_kj: stored by the panels before, B_j: by their launches), so the forward
+        // substitution costs no launch of its own and runs beside the look-ahead factorisation, which leaves most CUs
+        // idle.  One 32 x 32 block per workgroup, the j-range dealt to the four wavefronts (their partial sums meet
+        // in LDS); operands go straight from L2 into the MFMA operand layout: the mirrored copy of L (L' above the
+        // diagonal blocks of LL) makes the lanes of an A operand read consecutive addresses.
+        using M = Mma<T>;
+        constexpr int MB = M::MB, NBLK = NB / MB, KS = 64 / MB, NSTEP = NB / KS;
+        T(*red)[NB][NB + 1] = reinterpret_cast<T(*)[NB][NB + 1]>(&pool[0][0][0]); // two partial sums (pool[0..1] at most)
+        double(*sR)[NB + 1] = pool[2];
+        const int lane = tid & 63, wv = tid >> 6;
+        const int lm = lane % MB, lq = lane / MB;
+        const int c0 = bcol * NB;
+        const int kp = k0 / NB; // panels before this one
+        const T *Lt = sizeof(T) == 4 ? (const T *)LLf : (const T *)LL; // L' above the diagonal blocks, in T
+        typename M::acc_t acc[NBLK][NBLK];
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < NBLK; ++bj)
+#pragma unroll
+                for (int r = 0; r < M::NACC; ++r) acc[bi][bj][r] = (T)0;
+        // the wavefront's blocks j = wv, wv + 4, ...: operands of the next two blocks are in flight while one is multiplied
+        // (a block's MFMAs take 0.45 us, a load round trip under load over 1 us)
+        T la[3][NSTEP][NBLK], lb[3][NSTEP][NBLK];
+#define CB_LOAD(S_, J_)                                                                                           \
+    _Pragma("unroll") for (int st = 0; st < NSTEP; ++st) {                                                        \
+        const size_t kr = (size_t)(J_) * NB + st * KS + lq;                                                       \
+        _Pragma("unroll") for (int bb = 0; bb < NBLK; ++bb) {                                                     \
+            la[S_][st][bb] = Lt[kr * ldS + k0 + MB * bb + lm];                                                    \
+            lb[S_][st][bb] = Bout[kr * ld + c0 + MB * bb + lm];                                                   \
+        }                                                                                                         \
+    }
+#define CB_MMA(S_)                                                                                                \
+    _Pragma("unroll") for (int st = 0; st < NSTEP; ++st)                                                          \
+        _Pragma("unroll") for (int bi = 0; bi < NBLK; ++bi)                                                       \
+            _Pragma("unroll") for (int bj = 0; bj < NBLK; ++bj)                                                   \
+                acc[bi][bj] = M::mma(la[S_][st][bi], lb[S_][st][bj], acc[bi][bj]);
+        const int cnt = kp > wv ? (kp - wv + 3) / 4 : 0;
+        if (cnt > 0) { CB_LOAD(0, wv) }
+        if (cnt > 1) { CB_LOAD(1, wv + 4) }
+        for (int i = 0; i < cnt; i += 3) {
+            if (i + 2 < cnt) { CB_LOAD(2, wv + 4 * (i + 2)) }
+            CB_MMA(0)
+            if (i + 1 < cnt) {
+                if (i + 3 < cnt) { CB_LOAD(0, wv + 4 * (i + 3)) }
+                CB_MMA(1)
+            }
+            if (i + 2 < cnt) {
+                if (i + 4 < cnt) { CB_LOAD(1, wv + 4 * (i + 4)) }
+                CB_MMA(2)
+            }
+        }
+#undef CB_LOAD
+#undef CB_MMA
+        // partial sums: wavefronts 2, 3 through LDS to wavefronts 0, 1, whose sums meet in red[0..1]
+        if (wv >= 2) {
+#pragma unroll
+            for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < NBLK; ++bj)
+#pragma unroll
+                    for (int r = 0; r < M::NACC; ++r) red[wv - 2][MB * bi + M::row(r, lane)][MB * bj + M::col(lane)] = acc[bi][bj][r];
+        }
+        __syncthreads();
+        if (wv < 2) {
+#pragma unroll
+            for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < NBLK; ++bj)
+#pragma unroll
+                    for (int r = 0; r < M::NACC; ++r) red[wv][MB * bi + M::row(r, lane)][MB * bj + M::col(lane)] += acc[bi][bj][r];
+        }
+        const int r = tid >> 3, cg = (tid & 7) * 4;
+        T g4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g4[e] = G[(size_t)(k0 + r) * ld + c0 + cg + e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            sR[r][cg + e] = (double)g4[e] - ((double)red[0][r][cg + e] + (double)red[1][r][cg + e]);
+        __syncthreads();
+        double o[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q <= r; ++q) {
+            const double l = sLi[r][q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += l * sR[q][cg + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bout[(size_t)(k0 + r) * ld + c0 + cg + e] = (T)o[e];
+        SWEEP_TRACE(1)
+        return;
+    }
     if (b < n_stiles) {
-        __shared__ double sLI[NB][NB + 1];
-        __shared__ double sLJ[NB][NB + 1];
+        double(*sLI)[NB + 1] = pool[2];
+        double(*sLJ)[NB + 1] = pool[3];
         int ti = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
         while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
         while (ti * (ti + 1) / 2 > b) --ti;
@@ -250,6 +374,7 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
             __syncthreads();
             if (!block_chol_inv32_mf(sA, sB) && tid == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
             store_linv(V, W, Wf, ldw, k1, sB);
+            SWEEP_TRACE(0)
         }
         if (tj == 0) { // L_ik for the doubling levels: below the diagonal and, mirrored, above it (zero rows m..m_pad);
                        // after the factorisation in tile 0, off its critical path
@@ -259,65 +384,142 @@ k_chol_step(double *S, double *LL, int ldS, int m, int m_pad, int k0, int kb, do
             }
             for (int i = tid; i < NB * NB; i += 256) {
                 const int c = i / NB, r = i % NB;
-                if (i0 + r < m_pad && c < kb) LL[(size_t)(k0 + c) * ldS + i0 + r] = sLI[r][c];
+                if (i0 + r < m_pad && c < kb) {
+                    LL[(size_t)(k0 + c) * ldS + i0 + r] = sLI[r][c];
+                    if (LLf) LLf[(size_t)(k0 + c) * ldS + i0 + r] = (float)sLI[r][c];
+                }
             }
         }
+        SWEEP_TRACE(2)
         return;
     }
     // right-hand-side blocks: [ nu | Gc ] (Gc = fp64 camera columns of the gathered H P rows, fp32 configuration only) are
     // carried through the sweep like extra columns of S:  Z_k = Linv_k R_k (final rows of z and of Bc = inv(L) Gc), then
-    // R_i -= L_ik Z_k = S_ik (Linv_k' Z_k) for the rows below.  Block nb handles rows k1 + 256 nb ...; every block forms
+    // R_i -= L_ik Z_k = S_ik (Linv_k' Z_k) for the rows below.  Block nb handles rows k1 + 64 nb ...; every block forms
     // the 32 x 14 matrices itself (a 32^2 x 14 product) from the rows k0.. of the WORKING arrays nu / Gc, which nobody
     // writes in this launch; block 0 stores Z_k into the RESULT arrays zout / Bc (writing it back in place would race
     // with the other blocks' reads of those rows).
-    constexpr int NR = 14; // nu + 13 camera columns
-    __shared__ double sR[NB][NR + 1], sZ[NB][NR + 1], sW[NB][NR + 1];
+    constexpr int NRP = 16; // right-hand sides padded to one MFMA block
+    double(*sR)[NRP + 1] = reinterpret_cast<double(*)[NRP + 1]>(&pool[0][0][0]);
+    double(*sZ)[NRP + 1] = reinterpret_cast<double(*)[NRP + 1]>(&pool[1][0][0]);
+    double(*sW)[NRP + 1] = reinterpret_cast<double(*)[NRP + 1]>(&pool[2][0][0]);
     const int nb = b - n_stiles;
     const int nrhs = Gc ? NR : 1;
-    for (int i = tid; i < NB * NR; i += 256) {
-        const int r = i / NR, c = i % NR;
-        double v = 0.0;
-        if (r < kb && c < nrhs) v = c == 0 ? nu[k0 + r] : Gc[(size_t)(k0 + r) * 16 + c - 1];
-        sR[r][c] = v;
+    // the panel's rows of [ nu | Gc ] first (the products below wait for them), then this block's rows of S: 64 rows per
+    // block, four lanes to a row (each a quarter of the row's 32 columns: the lanes of a wavefront read 16 whole rows,
+    // 256 contiguous bytes each), in flight during the products
+    double rv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int idx = tid + q * 256, r = idx / NRP, c = idx % NRP;
+        rv[q] = 0.0;
+        if (r < kb && c < nrhs) rv[q] = c == 0 ? nu[k0 + r] : Gc[(size_t)(k0 + r) * 16 + c - 1];
     }
-    __syncthreads();
-    for (int i = tid; i < NB * NR; i += 256) { // Z = Linv_k R_k
-        const int r = i / NR, c = i % NR;
-        double z = 0.0;
-        if (c < nrhs)
-            for (int q = 0; q <= r; ++q) z += sLi[r][q] * sR[q][c];
-        sZ[r][c] = r < kb ? z : 0.0;
+    const int i = k1 + nb * 64 + (tid >> 2), part = tid & 3;
+    double sv[8];
+    {
+        const double *srow = S + (size_t)min(i, m - 1) * ldS + k0 + 8 * part;
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            const double2 t = *(const double2 *)(srow + q);
+            sv[q] = i < m ? t.x : 0.0;
+            sv[q + 1] = i < m ? t.y : 0.0;
+        }
     }
+    // ... and the values this lane will update (lane `part` of a row owns the right-hand sides part, part + 4, ...)
+    double old[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = part + 4 * q;
+        old[q] = 0.0;
+        if (i < m && c < nrhs) old[q] = c == 0 ? nu[i] : Gc[(size_t)i * 16 + c - 1];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) sR[(tid + q * 256) / NRP][(tid + q * 256) % NRP] = rv[q];
     __syncthreads();
-    for (int i = tid; i < NB * NR; i += 256) { // W = Linv_k' Z
-        const int r = i / NR, c = i % NR;
-        double w = 0.0;
-        if (c < nrhs)
-            for (int q = r; q < NB; ++q) w += sLi[q][r] * sZ[q][c];
-        sW[r][c] = w;
-        if (nb == 0 && r < kb && c < nrhs) {
-            if (c == 0) zout[k0 + r] = sZ[r][0];
-            else Bc[(size_t)(k0 + r) * 16 + c - 1] = sZ[r][c];
+    // Z = Linv_k R_k and W = Linv_k' Z on the fp64 MFMA (32 x 32 x 16: one 16 x 16 block per wavefront 0, 1; as scalar
+    // loops of dependent LDS reads the two products took 5 of this block's 9 us)
+    typedef double acc4 __attribute__((ext_vector_type(4)));
+    const int lane = tid & 63, wv = tid >> 6, lm = lane & 15, lq = lane >> 4;
+    if (wv < 2) {
+        acc4 z = {0, 0, 0, 0};
+#pragma unroll
+        for (int k4 = 0; k4 < NB; k4 += 4) z = __builtin_amdgcn_mfma_f64_16x16x4f64(sLi[16 * wv + lm][k4 + lq], sR[k4 + lq][lm], z, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 16 * wv + lq + 4 * q;
+            sZ[r][lm] = r < kb ? z[q] : 0.0;
         }
     }
     __syncthreads();
-    const int i = k1 + nb * 256 + tid;
-    if (i < m) {
+    if (wv < 2) {
+        acc4 w = {0, 0, 0, 0};
+#pragma unroll
+        for (int k4 = 0; k4 < NB; k4 += 4) w = __builtin_amdgcn_mfma_f64_16x16x4f64(sLi[k4 + lq][16 * wv + lm], sZ[k4 + lq][lm], w, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sW[16 * wv + lq + 4 * q][lm] = w[q];
+    } else if (nb == 0) {
+        for (int idx = tid - 128; idx < NB * NR; idx += 128) {
+            const int r = idx / NR, c = idx % NR;
+            if (r < kb && c < nrhs) {
+                if (c == 0) zout[k0 + r] = sZ[r][0];
+                else Bc[(size_t)(k0 + r) * 16 + c - 1] = sZ[r][c];
+            }
+        }
+    }
+    __syncthreads();
+    {
         double acc[NR];
 #pragma unroll
         for (int c = 0; c < NR; ++c) acc[c] = 0.0;
-        const double *srow = S + (size_t)i * ldS + k0;
-        for (int q = 0; q < kb; ++q) {
-            const double sv = srow[q];
 #pragma unroll
-            for (int c = 0; c < NR; ++c) acc[c] += sv * sW[q][c];
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int c = 0; c < NR; ++c)
+                if (c == 0 || Gc) acc[c] += sv[q] * sW[8 * part + q][c];
         }
-        nu[i] -= acc[0];
-        if (Gc) {
 #pragma unroll
-            for (int c = 1; c < NR; ++c) Gc[(size_t)i * 16 + c - 1] -= acc[c];
+        for (int c = 0; c < NR; ++c)
+            if (c == 0 || Gc) {
+                acc[c] += __shfl_xor(acc[c], 1, 64);
+                acc[c] += __shfl_xor(acc[c], 2, 64);
+            }
+        if (i < m) {
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                if ((c & 3) != part) continue; // the four lanes of a row share its stores
+                if (c == 0) nu[i] = old[0] - acc[0];
+                else if (Gc) Gc[(size_t)i * 16 + c - 1] = old[c >> 2] - acc[c];
+            }
         }
     }
+    SWEEP_TRACE(3)
+#undef SWEEP_TRACE
+}
+
+// Debug aid (scripts/sweep_trace.py): per launch of the sweep, the earliest workgroup start and the latest end of each
+// role (0 look-ahead published, 1 row block of B, 2 tiles, 3 right-hand sides), in 10 ns ticks of the constant clock.
+constexpr int TRACE_SLOTS = 8, TRACE_MAX = 4096;
+static unsigned long long *g_trace = nullptr;
+static int g_trace_n = 0;
+extern "C" int ekf_debug_sweep_trace(int enable, unsigned long long *out, int *count)
+{
+    if (enable && !g_trace) {
+        if (hipMalloc(&g_trace, sizeof(unsigned long long) * TRACE_SLOTS * TRACE_MAX) != hipSuccess) return -1;
+    }
+    if (out && g_trace) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(out, g_trace, sizeof(unsigned long long) * TRACE_SLOTS * g_trace_n, hipMemcpyDeviceToHost);
+        if (count) *count = g_trace_n;
+    }
+    if (g_trace) {
+        std::vector<unsigned long long> init(TRACE_SLOTS * TRACE_MAX, 0ull);
+        for (int i = 0; i < TRACE_MAX; ++i) init[(size_t)i * TRACE_SLOTS] = ~0ull;
+        (void)hipMemcpy(g_trace, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice);
+    }
+    g_trace_n = 0;
+    if (!enable && g_trace) { (void)hipFree(g_trace); g_trace = nullptr; }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------- inverse of a diagonal chunk of L
@@ -798,21 +1000,37 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         k_assemble_S<T><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts);
     }
+    // B = inv(L) G: up to B_SWEEP_MAX rows, row block k is formed inside the launch of panel k (forward substitution
+    // beside the look-ahead factorisation: no explicit inverse, no GEMM launch); above it the per-launch row block becomes
+    // longer than the factorisation it hides behind, and the explicit inverse + one big-tile GEMM is the better use of
+    // the MFMA pipe.  e->b_path (ekf_set_update_path): 0 by size, 1 always in the sweep, 2 always by GEMM.
+    const bool b_in_sweep = e->b_path == 1 || (e->b_path == 0 && m_pad <= B_SWEEP_MAX);
+    const int n_bblocks = b_in_sweep ? n_pad / NB : 0; // row block k of B = inv(L) G rides in the launch of panel k
     for (int k0 = 0; k0 < m; k0 += NB) {
         const int kb = min(NB, m - k0);
         const int k1 = k0 + kb;
         const int nrb = (m - k1 + NB - 1) / NB; // row blocks below the panel
         const int n_stiles = nrb * (nrb + 1) / 2;
-        const int n_rhs_blocks = max(1, (m - k1 + 255) / 256); // right-hand-side blocks, 256 rows each
-        k_chol_step<<<n_stiles + n_rhs_blocks, 256, 0, s>>>(e->d.S, e->d.LL, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles, V, W, Wf,
-                                                            ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr, e->d.zvec, e->d.Bc);
+        const int n_rhs_blocks = max(1, (m - k1 + 63) / 64); // right-hand-side blocks, 64 rows each
+        const int n_wgs = n_stiles + n_rhs_blocks + n_bblocks;
+        unsigned long long *tr = nullptr;
+        if (g_trace && g_trace_n < TRACE_MAX) {
+            tr = g_trace + (size_t)TRACE_SLOTS * g_trace_n++;
+            static unsigned long long tags[TRACE_MAX];
+            tags[g_trace_n - 1] = ((unsigned long long)k0 << 32) | (unsigned long long)m;
+            (void)hipMemcpyAsync(tr + 5, &tags[g_trace_n - 1], sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+        }
+        k_chol_step<T><<<n_wgs, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(T) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles,
+                                                                           V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
+                                                                           e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks, tr);
     }
     // inv(L): the 128 x 128 diagonal chunks in one launch, then by doubling 128 -> 256 -> ... until one block covers all rows
-    {
+    const bool need_inverse = !b_in_sweep;
+    if (need_inverse) {
         const int nbk = m_pad / NB, n_chunks = (nbk + INV_CH - 1) / INV_CH;
         if (nbk > 1) k_inv_diag<<<dim3(INV_CH - 1, n_chunks), 256, 0, s>>>(e->d.LL, ldS, V, W, Wf, ldw, nbk);
     }
-    for (int sz = INV_CH * NB; sz < m_pad; sz *= 2) {
+    for (int sz = INV_CH * NB; need_inverse && sz < m_pad; sz *= 2) {
         const int npairs = (m_pad - sz + 2 * sz - 1) / (2 * sz); // pairs whose second half has rows
         {   // 32x32 output tiles on the fp64 MFMA at every level: these products are small (m^3/3 flop in total) and
             // need many workgroups with short k-loops rather than big tiles (64x64 tiles left 3/4 of the CUs idle)
@@ -821,7 +1039,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.LL, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 1);
         }
     }
-    {   // B = inv(L) G = W' G : one GEMM, k <= row (W upper triangular)
+    if (!b_in_sweep) {   // B = inv(L) G = W' G : one GEMM, k <= row (W upper triangular)
         const int TM = sizeof(T) == 4 ? 128 : 64;
         XtyArgs g{};
         g.X = e->f32 ? (const void *)Wf : (const void *)W; g.ldx = ldw;
@@ -841,8 +1059,10 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const T *Gy = nullptr;
         if (sizeof(T) == 4) {
             Bc = e->d.Bc; // inv(L) Gc, produced by the right-hand-side blocks of k_chol_step
-            k_yvec<<<(m + 3) / 4, 256, 0, s>>>(W, ldw, m, e->d.zvec, e->d.yvec);
-            Gy = G;
+            // feature columns of dx: with the explicit inverse at hand, (H P)' y with y = inv(L)' z in fp64 (k_yvec);
+            // on the sweep path B' z (fp32 B): the same to 1e-6 of the largest component of a block, see DESIGN.md section 6
+            Gy = need_inverse ? G : nullptr;
+            if (Gy) k_yvec<<<(m + 3) / 4, 256, 0, s>>>(W, ldw, m, e->d.zvec, e->d.yvec);
         }
         k_dx_partial<T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld,
                                              fix ? e->d.sq_part : nullptr, fix ? e->d.cam_part : nullptr, Bc, (const T *)e->d.P,

@@ -52,8 +52,25 @@ def pmc_sq(db_paths, out_path, like="%k_p_update%"):
                         f"CUs with a resident wavefront {cu:.3f}; LDS bank conflicts {means.get('SQ_LDS_BANK_CONFLICT', (0,) * 6)[idx]:.0f}\n")
 
 
+def by_grid(db_path, like):
+    """mean duration of a kernel's launches by grid size (the sweep: one grid size per panel index)"""
+    cur = sqlite3.connect(db_path).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    gx = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else None)
+    dur = "duration" if "duration" in cols else "(end - start)"
+    if gx is None:
+        print("columns:", cols)
+        return
+    rows = list(cur.execute(f"select {gx}, count(*), avg({dur}) from kernels where name like ? group by {gx} order by {gx}", (like,)))
+    for g, n, d in rows:
+        print(f"grid {g:8d}  launches {n:5d}  avg {d / 1e3:8.2f} us")
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
+    if mode == "by_grid":
+        by_grid(sys.argv[2], sys.argv[3])
+        sys.exit(0)
     if mode == "pmc_sq":
         pmc_sq(sys.argv[3:], sys.argv[2])
         sys.exit(0)

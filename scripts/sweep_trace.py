@@ -1,0 +1,38 @@
+"""Per-launch timeline of the Cholesky sweep (GPU box): for one steady-state frame, when each role of a k_chol_step launch
+ends relative to the launch's first workgroup.  usage: sweep_trace.py [N] [warm frames]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from openekfmonoslam_amd import engine  # noqa: E402
+from openekfmonoslam_amd.synth import SyntheticSequence  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 15
+seq = SyntheticSequence(N, F + 1)
+e = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=1 if N >= 1000 else 0)
+e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+L = engine.load_library()
+fn = L.ekf_debug_sweep_trace
+fn.restype = C.c_int
+fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+for t in range(F):
+    e.step(*seq.frames[t])
+fn(1, None, None)
+info = e.step(*seq.frames[F])
+buf = np.zeros(8 * 4096, dtype=np.uint64)
+cnt = C.c_int(0)
+fn(0, buf.ctypes.data_as(C.c_void_p), C.byref(cnt))
+rows = buf[: 8 * cnt.value].reshape(-1, 8)
+print(f"frame: matches {info.n_matches} li {info.n_inliers} hi {info.n_rescued}; {cnt.value} sweep launches")
+print("   k0     m   lookahead   B-role   tiles     rhs   (us after the launch's first workgroup started)  last tile start  last rhs start")
+prev_start = None
+for i, r in enumerate(rows):
+    t0 = int(r[0])
+    d = [(int(x) - t0) / 100.0 if int(x) else float("nan") for x in r[1:5]]
+    st = [(int(x) - t0) / 100.0 if int(x) else float("nan") for x in r[6:8]]
+    print(f"{int(r[5]) >> 32:5d} {int(r[5]) & 0xffffffff:5d}   {d[0]:8.2f} {d[1]:8.2f} {d[2]:8.2f} {d[3]:8.2f}   {st[0]:8.2f} {st[1]:8.2f}")

@@ -301,10 +301,16 @@ def test_staged_frames_equal_host_frames(eng_mod, seq12):
     np.testing.assert_array_equal(Pa, Pb)
 
 
-def test_n200_fp64_frames_vs_oracle(eng_mod, oracle_lib):
+# the two ways an update forms B = inv(L) (H P) (ekf_set_update_path): inside the Cholesky sweep / inverse + GEMM
+UPDATE_PATHS = [pytest.param(1, id="sweep"), pytest.param(2, id="gemm")]
+
+
+@pytest.mark.parametrize("path", UPDATE_PATHS)
+def test_n200_fp64_frames_vs_oracle(eng_mod, oracle_lib, path):
     """configs[1] (N = 200, fp64 covariance): three frames against the LITERAL oracle."""
     seq = SyntheticSequence(200, 3)
     e, o = make_pair(eng_mod, oracle_lib, seq)
+    e.set_update_path(path)
     for t, (kps, desc) in enumerate(seq.frames):
         ie = e.step(kps, desc)
         io = o.step(kps, desc, oracle_lib.LITERAL)
@@ -313,10 +319,12 @@ def test_n200_fp64_frames_vs_oracle(eng_mod, oracle_lib):
         assert_state_close(e, o, 1e-8, f"N=200 step {t}")
 
 
-def test_n200_fp32_frames_vs_oracle(eng_mod, oracle_lib):
+@pytest.mark.parametrize("path", UPDATE_PATHS)
+def test_n200_fp32_frames_vs_oracle(eng_mod, oracle_lib, path):
     """fp32 covariance path at N = 200 against the fp64 oracle: the 1e-5 north-star tolerance, norm-wise on P."""
     seq = SyntheticSequence(200, 3)
     e, o = make_pair(eng_mod, oracle_lib, seq, precision=1)
+    e.set_update_path(path)
     for t, (kps, desc) in enumerate(seq.frames):
         ie = e.step(kps, desc)
         io = o.step(kps, desc, oracle_lib.ALGORITHMIC)

@@ -29,9 +29,10 @@ def eng_mod():
     return engine
 
 
-def run_pair(eng_mod, ol, seq, frames, precision=1):
+def run_pair(eng_mod, ol, seq, frames, precision=1, path=0):
     N = seq.n_features
     e = eng_mod.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=precision)
+    e.set_update_path(path)
     o = ol.Oracle(seq.cam, seq.par, N + 8)
     e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
     o.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
@@ -61,6 +62,14 @@ def test_n1000_fp32_four_frames_vs_oracle(eng_mod, oracle_lib, kw):
     seq = SyntheticSequence(1000, 4, **kw)
     worst = run_pair(eng_mod, oracle_lib, seq, 4)
     print("N=1000 fp32 worst block errors over 4 frames:", {k: f"{v:.2e}" for k, v in worst.items()})
+
+
+def test_n1000_fp32_inverse_and_gemm_path_vs_oracle(eng_mod, oracle_lib):
+    """The same bar with B = inv(L) H P forced onto the explicit inverse + GEMM (the path of updates with more than 2048
+    measurement rows; at N = 1000 the sweep path is the default and the five scenes above run it)."""
+    seq = SyntheticSequence(1000, 3)
+    worst = run_pair(eng_mod, oracle_lib, seq, 3, path=2)
+    print("N=1000 fp32 (inverse + GEMM) worst block errors over 3 frames:", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
 def test_n2000_fp32_two_frames_vs_oracle(eng_mod, oracle_lib):
