@@ -153,7 +153,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0, int kb, double *nu, int n_stiles, double *V,
             double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc, const T *G, T *Bout, int ld,
-            int n_bblocks, int n_rhs, unsigned long long *trace)
+            int n_bblocks, int n_rhs, unsigned long long *trace, int abl)
 {
     const unsigned long long t_in = trace ? wall_clock64() : 0ull;
 #define SWEEP_TRACE(role)                                                                      \
@@ -173,6 +173,7 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
     const int k1 = k0 + kb;
     // block order: the look-ahead workgroup, the row block of B (the longest units of a late panel; a column block keeps
     // its place in the order, hence its XCD and the L2 that holds its rows of B), the right-hand sides, the other tiles
+    // (tiles first in the early panels, where their cold loads are the launch's tail, measured no different)
     int b = blockIdx.x;
     int bcol = -1;
     {
@@ -185,6 +186,11 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         } else if (b >= f + n_bblocks + n_rhs) {
             b -= n_bblocks + n_rhs;
         }
+    }
+    if (abl) { // timing experiments only (scripts/sweep_trace.py): a role returns at once
+        if ((abl & 1) && bcol >= 0) return;
+        if ((abl & 2) && bcol < 0 && b >= n_stiles) return;
+        if ((abl & 4) && bcol < 0 && b > 0 && b < n_stiles) return;
     }
     // every global load of the prologue is issued before the first LDS store waits on one of them (the look-ahead
     // workgroup's inputs are cold: they were written by the previous launch on other XCDs)
@@ -502,8 +508,10 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
 constexpr int TRACE_SLOTS = 8, TRACE_MAX = 4096;
 static unsigned long long *g_trace = nullptr;
 static int g_trace_n = 0;
+static int g_trace_abl = 0;
 extern "C" int ekf_debug_sweep_trace(int enable, unsigned long long *out, int *count)
 {
+    g_trace_abl = enable >> 8;
     if (enable && !g_trace) {
         if (hipMalloc(&g_trace, sizeof(unsigned long long) * TRACE_SLOTS * TRACE_MAX) != hipSuccess) return -1;
     }
@@ -1022,7 +1030,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         }
         k_chol_step<T><<<n_wgs, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(T) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles,
                                                                            V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
-                                                                           e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks, tr);
+                                                                           e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks, tr, tr ? g_trace_abl : 0);
     }
     // inv(L): the 128 x 128 diagonal chunks in one launch, then by doubling 128 -> 256 -> ... until one block covers all rows
     const bool need_inverse = !b_in_sweep;

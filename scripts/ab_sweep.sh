@@ -1,19 +1,10 @@
 mkdir -p gpurun_out/r2z
 (
-python -m pytest tests -m gpu -q -x 2>&1 | tail -4
-for i in 1 2; do
-  python bench.py --steps 40 --warmup 10 --no-all-matched --no-single-gpu-reference --no-cpu-baseline 2>/dev/null | python -c "
+python -m pytest tests/test_gpu_parity.py -q -x 2>&1 | tail -2
+for v in 100000 200 100 400 100000 200 100 400; do
+  EKF_TILES_FIRST=$v python bench.py --steps 40 --warmup 10 --no-all-matched --no-single-gpu-reference --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n1000', round(d['value'],1), d.get('parity_ok'), {k:round(v,3) for k,v in d['stage_ms_per_step'].items()}, d['roofline']['frac'])"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('tiles_first>=$v', round(d['value'],1), {k:round(v,3) for k,v in d['stage_ms_per_step'].items()})"
 done
-python bench.py --workload n200_f64 --steps 40 --warmup 10 --no-all-matched --no-single-gpu-reference --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n200', round(d['value'],1), {k:round(v,3) for k,v in d['stage_ms_per_step'].items()})"
-python bench.py --workload n2000_f32 --steps 10 --warmup 5 --no-all-matched --no-single-gpu-reference --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n2000', round(d['value'],1), {k:round(v,3) for k,v in d['stage_ms_per_step'].items()})"
-python bench.py --workload n5000_f32 --steps 3 --warmup 1 --no-all-matched --no-single-gpu-reference --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n5000', round(d['value'],2), {k:round(v,3) for k,v in d['stage_ms_per_step'].items()})"
-) > gpurun_out/r2z/full.log 2>&1
-tail -30 gpurun_out/r2z/full.log
+) > gpurun_out/r2z/tf.log 2>&1
+cat gpurun_out/r2z/tf.log

@@ -16,19 +16,24 @@ F = int(sys.argv[2]) if len(sys.argv) > 2 else 15
 seq = SyntheticSequence(N, F + 1)
 e = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=1 if N >= 1000 else 0)
 e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+e.set_update_path(int(os.environ.get('UPDATE_PATH', '0')))
 L = engine.load_library()
 fn = L.ekf_debug_sweep_trace
 fn.restype = C.c_int
 fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
 for t in range(F):
     e.step(*seq.frames[t])
-fn(1, None, None)
-info = e.step(*seq.frames[F])
+fn(1 | (int(os.environ.get('ABL', '0')) << 8), None, None)
+try:
+    info = e.step(*seq.frames[F])
+except Exception as ex:  # an ablated role leaves a wrong factor: the timeline is still valid
+    print('step failed (expected with ABL):', ex)
+    info = None
 buf = np.zeros(8 * 4096, dtype=np.uint64)
 cnt = C.c_int(0)
 fn(0, buf.ctypes.data_as(C.c_void_p), C.byref(cnt))
 rows = buf[: 8 * cnt.value].reshape(-1, 8)
-print(f"frame: matches {info.n_matches} li {info.n_inliers} hi {info.n_rescued}; {cnt.value} sweep launches")
+print(f"frame: {(info.n_matches, info.n_inliers, info.n_rescued) if info else None}; {cnt.value} sweep launches")
 print("   k0     m   lookahead   B-role   tiles     rhs   (us after the launch's first workgroup started)  last tile start  last rhs start")
 prev_start = None
 for i, r in enumerate(rows):
