@@ -65,12 +65,32 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
     }
 }
 
+// one 32 x kb block of L (rows i0.., columns k0..) from LDS to LL / LLf, see k_chol_step
+__device__ __forceinline__ void store_l_block(double *LL, float *LLf, bool full, int ldS, int m_pad, int i0, int k0, int kb,
+                                              const double (*sL)[NB + 1])
+{
+    if (full) {
+        for (int i = threadIdx.x; i < NB * NB; i += 256) {
+            const int r = i / NB, c = i % NB;
+            if (i0 + r < m_pad && c < kb) LL[(size_t)(i0 + r) * ldS + k0 + c] = sL[r][c];
+        }
+    }
+    for (int i = threadIdx.x; i < NB * NB; i += 256) {
+        const int c = i / NB, r = i % NB;
+        if (i0 + r < m_pad && c < kb) {
+            if (full || !LLf) LL[(size_t)(k0 + c) * ldS + i0 + r] = sL[r][c];
+            if (LLf) LLf[(size_t)(k0 + c) * ldS + i0 + r] = (float)sL[r][c];
+        }
+    }
+}
+
 // inv(L_kk) goes to V (row-major inv(L)), its transpose to W (and to the fp32 copy of W, when present)
 __device__ __forceinline__ void store_linv(double *V, double *W, float *Wf, int ldw, int k0, const double (*x)[NB + 1])
 {
     for (int i = threadIdx.x; i < NB * NB; i += 256) {
         const int r = i / NB, c = i % NB;
         V[(size_t)(k0 + r) * ldw + k0 + c] = x[r][c];
+        if (!W) continue; // only the inverse + GEMM path reads W
         const double t = x[c][r]; // W[k0 + r][k0 + c] = inv(L)[k0 + c][k0 + r]
         W[(size_t)(k0 + r) * ldw + k0 + c] = t;
         if (Wf) Wf[(size_t)(k0 + r) * ldw + k0 + c] = (float)t;
@@ -382,20 +402,12 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
             store_linv(V, W, Wf, ldw, k1, sB);
             SWEEP_TRACE(0)
         }
-        if (tj == 0) { // L_ik for the doubling levels: below the diagonal and, mirrored, above it (zero rows m..m_pad);
-                       // after the factorisation in tile 0, off its critical path
-            for (int i = tid; i < NB * NB; i += 256) {
-                const int r = i / NB, c = i % NB;
-                if (i0 + r < m_pad && c < kb) LL[(size_t)(i0 + r) * ldS + k0 + c] = sLI[r][c];
-            }
-            for (int i = tid; i < NB * NB; i += 256) {
-                const int c = i / NB, r = i % NB;
-                if (i0 + r < m_pad && c < kb) {
-                    LL[(size_t)(k0 + c) * ldS + i0 + r] = sLI[r][c];
-                    if (LLf) LLf[(size_t)(k0 + c) * ldS + i0 + r] = (float)sLI[r][c];
-                }
-            }
-        }
+        // L_ik leaves the tiles of the first tile column: mirrored (L' above the diagonal blocks; zero rows m..m_pad) for
+        // the rows of B -- in fp32 when the covariance is --, and with W set (inverse + GEMM path) also row-major and in
+        // fp64 for the inverse's levels.  The look-ahead workgroup's own block is stored by tile (1, 0), which holds the
+        // same block as L_jk, when that tile exists: the look-ahead workgroup is the one the launch waits for.
+        if (tj == 0 && (b != 0 || n_stiles == 1)) store_l_block(LL, LLf, W != nullptr, ldS, m_pad, i0, k0, kb, sLI);
+        if (b == 1) store_l_block(LL, LLf, W != nullptr, ldS, m_pad, j0, k0, kb, sLJ);
         SWEEP_TRACE(2)
         return;
     }
@@ -995,8 +1007,13 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     const int n_pad = round_up(n, LD_ALIGN);
     T *G = (T *)e->d.G; // gathered rows of H P
     T *A = (T *)e->d.A; // B = inv(L) G
-    double *V = e->d.Dinv, *W = e->d.W;
-    float *Wf = e->f32 ? e->d.Wf : nullptr;
+    // B = inv(L) G: up to B_SWEEP_MAX rows, row block k is formed inside the launch of panel k (forward substitution
+    // beside the look-ahead factorisation: no explicit inverse, no GEMM launch); above it the per-launch row block becomes
+    // longer than the factorisation it hides behind, and the explicit inverse + one big-tile GEMM is the better use of
+    // the MFMA pipe.  e->b_path (ekf_set_update_path): 0 by size, 1 always in the sweep, 2 always by GEMM.
+    const bool b_in_sweep = e->b_path == 1 || (e->b_path == 0 && m_pad <= B_SWEEP_MAX);
+    double *V = e->d.Dinv, *W = b_in_sweep ? nullptr : e->d.W; // W = inv(L)' (and L row-major in LL): the GEMM path's
+    float *Wf = e->f32 && !b_in_sweep ? e->d.Wf : nullptr;
     {
         dim3 grid((n_pad / (int)(16 / sizeof(T)) + 255) / 256, m_pad);
         k_gather<T><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const T *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
@@ -1008,11 +1025,6 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         k_assemble_S<T><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts);
     }
-    // B = inv(L) G: up to B_SWEEP_MAX rows, row block k is formed inside the launch of panel k (forward substitution
-    // beside the look-ahead factorisation: no explicit inverse, no GEMM launch); above it the per-launch row block becomes
-    // longer than the factorisation it hides behind, and the explicit inverse + one big-tile GEMM is the better use of
-    // the MFMA pipe.  e->b_path (ekf_set_update_path): 0 by size, 1 always in the sweep, 2 always by GEMM.
-    const bool b_in_sweep = e->b_path == 1 || (e->b_path == 0 && m_pad <= B_SWEEP_MAX);
     const int n_bblocks = b_in_sweep ? n_pad / NB : 0; // row block k of B = inv(L) G rides in the launch of panel k
     for (int k0 = 0; k0 < m; k0 += NB) {
         const int kb = min(NB, m - k0);
