@@ -714,7 +714,7 @@ __global__ void __launch_bounds__(256) k_yvec(const double *W, int ldw, int m, c
     if (lane == 0) y[i] = s;
 }
 
-template <typename T>
+template <typename T, bool USE_G>
 __global__ void __launch_bounds__(256)
 k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, int ldpart, double *sq_part, double *cam_part,
              const double *Bc, const T *P, RowMap rm, double *dsave, double *csave, int avg, const T *G, const double *y)
@@ -745,18 +745,31 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
             for (int i = threadIdx.x; i < cnt * 13; i += 256) sc[i / 13][i % 13] = Bc[(size_t)(k0 + i / 13) * 16 + i % 13];
             __syncthreads();
         }
-        if (j < n)
-            for (int k = 0; k < cnt; ++k) {
-                const double b = (Bc && j < 13) ? sc[k][j] : (double)B[(size_t)(k0 + k) * ld + j];
-                // feature columns of the fp32 configuration: dx_j = sum_k (H P)_kj y_k (see k_yvec); camera columns: Bc' z (fp64)
-                if (G && j >= 13) s += (double)G[(size_t)(k0 + k) * ld + j] * y[k0 + k];
-                else s += b * z[k0 + k];
-                q += b * b; // (B'B)_jj in fp64, same pass over B: see k_diag_fix
-                if (cam_part) {
+        if (j < n) {
+            // the whole chunk's rows are requested before the first is used: a split is one round trip to memory, not
+            // one per few rows (the loop was latency-bound: 30 us for 23 MB)
+            T bv[64], gv[USE_G ? 64 : 1];
 #pragma unroll
-                    for (int a = 0; a < 13; ++a) c[a] += sc[k][a] * b; // (B'B)_aj, camera rows
+            for (int u = 0; u < 64; ++u) {
+                const int k = min(u, cnt - 1);
+                bv[u] = B[(size_t)(k0 + k) * ld + j];
+                if (USE_G) gv[u] = j >= 13 ? G[(size_t)(k0 + k) * ld + j] : (T)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 64; ++u) {
+                if (u < cnt) {
+                    const double b = (Bc && j < 13) ? sc[u][j] : (double)bv[u];
+                    // feature columns with the explicit inverse at hand: dx_j = sum_k (H P)_kj y_k (see k_yvec); camera columns: Bc' z (fp64)
+                    if (USE_G && j >= 13) s += (double)gv[u] * y[k0 + u];
+                    else s += b * z[k0 + u];
+                    q += b * b; // (B'B)_jj in fp64, same pass over B: see k_diag_fix
+                    if (cam_part) {
+#pragma unroll
+                        for (int a = 0; a < 13; ++a) c[a] += sc[u][a] * b; // (B'B)_aj, camera rows
+                    }
                 }
             }
+        }
     }
     if (j >= n) return;
     part[(size_t)ks * ldpart + j] = s;
@@ -1084,9 +1097,12 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             Gy = need_inverse ? G : nullptr;
             if (Gy) k_yvec<<<(m + 3) / 4, 256, 0, s>>>(W, ldw, m, e->d.zvec, e->d.yvec);
         }
-        k_dx_partial<T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld,
-                                             fix ? e->d.sq_part : nullptr, fix ? e->d.cam_part : nullptr, Bc, (const T *)e->d.P,
+#define DX_LAUNCH(USEG) k_dx_partial<T, USEG><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, \
+                                             fix ? e->d.sq_part : nullptr, fix ? e->d.cam_part : nullptr, Bc, (const T *)e->d.P, \
                                              e->rm, e->d.diag_save, fix ? e->d.cam_save : nullptr, avg, Gy, e->d.yvec);
+        if (Gy) { DX_LAUNCH(true) } else { DX_LAUNCH(false) }
+#undef DX_LAUNCH
+
         const int nt = max(e->N * 6, 1);
         k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
                                                        e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
