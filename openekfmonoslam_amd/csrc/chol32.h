@@ -301,4 +301,113 @@ __device__ __forceinline__ bool block_chol_inv32_mf(double (*a)[CH_NB + 1], doub
     return ok;
 }
 
+// block_chol_inv32_mf with less LDS traffic and no idle MFMAs (`a` is overwritten: it serves as scratch at the end).  The trailing block stays symmetric under the elimination,
+// so the panel column A[r][4J + k] is read as the pivot row's element A[4J + k][r]: only the four pivot rows of the A
+// half are published (one value per lane of wavefronts 0, 1); a lane's B operand is its own accumulator element (the
+// pivot row it holds), not a round trip through LDS.  Updates that cannot change a live element are not issued: rows
+// 0..15 once the pivot has passed them (J >= 3), columns of A the elimination has already left behind (wavefront 0 from
+// J = 3), columns of X the pivot rows cannot reach yet (wavefront 3 before J = 4), everything at the last step.
+__device__ __forceinline__ bool block_chol_inv32_v4(double (*a)[CH_NB + 1], double (*x)[CH_NB + 1])
+{
+    typedef double acc4 __attribute__((ext_vector_type(4)));
+    __shared__ double pr[2][4][CH_NB]; // pr[buf][k][c] = A[4J + k][c]
+    __shared__ double fac[8][10];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int lc = lane & 15, lq = lane >> 4;
+    acc4 m0, m1;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int r0 = lq + 4 * v, r1 = 16 + lq + 4 * v, c = 16 * w + lc;
+        if (w < 2) {
+            m0[v] = c <= r0 ? a[r0][c] : a[c][r0];
+            m1[v] = c <= r1 ? a[r1][c] : a[c][r1];
+        } else {
+            m0[v] = (c - CH_NB == r0) ? 1.0 : 0.0;
+            m1[v] = (c - CH_NB == r1) ? 1.0 : 0.0;
+        }
+    }
+    bool ok = true;
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+        const int p = J & 1, j0 = 4 * J;
+        const int v0 = (j0 % 16) / 4;
+        const double bv = (j0 < 16) ? m0[v0] : m1[v0]; // [A | X][4J + lq][16 w + lc]: this lane's pivot-row element
+        if (w < 2) pr[p][lq][16 * w + lc] = bv;
+        __syncthreads();
+        const double(*pp)[CH_NB] = pr[p];
+        const double d00 = pp[0][j0];
+        const double d10 = pp[1][j0], d11 = pp[1][j0 + 1];
+        const double d20 = pp[2][j0], d21 = pp[2][j0 + 1], d22 = pp[2][j0 + 2];
+        const double d30 = pp[3][j0], d31 = pp[3][j0 + 1], d32 = pp[3][j0 + 2], d33 = pp[3][j0 + 3];
+        const double i0 = fast_rcp(d00);
+        const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+        const double e11 = d11 - l10 * d10;
+        const double e21 = d21 - l20 * d10, e31 = d31 - l30 * d10;
+        const double i1 = fast_rcp(e11);
+        const double l21 = e21 * i1, l31 = e31 * i1;
+        const double e22 = d22 - l20 * d20 - l21 * e21;
+        const double e32 = d32 - l30 * d20 - l31 * e21;
+        const double i2 = fast_rcp(e22);
+        const double l32 = e32 * i2;
+        const double e33 = d33 - l30 * d30 - l31 * e31 - l32 * e32;
+        const double i3 = fast_rcp(e33);
+        ok = ok && d00 > 0.0 && e11 > 0.0 && e22 > 0.0 && e33 > 0.0;
+        if (t == 0) {
+            double *f = fac[J];
+            f[0] = l10; f[1] = l20; f[2] = l30; f[3] = l21; f[4] = l31; f[5] = l32;
+            f[6] = i0; f[7] = i1; f[8] = i2; f[9] = i3;
+        }
+        if (J == 7) break; // no rows below the last pivot block
+        const bool live = (w == 0 && J < 3) || (w == 1) || (w == 2) || (w == 3 && J >= 4); // wave-uniform, static per J
+        if (!live) continue;
+        // column lq of inv(D): solve D e = unit(lq)
+        const double u0 = lq == 0 ? 1.0 : 0.0, u1 = lq == 1 ? 1.0 : 0.0, u2 = lq == 2 ? 1.0 : 0.0, u3 = lq == 3 ? 1.0 : 0.0;
+        const double y0 = u0;
+        const double y1 = u1 - l10 * y0;
+        const double y2 = u2 - l20 * y0 - l21 * y1;
+        const double y3 = u3 - l30 * y0 - l31 * y1 - l32 * y2;
+        const double q3 = y3 * i3;
+        const double q2 = y2 * i2 - l32 * q3;
+        const double q1 = y1 * i1 - l21 * q2 - l31 * q3;
+        const double q0 = y0 * i0 - l10 * q1 - l20 * q2 - l30 * q3;
+        // w[r][lq] for this lane's rows (rows at or above the pivot block are not touched)
+        const int r1 = 16 + lc;
+        double w1 = pp[0][r1] * q0 + pp[1][r1] * q1 + pp[2][r1] * q2 + pp[3][r1] * q3;
+        if (r1 < j0 + 4) w1 = 0.0;
+        if (J < 3) {
+            const int r0 = lc;
+            double w0 = pp[0][r0] * q0 + pp[1][r0] * q1 + pp[2][r0] * q2 + pp[3][r0] * q3;
+            if (r0 < j0 + 4) w0 = 0.0;
+            m0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-w0, bv, m0, 0, 0, 0);
+        }
+        m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-w1, bv, m1, 0, 0, 0);
+    }
+    // X (wavefronts 2, 3) to LDS -- into `a`, which nobody reads any more: no barrier before, none between the solve's
+    // reads and the result's stores --, then the unit-lower solve inside each 4-row group and the sqrt of the pivots
+    if (w >= 2) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            a[lq + 4 * v][16 * (w - 2) + lc] = m0[v];
+            a[16 + lq + 4 * v][16 * (w - 2) + lc] = m1[v];
+        }
+    }
+    __syncthreads();
+    const int r = t >> 3, c0 = (t & 7) * 4;
+    const int base = r & ~3, q = r & 3;
+    const double *f = fac[r >> 2];
+    const double sr = sqrt(f[6 + q]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e;
+        const double u0 = a[base][c];
+        const double u1 = a[base + 1][c] - f[0] * u0;
+        const double u2 = a[base + 2][c] - f[1] * u0 - f[3] * u1;
+        const double u3 = a[base + 3][c] - f[2] * u0 - f[4] * u1 - f[5] * u2;
+        const double res = q == 0 ? u0 : (q == 1 ? u1 : (q == 2 ? u2 : u3));
+        x[r][c] = (c <= r) ? res * sr : 0.0;
+    }
+    __syncthreads();
+    return ok;
+}
+
 } // namespace ekf

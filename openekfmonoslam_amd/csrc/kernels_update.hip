@@ -144,14 +144,14 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
         sa[r][c] = (r < kb && c <= r) ? S[(size_t)r * ldS + c] : ((r == c) ? 1.0 : 0.0);
     }
     __syncthreads();
-    if (!block_chol_inv32_mf(sa, sx) && threadIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
+    if (!block_chol_inv32_v4(sa, sx) && threadIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
     store_linv(V, W, Wf, ldw, 0, sx);
 }
 
 // -------------------------------------------------------------------------------------- blocked Cholesky sweep
 // Right-looking sweep over [ S | nu ], panel width NB = 32, ONE launch per panel (k_chol_step).  The only serial
 // piece is the 32x32 diagonal block: its Cholesky factor and the inverse of that factor.  It is computed by one
-// workgroup with all 256 threads working in LDS (block_chol_inv32_mf in chol32.h: 4x4 block pivots, rank-4 updates on the fp64 MFMA, one barrier per
+// workgroup with all 256 threads working in LDS (block_chol_inv32_v4 in chol32.h: 4x4 block pivots, rank-4 updates on the fp64 MFMA, one barrier per
 // block column) and -- look-ahead -- inside the launch of the PREVIOUS panel, by the workgroup that owns tile
 // (k+1, k+1): while the other workgroups of that launch update their tiles, this one finishes its tile, factorises
 // it and stores inv(L_{k+1,k+1}) into V / W.  The panel solve L_ik = S_ik inv(L_kk)' is not a launch of its own:
@@ -398,7 +398,7 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
                 sA[r][c] = lv ? v[q] : ((r == c) ? 1.0 : 0.0);
             }
             __syncthreads();
-            if (!block_chol_inv32_mf(sA, sB) && tid == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
+            if (!block_chol_inv32_v4(sA, sB) && tid == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
             store_linv(V, W, Wf, ldw, k1, sB);
             SWEEP_TRACE(0)
         }

@@ -1,8 +1,13 @@
-out=$(realpath gpurun_out/r2z); root=$(pwd); mkdir -p $out
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/prof -- python3 $root/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-all-matched --no-single-gpu-reference > $out/prof.json 2> $out/prof.err
-cd $root
-db=$(find $out/prof -name "*.db" | head -1)
-python3 scripts/profile_summary.py stats $db $out/prof_stats.csv
-rm -rf $out/prof
-head -30 $out/prof_stats.csv
+mkdir -p gpurun_out/r2z
+(
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge_cases.py tests/test_gpu_sharded.py -q -x 2>&1 | tail -2
+for i in 1 2 3; do
+  python bench.py --steps 40 --warmup 10 --no-all-matched --no-single-gpu-reference --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n1000', round(d['value'],1), {k:round(v,3) for k,v in d['stage_ms_per_step'].items()})"
+done
+python bench.py --workload n200_f64 --steps 40 --warmup 10 --no-all-matched --no-single-gpu-reference --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n200', round(d['value'],1), {k:round(v,3) for k,v in d['stage_ms_per_step'].items()})"
+) > gpurun_out/r2z/q.log 2>&1
+cat gpurun_out/r2z/q.log

@@ -168,7 +168,8 @@ __global__ void __launch_bounds__(256) k_run(const double *A, double *Linv, long
         const long long c0 = clock64(), w0 = wall_clock64();
         if (V == 0) ok = block_chol_inv32(sa, sx, srs) && ok;
         else if (V == 1) ok = block_chol_inv32_bp(sa, sx) && ok;
-        else ok = block_chol_inv32_mf(sa, sx) && ok;
+        else if (V == 2) ok = block_chol_inv32_mf(sa, sx) && ok;
+        else ok = block_chol_inv32_v4(sa, sx) && ok;
         c_acc += clock64() - c0;
         w_acc += wall_clock64() - w0;
     }
@@ -192,7 +193,7 @@ int main()
     long long *dT;
     hipMalloc(&dA, n * n * 8); hipMalloc(&dL, n * n * 8); hipMalloc(&dT, 64);
     hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
-    for (int v = 0; v < 3; ++v) {
+    for (int v = 0; v < 4; ++v) {
         const int reps = 50;
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
@@ -200,7 +201,8 @@ int main()
             hipEventRecord(e0);
             if (v == 0) k_run<0><<<1, 256>>>(dA, dL, dT, reps);
             else if (v == 1) k_run<1><<<1, 256>>>(dA, dL, dT, reps);
-            else k_run<2><<<1, 256>>>(dA, dL, dT, reps);
+            else if (v == 2) k_run<2><<<1, 256>>>(dA, dL, dT, reps);
+            else k_run<3><<<1, 256>>>(dA, dL, dT, reps);
             hipEventRecord(e1);
             hipDeviceSynchronize();
         }
