@@ -5,8 +5,9 @@
 //     S  = G H' + R       (m x m fp64, lower triangle; block-sparse H => 13-term dot products)
 //     S  = L L'           (blocked right-looking Cholesky, fp64, one launch per 32-wide panel; z = inv(L) nu and, in the
 //                          fp32 configuration, the fp64 camera columns of B ride along as right-hand sides)
-//     inv(L)              (128 x 128 diagonal chunks in one launch, then doubling levels, fp64 MFMA)
-//     B  = inv(L) G       (ONE GEMM against the inverted factor, kernels_gemm.hip)
+//     B  = inv(L) G       up to 2048 rows: row block k inside the launch of panel k (forward substitution on the MFMA
+//                          beside the look-ahead factorisation); above: inv(L) explicitly (128 x 128 diagonal chunks,
+//                          then doubling levels, fp64 MFMA) and ONE GEMM against it (kernels_gemm.hip)
 //     dx = B' z           (= K nu,  K = P H' inv(S))
 //     P <- sym(P) - B' B  (= 0.5 ((I-KH)P + ((I-KH)P)'), kernels_pupdate.hip -- the MFMA kernel)
 //     q normalisation and its Jacobian on the rows/columns 3..6 of P (Update.cpp:45-85, 303-317)
