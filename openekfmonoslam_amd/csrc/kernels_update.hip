@@ -839,25 +839,36 @@ k_state_apply(double *st, double *feat_pos, const int *feat_type, const int *fea
               int ldpart, int normalise)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t == 0) {
-        double *x = st + ST_X;
-        for (int i = 0; i < 13; ++i) {
+    // this thread's feature parameter: the k-splits are requested together, before the camera part below
+    const bool live = t < N * 6 && (t % 6) < feat_dim(feat_type[t / 6]);
+    const int j = live ? feat_covpos[t / 6] + t % 6 : 0;
+    double pv[DX_SPLIT];
+#pragma unroll
+    for (int ks = 0; ks < DX_SPLIT; ++ks) pv[ks] = part[(size_t)ks * ldpart + j];
+    if (blockIdx.x == 0) { // camera part: one thread per component sums its splits, thread 0 applies and normalises
+        __shared__ double cam[13];
+        if (threadIdx.x < 13) {
             double s = 0.0;
-            for (int ks = 0; ks < DX_SPLIT; ++ks) s += part[(size_t)ks * ldpart + i];
-            if (fabs(s) > EKF_DELTA) x[i] += s;
+#pragma unroll
+            for (int ks = 0; ks < DX_SPLIT; ++ks) s += part[(size_t)ks * ldpart + threadIdx.x];
+            cam[threadIdx.x] = s;
         }
-        // the covariance downdate that sits between the state update and the normalisation in the reference
-        // (Update.cpp:299-312) does not read the state, so the normalisation is done here (not for updateOnlyState)
-        if (normalise) quat_norm_dev(st);
-        else quat_to_rot(x + 3, st + ST_R);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double *x = st + ST_X;
+            for (int i = 0; i < 13; ++i)
+                if (fabs(cam[i]) > EKF_DELTA) x[i] += cam[i];
+            // the covariance downdate that sits between the state update and the normalisation in the reference
+            // (Update.cpp:299-312) does not read the state, so the normalisation is done here (not for updateOnlyState)
+            if (normalise) quat_norm_dev(st);
+            else quat_to_rot(x + 3, st + ST_R);
+        }
     }
-    if (t >= N * 6) return;
-    const int f = t / 6, a = t % 6;
-    if (a >= feat_dim(feat_type[f])) return;
-    const int j = feat_covpos[f] + a;
+    if (!live) return;
     double s = 0.0;
-    for (int ks = 0; ks < DX_SPLIT; ++ks) s += part[(size_t)ks * ldpart + j];
-    if (fabs(s) > EKF_DELTA) feat_pos[6 * f + a] += s;
+#pragma unroll
+    for (int ks = 0; ks < DX_SPLIT; ++ks) s += pv[ks];
+    if (fabs(s) > EKF_DELTA) feat_pos[6 * (t / 6) + t % 6] += s;
 }
 
 // ------------------------------------------------------------------------------ quaternion normalisation tail

@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/r2z
 (
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge_cases.py tests/test_gpu_sharded.py -q -x 2>&1 | tail -2
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge_cases.py tests/test_gpu_sharded.py -q -x 2>&1 | grep -E "passed|failed"
 for i in 1 2 3; do
   python bench.py --steps 40 --warmup 10 --no-all-matched --no-single-gpu-reference --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
