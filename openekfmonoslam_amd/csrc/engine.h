@@ -216,11 +216,7 @@ struct XtyArgs {
     int M, N, K;                          // output rows / columns / k-depth per batch element
     int row0_first, row0_stride, m_lim;   // rows of element b that exist: min(M, m_lim - (row0_first + b row0_stride))
     int tri;                              // 0: all k; 1: Y[k][j] = 0 for k < j; 2: X[k][i] = 0 for k > i
-    int tiles_i, tiles_j;                 // row tiles of this launch (from ti_first on) / column tiles
-    int ti_first;                         // first row tile (a launch may cover a row range of the product)
-    int k_first;                          // first k (tri != 1): the k-range is [k_first, K), cut at I0 + TM when tri == 2
-    int accumulate;                       // C += alpha X'Y instead of C = alpha X'Y
-    int deep;                             // fp32: 32-deep k-slabs (short k-ranges are bound by the load round trip per slab)
+    int tiles_i, tiles_j;                 // row tiles / column tiles
     int n_split;                          // bottom row tiles cut into two half units (tri == 2, batch 1 only)
     double alpha;
 };

@@ -39,7 +39,6 @@ __global__ void __launch_bounds__(256, BK * sizeof(T) >= 128 ? 2 : 3) k_xty(XtyA
         ti = a.tri == 2 ? a.tiles_i - 1 - a.n_split - t / a.tiles_j : a.n_split + t / a.tiles_j;
         tj = t % a.tiles_j;
     }
-    ti += a.ti_first;
     const int I0 = ti * TM, J0 = tj * TM;
     // rows of this batch element that exist (the last pair of a level may be cut by m_pad)
     const int Mb = min(a.M, a.m_lim - (a.row0_first + b * a.row0_stride));
@@ -57,7 +56,7 @@ __global__ void __launch_bounds__(256, BK * sizeof(T) >= 128 ? 2 : 3) k_xty(XtyA
     for (int r = 0; r < M::NACC; ++r) c00[r] = c01[r] = c10[r] = c11[r] = (T)0;
 
     // k-range: tri 1: Y[k][j] = 0 for k < j ; tri 2: X[k][i] = 0 for k > i
-    const int k_lo = a.tri == 1 ? J0 : a.k_first;
+    const int k_lo = a.tri == 1 ? J0 : 0;
     const int k_hi = a.tri == 2 ? min(a.K, I0 + TM) : a.K;
     const int nk = (k_hi - k_lo) / BK; // K, the tile edges and BK are multiples of 32 (16 for fp32): whole slabs
     using V = typename M::vec_t;
@@ -124,7 +123,6 @@ __global__ void __launch_bounds__(256, BK * sizeof(T) >= 128 ? 2 : 3) k_xty(XtyA
                 const int gi = bi + M::row(r, lane), gj = bj + M::col(lane);
                 if (gi < Mb && gj < a.N) {
                     T v = alpha * cc[r];
-                    if (a.accumulate) v += C[(size_t)gi * a.ldc + gj];
                     if (C) C[(size_t)gi * a.ldc + gj] = v;
                     if (Ct) Ct[(size_t)gj * a.ldct + gi] = (double)v;
                     if (Ctf) Ctf[(size_t)gj * a.ldct + gi] = (float)v;
@@ -138,8 +136,7 @@ void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32, hipStream_t
     (void)e;
     const int grid = batch * (a.tiles_i + a.n_split) * a.tiles_j;
     if (grid <= 0) return;
-    if (f32 && a.deep) k_xty<float, 32><<<grid, 256, 0, stream>>>(a);
-    else if (f32) k_xty<float, 16><<<grid, 256, 0, stream>>>(a);
+    if (f32) k_xty<float, 16><<<grid, 256, 0, stream>>>(a);
     else k_xty<double, 32><<<grid, 256, 0, stream>>>(a);
 }
 

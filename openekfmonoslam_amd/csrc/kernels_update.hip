@@ -702,7 +702,8 @@ k_triinv_level(const double *S, int ldS, int m, int m_pad, double *V, double *W,
 // y = inv(L)' z = W z (W upper triangular, fp64): with it dx = (H P)' y = G' inv(S) nu, the gain applied without going
 // through B.  fp32 configuration only: B = inv(L) G comes out of an fp32 MFMA GEMM (accumulation error ~ sqrt(m) eps per
 // element), G is the fp64-accumulated H P rounded once -- measured at N = 1000: the inverse-depth components were
-// 2e-7 ... 1e-6 off (up to 8e-5 of a small rho) through B' z.  One wavefront per row.
+// 2e-7 ... 1e-6 off (up to 8e-5 of a small rho) through B' z.  Inverse + GEMM path only (W exists there); the sweep path
+// keeps B' z, inside the tolerance block-wise.  One wavefront per row.
 __global__ void __launch_bounds__(256) k_yvec(const double *W, int ldw, int m, const double *z, double *y)
 {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -724,7 +725,7 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int ks = blockIdx.y;
     if (ks == 0 && csave && j < n) {
-        // phase 0 of k_diag_fix: keep the diagonal and the camera rows of P as they are before the downdate
+        // phase 0 of the fp64 fix (k_fix_normalize): keep the diagonal and the camera rows of P as they are before the downdate
         // (avg: the first downdate after an arbitrary upload works on 0.5 (P(a,j) + P(j,a)))
         const bool mine = owns_row(rm, j);
         const T *prow = P + (size_t)local_row(rm, j) * ld;
@@ -763,7 +764,7 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
                     // feature columns with the explicit inverse at hand: dx_j = sum_k (H P)_kj y_k (see k_yvec); camera columns: Bc' z (fp64)
                     if (USE_G && j >= 13) s += (double)gv[u] * y[k0 + u];
                     else s += b * z[k0 + u];
-                    q += b * b; // (B'B)_jj in fp64, same pass over B: see k_diag_fix
+                    q += b * b; // (B'B)_jj in fp64, same pass over B: see k_fix_normalize
                     if (cam_part) {
 #pragma unroll
                         for (int a = 0; a < 13; ++a) c[a] += sc[u][a] * b; // (B'B)_aj, camera rows
@@ -787,34 +788,7 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
 // (k_dx_partial, no extra pass over B) and P_jj = P_jj(old) - (B'B)_jj is rounded to fp32 once.  The 13 camera rows
 // and columns get the same treatment: the camera state -- above all the angular velocity, which is observed only
 // through these cross-covariances -- inherits their error (measured: w block 2e-4 -> see DESIGN.md section 6).
-// The old values are saved by k_dx_partial (its k-split 0) before the downdate; this kernel runs after it.
-template <typename T>
-__global__ void __launch_bounds__(256)
-k_diag_fix(T *P, int ld, int n, RowMap rm, const double *dsave, const double *sq_part, const double *csave,
-           const double *cam_part, int ldpart)
-{
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    const bool mine = owns_row(rm, j);
-    T *prow = P + (size_t)local_row(rm, j) * ld;
-    if (mine && j >= 13) {
-        double q = 0.0;
-#pragma unroll
-        for (int ks = 0; ks < DX_SPLIT; ++ks) q += sq_part[(size_t)ks * ldpart + j];
-        prow[j] = (T)(dsave[j] - q);
-    }
-    // camera rows (replicated on every rank) and, for owned rows, their mirror: one value, written to both places
-#pragma unroll
-    for (int a = 0; a < 13; ++a) {
-        double q = 0.0;
-#pragma unroll
-        for (int ks = 0; ks < DX_SPLIT; ++ks) q += cam_part[((size_t)ks * 13 + a) * ldpart + j];
-        const T v = (T)(csave[(size_t)a * ldpart + j] - q);
-        P[(size_t)a * ld + j] = v;
-        if (mine) prow[a] = v;
-    }
-}
-
+// The old values are saved by k_dx_partial (its k-split 0) before the downdate; k_fix_normalize writes the new ones after it.
 // quaternion normalisation and its Jacobian (Update.cpp:45-62, 303-312), one thread
 __device__ inline void quat_norm_dev(double *st)
 {
@@ -935,7 +909,7 @@ __global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, cons
     }
 }
 
-// k_diag_fix + k_normalize_cov in one launch (fp32 covariance, covariance updates): both own the same elements -- the
+// The fp64 fix and k_normalize_cov in one launch (fp32 covariance, covariance updates): both own the same elements -- the
 // thread of column j writes the fp64-accumulated camera rows of its column (and, for owned rows, their mirror) and then
 // applies the quaternion-normalisation Jacobian to rows / columns 3..6 of it, from the values it has just rounded to T,
 // so nothing is written twice or re-read.  The 13 x 13 camera block needs all of its own values: block 0 assembles it in
@@ -960,7 +934,7 @@ k_fix_normalize(T *P, int ld, int n, RowMap rm, const double *dsave, const doubl
             double q = 0.0;
 #pragma unroll
             for (int ks = 0; ks < DX_SPLIT; ++ks) q += cam_part[((size_t)ks * 13 + a) * ldpart + j];
-            v[a] = (double)(T)(csave[(size_t)a * ldpart + j] - q); // rounded to T once, as k_diag_fix stores it
+            v[a] = (double)(T)(csave[(size_t)a * ldpart + j] - q); // rounded to T once
         }
         if (mine && j >= 13) {
             double q = 0.0;

@@ -77,12 +77,14 @@ def test_empty_map(eng_mod, oracle_lib, seq12):
     assert_state_close(e, o, 1e-12, "empty map")
 
 
+@pytest.mark.parametrize("path", [pytest.param(1, id="sweep"), pytest.param(2, id="gemm")])
 @pytest.mark.parametrize("M", [1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 160])
-def test_update_sizes_across_block_boundaries(eng_mod, oracle_lib, M):
+def test_update_sizes_across_block_boundaries(eng_mod, oracle_lib, M, path):
     """m = 2M rows of S: 2 .. 320, i.e. below / at / above one panel, one fp64 GEMM tile (64), one fp32 tile (128), and
-    the 256 switch of the inverse's doubling levels"""
+    the 256 switch of the inverse's doubling levels; on both ways of forming B = inv(L) H P (ekf_set_update_path)"""
     seq = SyntheticSequence(170, 1, outlier_fraction=0.0, distractors_per_feature=0.0, max_bit_flips=0)
     e, o = make_pair(eng_mod, oracle_lib, seq)
+    e.set_update_path(path)
     e.predict()
     o.predict()
     e.predict_measurements()
@@ -96,8 +98,9 @@ def test_update_sizes_across_block_boundaries(eng_mod, oracle_lib, M):
 
 def test_update_sizes_fp32(eng_mod, oracle_lib):
     seq = SyntheticSequence(170, 1, outlier_fraction=0.0, distractors_per_feature=0.0, max_bit_flips=0)
-    for M in (17, 64, 129, 160):
+    for M, path in ((17, 1), (64, 1), (129, 1), (160, 1), (17, 2), (129, 2), (160, 2)):
         e, o = make_pair(eng_mod, oracle_lib, seq, precision=1)
+        e.set_update_path(path)
         e.predict()
         o.predict()
         e.predict_measurements()
@@ -183,6 +186,9 @@ def test_abi_error_paths(eng_mod, seq12):
     assert ei.value.code == 1
     with pytest.raises(eng_mod.EkfError):          # removing a feature that does not exist
         e.remove_features([40])
+    with pytest.raises(eng_mod.EkfError) as ei:   # an update path that does not exist
+        e.set_update_path(3)
+    assert ei.value.code == 1
     # still healthy: a normal prediction + update on a subset of the keypoints
     kps, desc = seq12.frames[0]
     info = e.step(kps[:16], desc[:16])

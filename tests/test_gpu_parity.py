@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 from parity_metric import F32_TOL, F64_TOL  # 1e-5 (fp32 covariance, the north-star tolerance) / 1e-9 (fp64)
 # The angular-velocity block used to be the exception of the fp32 configuration (up to 3e-5 of its own magnitude: it is
 # observed only through cross-covariances).  Since the camera columns of B and the camera rows / diagonal of the downdate
-# are accumulated in fp64 (right-hand sides of k_chol_step, k_dx_partial, k_diag_fix) it meets the same 1e-5 as every other block.
+# are accumulated in fp64 (right-hand sides of k_chol_step, k_dx_partial, k_fix_normalize) it meets the same 1e-5 as every other block.
 F32_TOL_OMEGA = F32_TOL
 
 
