@@ -319,14 +319,119 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         SWEEP_TRACE(1)
         return;
     }
-    if (b < n_stiles) {
+    if (b > 0 && b < n_stiles) {
+        // Super-tile (TI, TJ): the 2 x 2 group of 32 x 32 tiles with block rows 2 TI, 2 TI + 1 and block columns 2 TJ, 2 TJ + 1
+        // of the trailing matrix (lower triangle; block (0, 0) is the look-ahead workgroup's).  One wavefront per tile.
+        // The four panel blocks L_ik = S_ik Linv' the group needs (two on the diagonal) are formed once, one per
+        // wavefront, and overwrite S_ik in LDS: five blocks loaded and four products for four tiles, where one tile per
+        // workgroup loaded four and made two -- with hundreds of tiles in flight that traffic was the early panels' tail.
+        typedef double acc4 __attribute__((ext_vector_type(4)));
+        const int sidx = b - 1;
+        int TI = (int)((sqrt(8.0 * sidx + 1.0) - 1.0) * 0.5);
+        while ((TI + 1) * (TI + 2) / 2 <= sidx) ++TI;
+        while (TI * (TI + 1) / 2 > sidx) --TI;
+        const int TJ = sidx - TI * (TI + 1) / 2;
+        const bool diag = TI == TJ;
+        const int lane = tid & 63, wv = tid >> 6;
+        const int lr = lane & 15, lk = lane >> 4;
+        const int qi = wv >> 1, qj = wv & 1; // this wavefront's tile of the group
+        const int i0 = k1 + (2 * TI + qi) * NB, j0 = k1 + (2 * TJ + qj) * NB;
+        const bool tile_live = i0 < m && j0 <= i0 && !(TI == 0 && TJ == 0 && qi == 0 && qj == 0);
+        double(*sP)[NB][NB + 1] = pool; // [0], [1]: rows 2 TI, 2 TI + 1; [2], [3]: columns 2 TJ, 2 TJ + 1 (off the diagonal)
+        // the tile's own values (accumulator layout of four 16 x 16 blocks), then the panel blocks
+        double v[2][2][4];
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = i0 + 16 * bi + lk + 4 * q, c = j0 + 16 * bj + lr;
+                    v[bi][bj][q] = (tile_live && r < m && c <= r) ? S[(size_t)r * ldS + c] : 0.0;
+                }
+        double gp[4][4];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            const int r0 = k1 + (blk < 2 ? 2 * TI + blk : 2 * TJ + blk - 2) * NB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = tid + q * 256, r = i / NB, c = i % NB;
+                gp[blk][q] = ((blk < 2 || !diag) && r0 + r < m && c < kb) ? S[(size_t)(r0 + r) * ldS + k0 + c] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * 256, r = i / NB, c = i % NB;
+            sLi[r][c] = gv[q];
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+                if (blk < 2 || !diag) sP[blk][r][c] = gp[blk][q];
+        }
+        __syncthreads();
+        // wavefront w: block w of the panel, L = S_blk Linv', written back over S_blk (only this wavefront reads it)
+        if (wv < 2 || !diag) {
+            acc4 c[2][2];
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < 2; ++bj) c[bi][bj] = acc4{0, 0, 0, 0};
+#pragma unroll
+            for (int k4 = 0; k4 < NB; k4 += 4) {
+                const double a0 = sP[wv][lr][k4 + lk], a1 = sP[wv][16 + lr][k4 + lk];
+                const double l0 = sLi[lr][k4 + lk], l1 = sLi[16 + lr][k4 + lk]; // b[k][c] = Linv[c][k]
+                c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, l0, c[0][0], 0, 0, 0);
+                c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, l1, c[0][1], 0, 0, 0);
+                c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, l0, c[1][0], 0, 0, 0);
+                c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, l1, c[1][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sP[wv][16 * bi + lk + 4 * q][16 * bj + lr] = c[bi][bj][q];
+        }
+        __syncthreads();
+        if (tile_live) {
+            const double(*Li)[NB + 1] = sP[qi];
+            const double(*Lj)[NB + 1] = sP[diag ? qj : 2 + qj];
+            acc4 c[2][2];
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < 2; ++bj) c[bi][bj] = acc4{0, 0, 0, 0};
+#pragma unroll
+            for (int k4 = 0; k4 < NB; k4 += 4) {
+                const double a0 = Li[lr][k4 + lk], a1 = Li[16 + lr][k4 + lk];
+                const double b0 = Lj[lr][k4 + lk], b1 = Lj[16 + lr][k4 + lk];
+                c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c[0][0], 0, 0, 0);
+                c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c[0][1], 0, 0, 0);
+                c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c[1][0], 0, 0, 0);
+                c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c[1][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = i0 + 16 * bi + lk + 4 * q, cc = j0 + 16 * bj + lr;
+                        if (r < m && cc <= r) S[(size_t)r * ldS + cc] = v[bi][bj][q] - c[bi][bj][q];
+                    }
+        }
+        // L_ik leaves the groups of the first group column (see store_l_block), the look-ahead workgroup's block with it
+        if (TJ == 0) {
+            store_l_block(LL, LLf, W != nullptr, ldS, m_pad, k1 + 2 * TI * NB, k0, kb, sP[0]);
+            store_l_block(LL, LLf, W != nullptr, ldS, m_pad, k1 + (2 * TI + 1) * NB, k0, kb, sP[1]);
+        }
+        SWEEP_TRACE(2)
+        return;
+    }
+    if (b < n_stiles) { // b == 0: the look-ahead workgroup, tile (0, 0) of the trailing matrix
         double(*sLI)[NB + 1] = pool[2];
         double(*sLJ)[NB + 1] = pool[3];
-        int ti = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
-        while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
-        while (ti * (ti + 1) / 2 > b) --ti;
-        const int tj = b - ti * (ti + 1) / 2;
-        const int i0 = k1 + ti * NB, j0 = k1 + tj * NB;
+        const int ti = 0, tj = 0;
+        const int i0 = k1, j0 = k1;
         // Each wavefront owns one 16x16 block (bi, bj) of the 32x32 tile; the three 32^3 products run on the fp64 MFMA
         // (v_mfma_f64_16x16x4: lane l feeds a[l % 16][l / 16] and b[l / 16][l % 16], holds rows (l >> 4) + 4 v of column
         // l & 15) -- as plain FMA loops they were LDS-bound and cost 4 of the 19 us of this launch's critical path.
@@ -386,7 +491,6 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
             for (int q = 0; q < 4; ++q)
                 if (live[q]) {
                     v[q] -= cu[q];
-                    if (b != 0) S[(size_t)(i0 + 16 * bi + lk + 4 * q) * ldS + j0 + 16 * bj + lr] = v[q];
                 }
         }
         if (b == 0) {
@@ -405,10 +509,9 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         }
         // L_ik leaves the tiles of the first tile column: mirrored (L' above the diagonal blocks; zero rows m..m_pad) for
         // the rows of B -- in fp32 when the covariance is --, and with W set (inverse + GEMM path) also row-major and in
-        // fp64 for the inverse's levels.  The look-ahead workgroup's own block is stored by tile (1, 0), which holds the
-        // same block as L_jk, when that tile exists: the look-ahead workgroup is the one the launch waits for.
-        if (tj == 0 && (b != 0 || n_stiles == 1)) store_l_block(LL, LLf, W != nullptr, ldS, m_pad, i0, k0, kb, sLI);
-        if (b == 1) store_l_block(LL, LLf, W != nullptr, ldS, m_pad, j0, k0, kb, sLJ);
+        // fp64 for the inverse's levels.  The look-ahead workgroup's own block is stored by the first group of tiles, which
+        // holds the same block, when there is one: the look-ahead workgroup is the one the launch waits for.
+        if (n_stiles == 1) store_l_block(LL, LLf, W != nullptr, ldS, m_pad, i0, k0, kb, sLI);
         SWEEP_TRACE(2)
         return;
     }
@@ -1029,7 +1132,8 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const int kb = min(NB, m - k0);
         const int k1 = k0 + kb;
         const int nrb = (m - k1 + NB - 1) / NB; // row blocks below the panel
-        const int n_stiles = nrb * (nrb + 1) / 2;
+        const int nsr = (nrb + 1) / 2;          // 2 x 2 groups of tiles per side
+        const int n_stiles = nrb == 0 ? 0 : 1 + (nrb >= 2 ? nsr * (nsr + 1) / 2 : 0); // look-ahead tile + groups
         const int n_rhs_blocks = max(1, (m - k1 + 63) / 64); // right-hand-side blocks, 64 rows each
         const int n_wgs = n_stiles + n_rhs_blocks + n_bblocks;
         unsigned long long *tr = nullptr;
