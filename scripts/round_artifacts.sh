@@ -2,12 +2,14 @@
 # Everything profiles/ holds for a round, from the repo root on the GPU box: scripts/round_artifacts.sh <outdir>
 out=$(realpath -m "$1"); root=$(pwd); mkdir -p "$out"
 python -m pytest tests -m gpu -q > "$out/pytest_gpu.log" 2>&1
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$out/smoke.log" 2>&1
 python bench.py > "$out/bench_n1000_f32.json" 2> "$out/bench_n1000_f32.err"
 python bench.py --workload n200_f64 --steps 60 --warmup 10 > "$out/bench_n200_f64.json" 2> /dev/null
 python bench.py --workload n1000_f64 --steps 20 --warmup 5 > "$out/bench_n1000_f64.json" 2> /dev/null
 python bench.py --workload n2000_f32 --steps 20 --warmup 5 > "$out/bench_n2000_f32.json" 2> /dev/null
 python bench.py --workload n5000_f32 --steps 3 --warmup 1 > "$out/bench_n5000_f32.json" 2> /dev/null
 python scripts/sweep_trace.py 1000 15 > "$out/sweep_trace_n1000_f32.txt" 2>&1
+python scripts/sweep_trace.py 2000 8 > "$out/sweep_trace_n2000_f32.txt" 2>&1
 bash scripts/profile_all.sh "$out/prof"
 for w in n1000_f32 n200_f64 n2000_f32 n5000_f32; do
   db=$(find "$out/prof/$w" -name "*.db" | head -1)
