@@ -221,10 +221,7 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         const int i = tid + q * 256;
         gv[q] = V[(size_t)(k0 + i / NB) * ldw + k0 + i % NB];
     }
-    if (b >= n_stiles) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sLi[(tid + q * 256) / NB][(tid + q * 256) % NB] = gv[q];
-    }
+    // (gv lands in sLi inside each role, after the role's own loads have been requested: one round trip, not two)
     if (bcol >= 0) {
         // Row block k of B = inv(L) G, columns 32 bcol ..: B_k = inv(L_kk) (G_k - sum_{j<k} L_kj B_j) -- every operand
         // is final when this launch starts (L_kj: stored by the panels before, B_j: by their launches), so the forward
@@ -241,6 +238,11 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         const int c0 = bcol * NB;
         const int kp = k0 / NB; // panels before this one
         const T *Lt = sizeof(T) == 4 ? (const T *)LLf : (const T *)LL; // L' above the diagonal blocks, in T
+        // this thread's four elements of G_k, requested first: they are cold and only needed at the end
+        const int r = tid >> 3, cg = (tid & 7) * 4;
+        T g4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g4[e] = G[(size_t)(k0 + r) * ld + c0 + cg + e];
         typename M::acc_t acc[NBLK][NBLK];
 #pragma unroll
         for (int bi = 0; bi < NBLK; ++bi)
@@ -281,6 +283,8 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         }
 #undef CB_LOAD
 #undef CB_MMA
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sLi[(tid + q * 256) / NB][(tid + q * 256) % NB] = gv[q];
         // partial sums: wavefronts 2, 3 through LDS to wavefronts 0, 1, whose sums meet in red[0..1]
         if (wv >= 2) {
 #pragma unroll
@@ -299,10 +303,6 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
 #pragma unroll
                     for (int r = 0; r < M::NACC; ++r) red[wv][MB * bi + M::row(r, lane)][MB * bj + M::col(lane)] += acc[bi][bj][r];
         }
-        const int r = tid >> 3, cg = (tid & 7) * 4;
-        T g4[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) g4[e] = G[(size_t)(k0 + r) * ld + c0 + cg + e];
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -556,6 +556,8 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         old[q] = 0.0;
         if (i < m && c < nrhs) old[q] = c == 0 ? nu[i] : Gc[(size_t)i * 16 + c - 1];
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sLi[(tid + q * 256) / NB][(tid + q * 256) % NB] = gv[q];
 #pragma unroll
     for (int q = 0; q < 2; ++q) sR[(tid + q * 256) / NRP][(tid + q * 256) % NRP] = rv[q];
     __syncthreads();
