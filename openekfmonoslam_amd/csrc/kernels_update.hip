@@ -66,6 +66,18 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
     }
 }
 
+// sum over the four lanes of a quad, in every lane: two DPP quad permutes (lane ^ 1, lane ^ 2) -- register moves, where
+// __shfl_xor goes through the LDS crossbar (ds_bpermute: the 28 dependent pairs of the right-hand-side role cost 4 us)
+__device__ __forceinline__ double quad_sum(double x)
+{
+    double y = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(x), 0xB1, 0xF, 0xF, true),
+                                __builtin_amdgcn_mov_dpp(__double2loint(x), 0xB1, 0xF, 0xF, true)); // quad_perm [1,0,3,2]
+    x += y;
+    y = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(x), 0x4E, 0xF, 0xF, true),
+                         __builtin_amdgcn_mov_dpp(__double2loint(x), 0x4E, 0xF, 0xF, true)); // quad_perm [2,3,0,1]
+    return x + y;
+}
+
 // one 32 x kb block of L (rows i0.., columns k0..) from LDS to LL / LLf, see k_chol_step
 __device__ __forceinline__ void store_l_block(double *LL, float *LLf, bool full, int ldS, int m_pad, int i0, int k0, int kb,
                                               const double (*sL)[NB + 1])
@@ -604,10 +616,7 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         }
 #pragma unroll
         for (int c = 0; c < NR; ++c)
-            if (c == 0 || Gc) {
-                acc[c] += __shfl_xor(acc[c], 1, 64);
-                acc[c] += __shfl_xor(acc[c], 2, 64);
-            }
+            if (c == 0 || Gc) acc[c] = quad_sum(acc[c]);
         if (i < m) {
 #pragma unroll
             for (int c = 0; c < NR; ++c) {
