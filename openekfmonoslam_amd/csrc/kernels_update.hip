@@ -321,8 +321,9 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
             sR[r][cg + e] = (double)g4[e] - ((double)red[0][r][cg + e] + (double)red[1][r][cg + e]);
         __syncthreads();
         double o[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int q = 0; q <= r; ++q) {
-            const double l = sLi[r][q];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) { // inv(L_kk) is stored with its zeros above the diagonal: a fixed trip count, so the
+            const double l = sLi[r][q]; // LDS reads are all in flight together
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += l * sR[q][cg + e];
         }
@@ -608,15 +609,22 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         double acc[NR];
 #pragma unroll
         for (int c = 0; c < NR; ++c) acc[c] = 0.0;
+        if (Gc) { // one branch around branch-free loops: with the test inside, every LDS read waited for the one before it
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 8; ++q) {
+                double wrow[NR];
 #pragma unroll
-            for (int c = 0; c < NR; ++c)
-                if (c == 0 || Gc) acc[c] += sv[q] * sW[8 * part + q][c];
+                for (int c = 0; c < NR; ++c) wrow[c] = sW[8 * part + q][c];
+#pragma unroll
+                for (int c = 0; c < NR; ++c) acc[c] += sv[q] * wrow[c];
+            }
+#pragma unroll
+            for (int c = 0; c < NR; ++c) acc[c] = quad_sum(acc[c]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[0] += sv[q] * sW[8 * part + q][0];
+            acc[0] = quad_sum(acc[0]);
         }
-#pragma unroll
-        for (int c = 0; c < NR; ++c)
-            if (c == 0 || Gc) acc[c] = quad_sum(acc[c]);
         if (i < m) {
 #pragma unroll
             for (int c = 0; c < NR; ++c) {
