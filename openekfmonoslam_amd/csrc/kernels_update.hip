@@ -132,10 +132,11 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
                 s0 += v * hs[k];
                 s1 += v * hs[7 + k];
             }
-            for (int k = 0; k < d; ++k) {
-                const double v = (double)ar[pos + k];
-                s0 += v * hf[k];
-                s1 += v * hf[6 + k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { // fixed trip count (d = 3 or 6): the six loads are requested together
+                const double v = (double)ar[pos + min(k, d - 1)];
+                s0 += k < d ? v * hf[k] : 0.0;
+                s1 += k < d ? v * hf[6 + k] : 0.0;
             }
             if (a == b) {
                 if (r == 0) s0 += pixel_err;
