@@ -176,6 +176,8 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     hipError_t st;
     if ((st = hipSetDevice(e->device)) != hipSuccess) return fail(st, "hipSetDevice");
     if ((st = hipStreamCreate(&e->stream)) != hipSuccess) return fail(st, "hipStreamCreate");
+    (void)hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, e->device);
+    if (e->n_cus <= 0) e->n_cus = 256;
     if ((st = hipStreamCreate(&e->stream2)) != hipSuccess) return fail(st, "hipStreamCreate");
     if ((st = hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
     if ((st = hipEventCreateWithFlags(&e->ev_prefetch, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");

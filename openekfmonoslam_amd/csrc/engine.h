@@ -170,6 +170,7 @@ struct EkfEngine {
     EkfExchangeFn xchg = nullptr;        // all-gather of per-feature row blocks between the ranks
     void *comm = nullptr;                // ncclComm_t of the in-engine transport (ekf_comm_init), or null
     void *xchg_user = nullptr;
+    int n_cus = 256;           // compute units of the device (launch-shape decisions)
     int b_path = 0;            // ekf_set_update_path: 0 by size (B_SWEEP_MAX), 1 B in the sweep, 2 inverse + GEMM
     bool async_errors = false; // ekf_set_async_errors: no read-back at the end of a step
     bool p_exact_sym = false; // P known to be bitwise symmetric (engine-maintained invariant)

@@ -165,29 +165,29 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 // -------------------------------------------------------------------------------------- blocked Cholesky sweep
 // Right-looking sweep over [ S | nu ], panel width NB = 32, ONE launch per panel (k_chol_step).  The only serial
 // piece is the 32x32 diagonal block: its Cholesky factor and the inverse of that factor.  It is computed by one
-// workgroup with all 256 threads working in LDS (block_chol_inv32_v4 in chol32.h: 4x4 block pivots, rank-4 updates on the fp64 MFMA, one barrier per
-// block column) and -- look-ahead -- inside the launch of the PREVIOUS panel, by the workgroup that owns tile
-// (k+1, k+1): while the other workgroups of that launch update their tiles, this one finishes its tile, factorises
-// it and stores inv(L_{k+1,k+1}) into V / W.  The panel solve L_ik = S_ik inv(L_kk)' is not a launch of its own:
-// every tile workgroup forms the two panel tiles it needs itself.
-// B = inv(L) A is NOT part of the sweep: it is independent per column of A and runs afterwards as one launch
-// (k_xty, kernels_gemm.hip) on the MFMA pipe, against the explicitly inverted factor.
-
-
-
-// One launch per panel k (width NB = 32), Linv_k = inv(L_kk) already in V (look-ahead of the previous launch):
-//   grid.x : [0, n_stiles) lower-triangular 32x32 tiles (i >= j > k) of the trailing matrix, then one block for nu.
-//   tile (i, j): L_ik = S_ik Linv_k' and L_jk = S_jk Linv_k' are formed IN the workgroup (two 32^3 triangular
-//   products from LDS; cheaper than a separate panel launch on the serial path), then S_ij -= L_ik L_jk'.
-//   The tiles of the first tile column (j = k+1) also store L_ik into LL (row-major L below the diagonal blocks and,
-//   mirrored, L' above them: the operands of the inverse's doubling levels).  S itself is only read in column k, so
-//   nothing races.  Tile 0 = block (k+1, k+1): look-ahead factorisation, publishes Linv_{k+1}.
-//   nu block: z_k = Linv_k nu_k, then nu_i -= L_ik z_k = S_ik (Linv_k' z_k) for all rows below.
+// workgroup with all 256 threads working in LDS (block_chol_inv32_v4 in chol32.h: 4x4 block pivots, rank-4 updates on
+// the fp64 MFMA, one barrier per block column) and -- look-ahead -- inside the launch of the PREVIOUS panel, by the
+// workgroup that owns tile (k+1, k+1): while the other workgroups of that launch do their work, this one finishes its
+// tile, factorises it and stores inv(L_{k+1,k+1}) into V.  That workgroup needs ~7.5 us and one CU; everything else a
+// panel has to do is arranged to fit in its shadow on the other 255 (scripts/sweep_trace.py shows when each role ends):
+//
+//   grid.x, one launch per panel k, Linv_k = inv(L_kk) already in V (look-ahead of the previous launch):
+//     [0]                the look-ahead workgroup: tile (k+1, k+1) updated, factorised, its inverse published
+//     [1 .. n_bblocks]   rows of B (m <= B_SWEEP_MAX): B_k = Linv_k (G_k - sum_{j<k} L_kj B_j), one 32x32 block each
+//     [.. + n_rhs]       right-hand sides: z_k = Linv_k nu_k (and the fp64 camera columns Bc_k), then for 64 rows each
+//                        nu_i -= L_ik z_k = S_ik (Linv_k' z_k)
+//     [the rest]         the trailing tiles in 2 x 2 groups: S_ij -= L_ik L_jk' with L_ik = S_ik Linv_k' formed in the
+//                        group (the panel solve is not a launch of its own); the groups of the first group column also
+//                        store L_ik into LL / LLf (mirrored: L' above the diagonal blocks, the A operand of the rows of
+//                        B; on the inverse + GEMM path also row-major, the operands of the inverse's doubling levels)
+//   S itself is only read in column k, B only in rows above k, nu / Gc only in rows k: nothing races inside a launch.
+// Above B_SWEEP_MAX rows B = inv(L) G is not part of the sweep: the factor is inverted explicitly (k_inv_diag,
+// k_triinv_level) and B is one GEMM against it (k_xty, kernels_gemm.hip).
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0, int kb, double *nu, int n_stiles, double *V,
             double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc, const T *G, T *Bout, int ld,
-            int n_bblocks, int n_rhs, unsigned long long *trace, int abl)
+            int n_bblocks, int n_rhs, int tiles_first, unsigned long long *trace, int abl)
 {
     const unsigned long long t_in = trace ? wall_clock64() : 0ull;
 #define SWEEP_TRACE(role)                                                                      \
@@ -205,16 +205,23 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
     double(*sB)[NB + 1] = pool[1];
     const int tid = threadIdx.x;
     const int k1 = k0 + kb;
-    // block order: the look-ahead workgroup, the row block of B (the longest units of a late panel; a column block keeps
-    // its place in the order, hence its XCD and the L2 that holds its rows of B), the right-hand sides, the other tiles
-    // (tiles first in the early panels, where their cold loads are the launch's tail, measured no different)
+    // block order: the look-ahead workgroup first.  A launch that fits one workgroup per CU: then the row block of B (the
+    // longest units of a late panel; a column block keeps its place in the order, hence its XCD and the L2 that holds its
+    // rows of B), the right-hand sides, the tile groups.  A launch with more workgroups than CUs (early panels): the
+    // tile groups before B, so that the workgroup which ends up sharing the look-ahead workgroup's CU is a short B unit
+    // and not a tile group (the look-ahead publishes 1.5 us later beside one: 9.1 against 7.5 us).
     int b = blockIdx.x;
     int bcol = -1;
-    {
+    if (tiles_first) { // [look-ahead][tile groups][right-hand sides][B]: b is already the tile / right-hand-side index
+        if (b >= n_stiles + n_rhs) {
+            bcol = b - n_stiles - n_rhs;
+            b = n_stiles + 1; // not a tile
+        }
+    } else {
         const int f = n_stiles > 0 ? 1 : 0;
         if (b >= f && b < f + n_bblocks) {
             bcol = b - f;
-            b = n_stiles + 1; // not a tile: takes the loads of a right-hand-side block below
+            b = n_stiles + 1; // not a tile
         } else if (b >= f + n_bblocks && b < f + n_bblocks + n_rhs) {
             b = n_stiles + (b - f - n_bblocks);
         } else if (b >= f + n_bblocks + n_rhs) {
@@ -1165,7 +1172,8 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         }
         k_chol_step<T><<<n_wgs, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(T) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles,
                                                                            V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
-                                                                           e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks, tr, tr ? g_trace_abl : 0);
+                                                                           e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks,
+                                             n_wgs > e->n_cus ? 1 : 0, tr, tr ? g_trace_abl : 0);
     }
     // inv(L): the 128 x 128 diagonal chunks in one launch, then by doubling 128 -> 256 -> ... until one block covers all rows
     const bool need_inverse = !b_in_sweep;
