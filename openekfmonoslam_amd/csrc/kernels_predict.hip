@@ -230,7 +230,7 @@ void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool sta
 {
     const bool sub = state_only || d_idx != nullptr;
     if (count <= 0) {
-        hipMemsetAsync(e->d.counts + (sub ? CNT_NPRED_SUB : CNT_NPRED), 0, sizeof(int), e->stream);
+        (void)hipMemsetAsync(e->d.counts + (sub ? CNT_NPRED_SUB : CNT_NPRED), 0, sizeof(int), e->stream);
         return;
     }
     const int nb = (count + 255) / 256;
