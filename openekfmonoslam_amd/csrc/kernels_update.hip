@@ -187,7 +187,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0, int kb, double *nu, int n_stiles, double *V,
             double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc, const T *G, T *Bout, int ld,
-            int n_bblocks, int n_rhs, int tiles_first, unsigned long long *trace, int abl)
+            int n_bblocks, int n_rhs, int tiles_first, int spacer, unsigned long long *trace, int abl)
 {
     const unsigned long long t_in = trace ? wall_clock64() : 0ull;
 #define SWEEP_TRACE(role)                                                                      \
@@ -212,6 +212,12 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
     // and not a tile group (the look-ahead publishes 1.5 us later beside one: 9.1 against 7.5 us).
     int b = blockIdx.x;
     int bcol = -1;
+    if (spacer > 0) {
+        // Workgroups are handed to the CUs in turn, so block `spacer` (= the number of CUs), 2 spacer, ... would land on
+        // the CU of block 0, the look-ahead workgroup, which then publishes 1.5 us later.  Those blocks are empty.
+        if (b > 0 && b % spacer == 0) return;
+        b -= b / spacer;
+    }
     if (tiles_first) { // [look-ahead][tile groups][right-hand sides][B]: b is already the tile / right-hand-side index
         if (b >= n_stiles + n_rhs) {
             bcol = b - n_stiles - n_rhs;
@@ -1170,10 +1176,12 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             tags[g_trace_n - 1] = ((unsigned long long)k0 << 32) | (unsigned long long)m;
             (void)hipMemcpyAsync(tr + 5, &tags[g_trace_n - 1], sizeof(unsigned long long), hipMemcpyHostToDevice, s);
         }
-        k_chol_step<T><<<n_wgs, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(T) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles,
+        const int spacer = n_wgs > e->n_cus ? e->n_cus : 0; // see k_chol_step: empty blocks where the look-ahead workgroup's CU comes round again
+        const int n_spacers = spacer ? (n_wgs - 1) / (spacer - 1) : 0; // blocks spacer, 2 spacer, ... among n_wgs + n_spacers
+        k_chol_step<T><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(T) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles,
                                                                            V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
                                                                            e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks,
-                                             n_wgs > e->n_cus ? 1 : 0, tr, tr ? g_trace_abl : 0);
+                                             n_wgs > e->n_cus ? 1 : 0, spacer, tr, tr ? g_trace_abl : 0);
     }
     // inv(L): the 128 x 128 diagonal chunks in one launch, then by doubling 128 -> 256 -> ... until one block covers all rows
     const bool need_inverse = !b_in_sweep;
