@@ -21,15 +21,18 @@
 
 namespace ekf {
 
+#ifndef PU_LDS_DMA
+#define PU_LDS_DMA 0 // 1: slabs of B by LDS-DMA instead of staging registers (same results; measured, not faster: DESIGN 4.1)
+#endif
 #ifndef PU_MIN_WAVES
-#define PU_MIN_WAVES 3
+#define PU_MIN_WAVES 3 // with PU_LDS_DMA 4 fits (128 VGPRs, 4 x 32 KB LDS): +2.4 % at N = 1000, -3 % at N = 2000 / 5000
 #endif
 // RECT (row-sharded storage): the rank owns row tiles, not a triangle.  Tile row 0 is the replicated
 // camera block (13 live rows), tile row t >= 1 holds the owned global rows rm.r0 + (t-1) TM ..., stored from local
 // row rm.base + (t-1) TM; every (row tile, column tile) pair is computed and written in place, nothing is mirrored.
 // Swapping the operands of an MFMA product changes no bit, so P[i][j] here equals P[j][i] on the rank that owns j.
 template <typename T, bool AVG, bool RECT>
-__global__ void __launch_bounds__(256, PU_MIN_WAVES)
+__global__ void __launch_bounds__(256, sizeof(T) == 4 ? PU_MIN_WAVES : 3)
 k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, const int4 *units, RowMap rm, int stagger)
 {
     using M = Mma<T>;
@@ -85,6 +88,50 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
 #define PU_PIECE(q) const int lk##q = ((tid + q * 256) * VEC) / TM, lc##q = ((tid + q * 256) * VEC) % TM; \
                     const T *gI##q = B + (size_t)lk##q * ldb + I0 + lc##q; const T *gJ##q = B + (size_t)lk##q * ldb + J0 + lc##q; \
                     V rI##q = *(const V *)gI##q, rJ##q = *(const V *)gJ##q;
+#if PU_LDS_DMA
+    // Slabs travel from global memory straight into LDS (global_load_lds_dwordx4: lane l of a wavefront writes 16 bytes at
+    // the wavefront's LDS base + 16 l, which is exactly this kernel's [k][column] image: a wavefront's 64 pieces of a slab
+    // are 1 KB of consecutive LDS).  No staging registers, no ds_write; completion is counted by vmcnt.
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+#define PU_PIECE(q) const int lk##q = ((tid + q * 256) * VEC) / TM, lc##q = ((tid + q * 256) * VEC) % TM; \
+                    const T *gI##q = B + (size_t)lk##q * ldb + I0 + lc##q; const T *gJ##q = B + (size_t)lk##q * ldb + J0 + lc##q;
+    PU_PIECE(0)
+    PU_PIECE(1)
+    PU_PIECE(2)
+    PU_PIECE(3)
+#undef PU_PIECE
+    const int wbase = __builtin_amdgcn_readfirstlane(wv * 64 * VEC); // first element of this wavefront's pieces in a slab image
+#define PU_DMA(q, off, b)                                                                                               \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gI##q + (off)), (lptr_t)(&sI[b][0][0] + wbase + q * 256 * VEC), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gJ##q + (off)), (lptr_t)(&sJ[b][0][0] + wbase + q * 256 * VEC), 16, 0, 0);
+    PU_DMA(0, (size_t)0, 0)
+    PU_DMA(1, (size_t)0, 0)
+    if (LOADS == 4) {
+        PU_DMA(2, (size_t)0, 0)
+        PU_DMA(3, (size_t)0, 0)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) { // the next slab lands in the other buffer while this one is consumed (every wavefront left it at the barrier)
+            const size_t off = (size_t)(kt + 1) * slab;
+            PU_DMA(0, off, buf ^ 1)
+            PU_DMA(1, off, buf ^ 1)
+            if (LOADS == 4) {
+                PU_DMA(2, off, buf ^ 1)
+                PU_DMA(3, off, buf ^ 1)
+            }
+        }
+        if (full) pu_slab<T, true, TM>(sI[buf], sJ[buf], klane, rbase + idx, wc * 2 * MB + idx, c00, c01, c10, c11);
+        else pu_slab<T, false, TM>(sI[buf], sJ[buf], klane, rbase + idx, wc * 2 * MB + idx, c00, c01, c10, c11);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef PU_DMA
+#else
     PU_PIECE(0)
     PU_PIECE(1)
     PU_PIECE(2)
@@ -125,6 +172,7 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
     }
 #undef PU_STORE
 #undef PU_LOAD
+#endif
 
     // epilogue.  P is bitwise symmetric on entry (engine invariant) unless AVG.
     //  - diagonal tiles: every element (i, j) of the tile is computed (acc is bitwise symmetric), written in place;
