@@ -13,7 +13,7 @@
 //     consecutive banks).
 //   * workgroup = 256 threads = 2 x 2 wavefronts, each wavefront owns 2 x 2 MFMA blocks (fp32: 64 x 64 outputs,
 //     64 accumulator VGPRs), workgroup tile TM x TM with TM = 4 MB (fp32 128, fp64 64), k-slab BK = 16,
-//     register-staged double buffering through LDS (32 KB).
+//     double buffering through LDS (32 KB): fp32 register-staged, fp64 by LDS-DMA (PU_LDS_DMA / PU_LDS_DMA_F64).
 //   * only tiles with I <= J are launched; the epilogue subtracts from P, writes the tile and its mirror image,
 //     so P stays bitwise symmetric.
 #include "engine.h"
@@ -23,6 +23,9 @@ namespace ekf {
 
 #ifndef PU_LDS_DMA
 #define PU_LDS_DMA 0 // 1: slabs of B by LDS-DMA instead of staging registers (same results; measured, not faster: DESIGN 4.1)
+#endif
+#ifndef PU_LDS_DMA_F64
+#define PU_LDS_DMA_F64 1 // the fp64 instance needs 86 VGPRs either way; without the staging stores it is 2 % faster at N = 1000
 #endif
 #ifndef PU_MIN_WAVES
 #define PU_MIN_WAVES 3 // with PU_LDS_DMA 4 fits (128 VGPRs, 4 x 32 KB LDS): +2.4 % at N = 1000, -3 % at N = 2000 / 5000
@@ -88,19 +91,19 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
 #define PU_PIECE(q) const int lk##q = ((tid + q * 256) * VEC) / TM, lc##q = ((tid + q * 256) * VEC) % TM; \
                     const T *gI##q = B + (size_t)lk##q * ldb + I0 + lc##q; const T *gJ##q = B + (size_t)lk##q * ldb + J0 + lc##q; \
                     V rI##q = *(const V *)gI##q, rJ##q = *(const V *)gJ##q;
-#if PU_LDS_DMA
+    if constexpr (PU_LDS_DMA || (PU_LDS_DMA_F64 && sizeof(T) == 8)) {
     // Slabs travel from global memory straight into LDS (global_load_lds_dwordx4: lane l of a wavefront writes 16 bytes at
     // the wavefront's LDS base + 16 l, which is exactly this kernel's [k][column] image: a wavefront's 64 pieces of a slab
     // are 1 KB of consecutive LDS).  No staging registers, no ds_write; completion is counted by vmcnt.
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
-#define PU_PIECE(q) const int lk##q = ((tid + q * 256) * VEC) / TM, lc##q = ((tid + q * 256) * VEC) % TM; \
+#define PU_PIECE_DMA(q) const int lk##q = ((tid + q * 256) * VEC) / TM, lc##q = ((tid + q * 256) * VEC) % TM; \
                     const T *gI##q = B + (size_t)lk##q * ldb + I0 + lc##q; const T *gJ##q = B + (size_t)lk##q * ldb + J0 + lc##q;
-    PU_PIECE(0)
-    PU_PIECE(1)
-    PU_PIECE(2)
-    PU_PIECE(3)
-#undef PU_PIECE
+    PU_PIECE_DMA(0)
+    PU_PIECE_DMA(1)
+    PU_PIECE_DMA(2)
+    PU_PIECE_DMA(3)
+#undef PU_PIECE_DMA
     const int wbase = __builtin_amdgcn_readfirstlane(wv * 64 * VEC); // first element of this wavefront's pieces in a slab image
 #define PU_DMA(q, off, b)                                                                                               \
     __builtin_amdgcn_global_load_lds((gptr_t)(gI##q + (off)), (lptr_t)(&sI[b][0][0] + wbase + q * 256 * VEC), 16, 0, 0); \
@@ -131,7 +134,7 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
         __syncthreads();
     }
 #undef PU_DMA
-#else
+    } else {
     PU_PIECE(0)
     PU_PIECE(1)
     PU_PIECE(2)
@@ -172,7 +175,7 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
     }
 #undef PU_STORE
 #undef PU_LOAD
-#endif
+    }
 
     // epilogue.  P is bitwise symmetric on entry (engine invariant) unless AVG.
     //  - diagonal tiles: every element (i, j) of the tile is computed (acc is bitwise symmetric), written in place;
