@@ -836,6 +836,9 @@ static int wait_counts(EkfEngine *e, int seq)
             return EKF_OK;
         }
         if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(e->stream) == hipSuccess && m[CNT_COUNT] != seq) break;
+#if defined(__x86_64__)
+        __builtin_ia32_pause(); // the caller's thread polls one cache line; leave the core's other thread its issue slots
+#endif
     }
     return read_counts(e); // the stream drained without the write (or the poll gave up): the plain path
 }
