@@ -263,12 +263,43 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
     const int pos = feat_covpos[fi];
     // updateMapFeatures' timesPredicted++ (MapManagement.cpp:81-86) rides along when a step asks for it (every rank counts
     // every feature: the map is replicated)
-    if (times_predicted && tid == 0) times_predicted[fi]++;
+    // blockIdx.y: the chunk of 256 x 16 bytes of the row pair this workgroup produces (one round of loads per workgroup:
+    // a feature's 7 + d rows are 13 x n x w bytes, and one workgroup walking all of them was six dependent rounds -- the
+    // outlier re-prediction, with fewer features than CUs, ran at a third of the bandwidth of the full pass)
+    const bool first = blockIdx.y == 0;
+    if (times_predicted && tid == 0 && first) times_predicted[fi]++;
     if (!owns_row(rm, pos)) return; // sharded: the owner of the feature's rows computes them, the exchange delivers them
     const T *Pf = P + (size_t)local_row(rm, pos) * ld;
     if (tid < 14) sH[tid] = Hs_tab[14 * fi + tid];
     else if (tid < 26) sH[tid] = Hf_tab[12 * fi + tid - 14];
+    // chunk 0 also forms the 2 x 2 S_f: the fp64 H P at the 7 camera columns and at the feature's own d columns, one
+    // thread per column (same operations in the same order as the row pair's elements below)
+    double pcol[13];
+    int jcol = -1;
+    if (first && tid >= 64 && tid < 64 + 7 + d) {
+        jcol = tid - 64 < 7 ? tid - 64 : pos + (tid - 64 - 7);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) pcol[a] = a < d ? (double)Pf[(size_t)a * ld + jcol] : 0.0;
+#pragma unroll
+        for (int a = 0; a < 7; ++a) pcol[6 + a] = (double)P[(size_t)a * ld + jcol];
+    }
     __syncthreads();
+    if (jcol >= 0) {
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+            if (a < d) {
+                a0 += sH[14 + a] * pcol[a];
+                a1 += sH[20 + a] * pcol[a];
+            }
+#pragma unroll
+        for (int a = 0; a < 7; ++a) {
+            b0 += sH[a] * pcol[6 + a];
+            b1 += sH[7 + a] * pcol[6 + a];
+        }
+        sHP[0][tid - 64] = a0 + b0;
+        sHP[1][tid - 64] = a1 + b1;
+    }
     T *o0 = HP + (size_t)(2 * fi) * ld;
     T *o1 = o0 + ld;
     // 16 bytes per lane and row: a wavefront reads 1 KB (fp32) / 1 KB (fp64, two columns) of CONTIGUOUS row per load
@@ -276,7 +307,8 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
     // reading up to the padded row end is in bounds; columns >= n are never stored)
     constexpr int VW = 16 / sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(VW)));
-    for (int jb = tid * VW; jb < n; jb += 256 * VW) {
+    const int jb = ((int)blockIdx.y * 256 + tid) * VW;
+    if (jb < n) {
         vec_t pf[6], pc[7];
 #pragma unroll
         for (int a = 0; a < 6; ++a)
@@ -310,13 +342,6 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
                 HPc[(size_t)(2 * fi) * 16 + j] = a0;
                 HPc[(size_t)(2 * fi + 1) * 16 + j] = a1;
             }
-            if (j < 7) {
-                sHP[0][j] = a0;
-                sHP[1][j] = a1;
-            } else if (j >= pos && j < pos + d) {
-                sHP[0][7 + j - pos] = a0;
-                sHP[1][7 + j - pos] = a1;
-            }
         }
         if (jb + VW <= n) {
             *(vec_t *)(o0 + jb) = r0;
@@ -327,6 +352,7 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
                 if (jb + v < n) { o0[jb + v] = r0[v]; o1[jb + v] = r1[v]; }
         }
     }
+    if (!first) return;
     __syncthreads();
     if (tid < 4) {
         const int r = tid >> 1, c = tid & 1;
@@ -341,12 +367,13 @@ void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_pred
 {
     unsigned *tp = count_predicted ? e->d.feat_times_predicted : nullptr;
     if (n_list <= 0) return;
+    const int chunks_f = (e->n + 256 * 4 - 1) / (256 * 4), chunks_d = (e->n + 256 * 2 - 1) / (256 * 2);
     if (e->f32)
-        k_hp_rows<float><<<n_list, 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
+        k_hp_rows<float><<<dim3(n_list, chunks_f), 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
                                                         e->d.feat_covpos, e->d.Hs, e->d.Hf, (float *)e->d.HP,
                                                         e->d.pred_S, e->rm, e->d.HPc, tp, d_count);
     else
-        k_hp_rows<double><<<n_list, 256, 0, e->stream>>>((const double *)e->d.P, e->ldP, e->n, d_list,
+        k_hp_rows<double><<<dim3(n_list, chunks_d), 256, 0, e->stream>>>((const double *)e->d.P, e->ldP, e->n, d_list,
                                                          e->d.feat_type, e->d.feat_covpos, e->d.Hs, e->d.Hf,
                                                          (double *)e->d.HP, e->d.pred_S, e->rm, e->d.HPc, tp, d_count);
 }

@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/r2z
 (
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge_cases.py tests/test_gpu_sharded.py -q -x 2>&1 | grep -E "passed|failed|Error" | head -5
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge_cases.py tests/test_gpu_sharded.py tests/test_gpu_map_management.py -q -x 2>&1 | grep -E "passed|failed|Error" | head -5
 for i in 1 2 3; do
   python bench.py --steps 40 --warmup 10 --no-all-matched --no-single-gpu-reference --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
@@ -12,7 +12,5 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n200', round(d['
 python bench.py --workload n2000_f32 --steps 10 --warmup 5 --no-all-matched --no-single-gpu-reference --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('n2000', round(d['value'],1), {k:round(v,3) for k,v in d['stage_ms_per_step'].items()})"
-python scripts/sweep_trace.py 1000 15 2>&1 | sed -n 3,12p
-python scripts/sweep_trace.py 2000 8 2>&1 | sed -n 3,12p
 ) > gpurun_out/r2z/q.log 2>&1
 cat gpurun_out/r2z/q.log
