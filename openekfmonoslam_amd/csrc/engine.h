@@ -223,6 +223,32 @@ struct XtyArgs {
 };
 void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32, hipStream_t stream);
 
+// Exclusive prefix sum of one int per thread over a 1024-thread workgroup (and the total): inside a wavefront by shuffles,
+// across the 16 wavefronts through LDS -- one barrier, where a Hillis-Steele scan in LDS needs twenty.  Device code only.
+#ifdef __HIPCC__
+__device__ __forceinline__ int block_exclusive_scan_1024(int c, int *wtot /* __shared__ int[16] */, int *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int x = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wtot[wv] = x;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int t = wtot[w];
+        base += w < wv ? t : 0;
+        tot += t;
+    }
+    *total = tot;
+    return base + x - c;
+}
+#endif
+
 // ---- launchers (kernels_*.hip) ; T selected by e->f32 ----------------------------------------------------
 void launch_predict(EkfEngine *e);
 // full (idx == nullptr) or subset prediction; fills tables, compacted list and CNT_NPRED / CNT_NPRED_SUB

@@ -108,21 +108,14 @@ k_match_compact(const int *plist, int n_pred, const int *mt_valid, const int *mt
                 const EkfKeypoint *kps, int by_slot, EkfMatch *out, int *out_count, const int *d_npred)
 {
     if (d_npred) n_pred = *d_npred;
-    __shared__ int part[1024];
+    __shared__ int wtot[16];
     const int tid = threadIdx.x;
     const int per = (n_pred + 1023) / 1024;
     const int b = tid * per, e = min(n_pred, b + per);
     int c = 0;
     for (int i = b; i < e; ++i) c += mt_valid[i];
-    part[tid] = c;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        int v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int pos = part[tid] - c;
+    int total;
+    int pos = block_exclusive_scan_1024(c, wtot, &total);
     for (int i = b; i < e; ++i)
         if (mt_valid[i]) {
             EkfMatch m;
@@ -136,7 +129,7 @@ k_match_compact(const int *plist, int n_pred, const int *mt_valid, const int *mt
             m._pad = 0.f;
             out[pos++] = m;
         }
-    if (tid == 1023) *out_count = part[1023];
+    if (tid == 1023) *out_count = total;
 }
 
 void launch_match(EkfEngine *e, int n_pred, int n_kp, const int *d_npred)
@@ -189,21 +182,14 @@ k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, Ek
             uint8_t *feat_desc, unsigned *times_matched, int desc_bytes, int *idx0, const int *counts, int *mirror,
             int publish_seq)
 {
-    __shared__ int part[1024];
+    __shared__ int wtot[16];
     const int tid = threadIdx.x;
     const int per = (M + 1023) / 1024;
     const int b = tid * per, e = min(M, b + per);
     int c = 0;
     for (int i = b; i < e; ++i) c += flags[i] ? 1 : 0;
-    part[tid] = c;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        int v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int p1 = part[tid] - c;
+    int total;
+    int p1 = block_exclusive_scan_1024(c, wtot, &total);
     int p0 = b - p1;
     for (int i = b; i < e; ++i) {
         if (flags[i]) dst1[p1++] = src[i];
@@ -212,13 +198,13 @@ k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, Ek
             dst0[p0++] = src[i];
         }
     }
-    if (tid == 1023 && cnt1) *cnt1 = part[1023];
+    if (tid == 1023 && cnt1) *cnt1 = total;
     if (publish_seq > 0) publish_counts_block(counts, mirror, publish_seq); // the count above is part of the block
     if (!times_matched) return;
     // updateMapFeatures for the selected matches (MapManagement.cpp:88-113), fused: timesMatched++ and the map descriptor
     // replaced by the matched keypoint's (matcher mode B has no keypoint: keypointIndex < 0)
     __syncthreads();
-    const int count = part[1023];
+    const int count = total;
     for (int i = tid; i < count; i += 1024) {
         const int fi = dst1[i].featureIndex, kp = dst1[i].keypointIndex;
         atomicAdd(&times_matched[fi], 1u); // one match per feature on every engine path; atomic all the same

@@ -204,24 +204,17 @@ k_predict_features(const double *st, CamD cam, const double *feat_pos, const int
 // work item (input order, as the reference's push_back order), *out_count = how many.
 __global__ void __launch_bounds__(1024) k_compact(const int *flag, const int *idx, int count, int *list, int *out_count)
 {
-    __shared__ int part[1024];
+    __shared__ int wtot[16];
     const int tid = threadIdx.x;
     const int per = (count + 1023) / 1024;
     const int b = tid * per, e = min(count, b + per);
     int c = 0;
     for (int i = b; i < e; ++i) c += flag[i] ? 1 : 0;
-    part[tid] = c;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) { // Hillis-Steele inclusive scan
-        int v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int pos = part[tid] - c;
+    int total;
+    int pos = block_exclusive_scan_1024(c, wtot, &total);
     for (int i = b; i < e; ++i)
         if (flag[i]) list[pos++] = idx ? idx[i] : i;
-    if (tid == 1023) *out_count = part[1023];
+    if (tid == 1023) *out_count = total;
 }
 
 // state_only: pixel predictions into the scratch tables (vis2/uv2, list plist_sub, counter CNT_NPRED_SUB) so the
