@@ -12,15 +12,17 @@
 
 namespace ekf {
 
+constexpr int HYP_THREADS = 512;  // threads of a hypothesis' workgroup
+
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(HYP_THREADS)
 k_ransac_hyp(const double *st, CamD cam, double thr, const double *feat_pos, const int *feat_type,
              const int *feat_covpos, int N, const T *HP, int ld, const double *uv_tab, const double *S_tab,
              const EkfMatch *matches, int M, const int *match_of_feat, int h0, int *hyp_count, uint8_t *hyp_flags,
              int mcap, const int *d_M)
 {
     __shared__ double sx[13], sRt[9], sRinv[9], sw[2];
-    __shared__ int s_cnt[4];
+    __shared__ int s_cnt[HYP_THREADS / 64];
     if (d_M) M = *d_M; // the number of matches is only known on the device (step path without read-backs)
     const int h = h0 + blockIdx.x;
     if (h >= M) return;
@@ -57,10 +59,11 @@ k_ransac_hyp(const double *st, CamD cam, double thr, const double *feat_pos, con
     __syncthreads();
     const double w0 = sw[0], w1 = sw[1];
     uint8_t *flags = hyp_flags + (size_t)blockIdx.x * mcap;
-    for (int k = tid; k < M; k += 256) flags[k] = 0; // this hypothesis' support mask (only matched features are written below)
+    const int nthr = blockDim.x; // 256 for small maps, HYP_THREADS otherwise
+    for (int k = tid; k < M; k += nthr) flags[k] = 0; // this hypothesis' support mask (only matched features are written below)
     __syncthreads();
     int cnt = 0;
-    for (int f = tid; f < N; f += 256) {
+    for (int f = tid; f < N; f += nthr) { // the loop body is a chain of dependent loads: few iterations per thread (1024 threads would spill)
         const int mi = match_of_feat[f];
         if (mi >= M) continue; // features without a match cannot add support (1PointRansac.cpp:60-82)
         const int type = feat_type[f], pos = feat_covpos[f], d = feat_dim(type);
@@ -83,7 +86,11 @@ k_ransac_hyp(const double *st, CamD cam, double thr, const double *feat_pos, con
     cnt = wave_sum_i(cnt);
     if ((tid & 63) == 0) s_cnt[tid >> 6] = cnt;
     __syncthreads();
-    if (tid == 0) hyp_count[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < nthr / 64; ++w) tot += s_cnt[w];
+        hyp_count[blockIdx.x] = tot;
+    }
 }
 
 // Sequential bookkeeping of the hypothesis loop (1PointRansac.cpp:125,164-178) over one batch.
@@ -154,13 +161,13 @@ void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M,
     const int nb = batch; // hyp_flags rows are zeroed by their workgroups, hyp_count[b] is only read for launched hypotheses
     const double thr = e->cfg.par.ransacThresholdPredictDistance;
     if (e->f32)
-        k_ransac_hyp<float><<<nb, 256, 0, e->stream>>>(e->d.state, e->cam, thr, e->d.feat_pos, e->d.feat_type,
+        k_ransac_hyp<float><<<nb, e->N > 256 ? HYP_THREADS : 256, 0, e->stream>>>(e->d.state, e->cam, thr, e->d.feat_pos, e->d.feat_type,
                                                        e->d.feat_covpos, e->N, (const float *)e->d.HP, e->ldP,
                                                        e->d.pred_uv, e->d.pred_S, e->d.matches, M,
                                                        e->d.match_of_feat, h0, e->d.hyp_count, e->d.hyp_flags,
                                                        e->mcap, d_M);
     else
-        k_ransac_hyp<double><<<nb, 256, 0, e->stream>>>(e->d.state, e->cam, thr, e->d.feat_pos, e->d.feat_type,
+        k_ransac_hyp<double><<<nb, e->N > 256 ? HYP_THREADS : 256, 0, e->stream>>>(e->d.state, e->cam, thr, e->d.feat_pos, e->d.feat_type,
                                                         e->d.feat_covpos, e->N, (const double *)e->d.HP, e->ldP,
                                                         e->d.pred_uv, e->d.pred_S, e->d.matches, M,
                                                         e->d.match_of_feat, h0, e->d.hyp_count, e->d.hyp_flags,
