@@ -18,9 +18,10 @@ k_match(const int *plist, const double *uv_tab, const double *S_tab, const uint8
     if (d_npred && (int)blockIdx.x >= *d_npred) return; // grid = upper bound, count on the device
     __shared__ Gate g;
     __shared__ uint32_t qd[1024]; // the map feature's descriptor: 8 words (CV_8U) or up to 1024 floats (CV_32F)
-    __shared__ int c_idx[256];
-    __shared__ double c_dist[256]; // computeDistance returns double (an integer value for Hamming)
-    __shared__ int wave_cnt[4];
+    constexpr int PASS = 8; // keypoints per thread and pass: their loads are in flight together, one barrier pair per pass
+    __shared__ int c_idx[256 * PASS];
+    __shared__ double c_dist[256 * PASS]; // computeDistance returns double (an integer value for Hamming)
+    __shared__ int wave_cnt[PASS][4];
     // list state (thread 0); DMatch::distance is a float (Matching.cpp:133)
     __shared__ int s_list_n, s_front;
     __shared__ float s_dfront, s_dback;
@@ -38,47 +39,64 @@ k_match(const int *plist, const double *uv_tab, const double *S_tab, const uint8
     }
     const int words = desc_bytes / 4;
     for (int w = tid; w < words; w += 256) qd[w] = ((const uint32_t *)(feat_desc + (size_t)fi * desc_bytes))[w];
-    __syncthreads();
-
     const int lane = tid & 63, wv = tid >> 6;
-    for (int base = 0; base < n_kp; base += 256) {
-        const int j = base + tid;
-        bool inside = false;
-        double dist = 0.0;
-        if (j < n_kp) {
-            const double px = (double)kps[j].x, py = (double)kps[j].y;
+    for (int base = 0; base < n_kp; base += 256 * PASS) {
+        // this pass's keypoints, requested before the gate is needed
+        float kx[PASS], ky[PASS];
+#pragma unroll
+        for (int i = 0; i < PASS; ++i) {
+            const int j = min(base + i * 256 + tid, n_kp - 1);
+            kx[i] = kps[j].x;
+            ky[i] = kps[j].y;
+        }
+        __syncthreads(); // the gate and the descriptor (first pass); the candidate buffers are free (later passes)
+        bool inside[PASS];
+        double dist[PASS];
+        int rank[PASS];
+#pragma unroll
+        for (int i = 0; i < PASS; ++i) {
+            const int j = base + i * 256 + tid;
+            const double px = (double)kx[i], py = (double)ky[i];
             const double a1x = px - g.f1x, a1y = py - g.f1y, a2x = px - g.f2x, a2y = py - g.f2y;
             const double ns = sqrt(a1x * a1x + a1y * a1y) + sqrt(a2x * a2x + a2y * a2y);
-            inside = ns <= g.two_major;
-            if (inside) {
+            inside[i] = j < n_kp && ns <= g.two_major;
+            dist[i] = 0.0;
+            if (inside[i]) {
                 const uint32_t *cd = (const uint32_t *)(kdesc + (size_t)j * desc_bytes);
                 if (desc_f32) { // Matching.cpp:60-73: float difference, float square, double sum in column order, sqrt
+                    double acc = 0.0;
                     for (int w = 0; w < words; ++w) {
                         const float subs = __uint_as_float(qd[w]) - __uint_as_float(cd[w]);
-                        dist += (double)(subs * subs);
+                        acc += (double)(subs * subs);
                     }
-                    dist = sqrt(dist);
+                    dist[i] = sqrt(acc);
                 } else {
                     int d = 0;
                     for (int w = 0; w < words; ++w) d += __popc(cd[w] ^ qd[w]);
-                    dist = (double)d;
+                    dist[i] = (double)d;
                 }
             }
+            // ordered compaction of the candidates: keypoint order = (i, wavefront, lane)
+            const unsigned long long bal = __ballot(inside[i]);
+            rank[i] = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_cnt[i][wv] = __popcll(bal);
         }
-        // ordered compaction of this chunk's candidates
-        const unsigned long long bal = __ballot(inside);
-        const int rank = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[wv] = __popcll(bal);
         __syncthreads();
-        int off = 0;
-        for (int w = 0; w < wv; ++w) off += wave_cnt[w];
-        if (inside) {
-            c_idx[off + rank] = j;
-            c_dist[off + rank] = dist;
+        int nc = 0;
+#pragma unroll
+        for (int i = 0; i < PASS; ++i) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int c = wave_cnt[i][w];
+                if (w == wv && inside[i]) {
+                    c_idx[nc + rank[i]] = base + i * 256 + tid;
+                    c_dist[nc + rank[i]] = dist[i];
+                }
+                nc += c;
+            }
         }
         __syncthreads();
         if (tid == 0) {
-            const int nc = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
             // findBestNMatches, nBest = 2: push_front when (dist < min) or fewer than two entries
             for (int c = 0; c < nc; ++c) {
                 const double dc = c_dist[c];
@@ -91,8 +109,8 @@ k_match(const int *plist, const double *uv_tab, const double *S_tab, const uint8
                 }
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
     if (tid == 0) {
         // matchICDescriptors: accept a lone candidate, or front <= back * coef (distances are floats in DMatch)
         const bool ok = s_list_n == 1 || (s_list_n >= 2 && (double)s_dfront <= (double)s_dback * coef);

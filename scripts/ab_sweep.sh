@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/r2z
 (
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge_cases.py tests/test_gpu_sharded.py tests/test_gpu_map_management.py -q -x 2>&1 | grep -E "passed|failed|Error" | head -5
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge_cases.py tests/test_gpu_sharded.py tests/test_gpu_map_management.py tests/test_gpu_compat.py tests/test_gpu_sequence.py -q -x 2>&1 | grep -E "passed|failed|Error" | head -5
 for i in 1 2 3; do
   python bench.py --steps 40 --warmup 10 --no-all-matched --no-single-gpu-reference --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
