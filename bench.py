@@ -357,7 +357,10 @@ def main():
         torch.cuda.synchronize()
         ranks.barrier()
         torch.cuda.synchronize()
-        return time.perf_counter() - t0, infos
+        dt = time.perf_counter() - t0
+        for e in (group.engines if group else [eng]):
+            e.synchronize()  # async error mode: a failed factorisation in the LAST frame's update surfaces here (raises)
+        return dt, infos
 
     elapsed, infos = run(False)
     elapsed = ranks.max_over_ranks(elapsed)

@@ -190,7 +190,8 @@ int ekf_frames_upload(EkfEngine *e, int n_frames, const int32_t *kp_counts, cons
 int ekf_step_frame(EkfEngine *e, int frame, EkfStepInfo *info);
 /* on: ekf_step / ekf_step_frame return without the final read-back of the error flag (they then return as soon as the
  * second update is ENQUEUED).  A failed factorisation of that update (EKF_ERR_NOT_POSITIVE_DEFINITE) is reported by the
- * next ekf_step* instead -- the reference reports nothing at all (cv::invert returns zeros).  Default off. */
+ * next ekf_step*, ekf_synchronize or ekf_get_state, whichever comes first (the flag is sticky on the device until one of
+ * them reports and clears it) -- the reference reports nothing at all (cv::invert returns zeros).  Default off. */
 int ekf_set_async_errors(EkfEngine *e, int on);
 /* How an update forms B = inv(L) (H P), the factor of the covariance downdate (replaces K = P H' inv(S),
  * EKF/Update.cpp:105-108): EKF_UPDATE_PATH_AUTO by the number of measurement rows (the default), EKF_UPDATE_PATH_SWEEP

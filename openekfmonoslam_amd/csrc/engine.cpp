@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include <dlfcn.h>
@@ -49,23 +50,27 @@ struct RcclApi {
 static RcclApi &rccl_api()
 {
     static RcclApi api;
-    if (api.lib) return api;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (api.lib) break;
-    }
-    if (!api.lib) return api;
+    static std::once_flag once; // engines may be created from several threads: the table is filled exactly once
+    std::call_once(once, [] {
+        // a copy that is already mapped (torch.distributed's "nccl" backend) first: two RCCL copies in one process would
+        // each keep their own device state
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *name : names)
+            if ((api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD))) break;
+        for (int i = 0; !api.lib && i < 3; ++i) api.lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!api.lib) return;
 #define RCCL_SYM(field, sym) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, sym))
-    RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
-    RCCL_SYM(CommInitRank, "ncclCommInitRank");
-    RCCL_SYM(CommDestroy, "ncclCommDestroy");
-    RCCL_SYM(GroupStart, "ncclGroupStart");
-    RCCL_SYM(GroupEnd, "ncclGroupEnd");
-    RCCL_SYM(Send, "ncclSend");
-    RCCL_SYM(Recv, "ncclRecv");
-    RCCL_SYM(GetErrorString, "ncclGetErrorString");
+        RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+        RCCL_SYM(CommInitRank, "ncclCommInitRank");
+        RCCL_SYM(CommDestroy, "ncclCommDestroy");
+        RCCL_SYM(GroupStart, "ncclGroupStart");
+        RCCL_SYM(GroupEnd, "ncclGroupEnd");
+        RCCL_SYM(Send, "ncclSend");
+        RCCL_SYM(Recv, "ncclRecv");
+        RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef RCCL_SYM
-    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Send && api.Recv;
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Send && api.Recv;
+    });
     return api;
 }
 
@@ -435,12 +440,18 @@ int ekf_state_dim(const EkfEngine *e) { return e ? e->n : 0; }
 int ekf_descriptor_bytes(const EkfEngine *e) { return e ? e->desc_bytes : 0; }
 int ekf_num_features(const EkfEngine *e) { return e ? e->N : 0; }
 
+static int finish_update(EkfEngine *e);
+
+// With ekf_set_async_errors a step does not read the error flag of its last update back; the flag is sticky on the
+// device and is reported (and cleared) by the next step, by ekf_synchronize or by ekf_get_state, whichever comes first.
+static int take_pending_error(EkfEngine *e) { return e->async_errors ? finish_update(e) : EKF_OK; }
+
 int ekf_synchronize(EkfEngine *e)
 {
     if (!e) return EKF_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
-    return EKF_OK;
+    return take_pending_error(e);
 }
 
 // ------------------------------------------------------------------------------------------- state transfer
@@ -533,6 +544,7 @@ int ekf_get_state(EkfEngine *e, double x13[13], double *feature_pos, double *P)
     if (!e) return EKF_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
+    const int pending = take_pending_error(e); // the state is still copied out: the caller sees what the failed update left
     if (x13) HIPCHK(hipMemcpy(x13, e->d.state, 13 * sizeof(double), hipMemcpyDeviceToHost));
     if (feature_pos && e->N > 0)
         HIPCHK(hipMemcpy(feature_pos, e->d.feat_pos, (size_t)6 * e->N * sizeof(double), hipMemcpyDeviceToHost));
@@ -556,7 +568,7 @@ int ekf_get_state(EkfEngine *e, double x13[13], double *feature_pos, double *P)
             }
         }
     }
-    return EKF_OK;
+    return pending;
 }
 
 

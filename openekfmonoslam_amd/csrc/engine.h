@@ -180,9 +180,10 @@ struct EkfEngine {
     int n_step_preds = 0;
     int cells_cap = 0;        // detector cell buffers allocated for this many cells
     int n_kp = 0;
-    int pu_tilemap_nt = -1;
-    std::map<int, std::pair<void *, int>> pu_tables; // built work lists of the downdate: key -> (device list, units per XCD)
+    long long pu_tilemap_nt = -1;
+    std::map<long long, std::pair<void *, int>> pu_tables; // built work lists of the downdate: key -> (device list, units per XCD)
     int pu_per_xcd = 0;
+    int pu_slots = 0;         // resident workgroups of the downdate kernel on this device (0: not asked yet, -1: unknown)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // image-only work of the next frame, overlapped with the update
     hipEvent_t ev_main = nullptr, ev_prefetch = nullptr;

@@ -19,6 +19,8 @@
 #include "engine.h"
 #include "mma_tile.h"
 
+#include <algorithm>
+
 namespace ekf {
 
 #ifndef PU_LDS_DMA
@@ -26,6 +28,9 @@ namespace ekf {
 #endif
 #ifndef PU_LDS_DMA_F64
 #define PU_LDS_DMA_F64 1 // the fp64 instance needs 86 VGPRs either way; without the staging stores it is 2 % faster at N = 1000
+#endif
+#ifndef PU_F32_PAIRS
+#define PU_F32_PAIRS 1 // fp32: k_p_update_f32 (operand pairs by 8-byte LDS reads); 0: the generic kernel below
 #endif
 #ifndef PU_MIN_WAVES
 #define PU_MIN_WAVES 3 // with PU_LDS_DMA 4 fits (128 VGPRs, 4 x 32 KB LDS): +2.4 % at N = 1000, -3 % at N = 2000 / 5000
@@ -246,12 +251,215 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
         }
 }
 
+// ------------------------------------------------------------------------------------------------ fp32 instance
+// The same tiles, units and slab pipeline as k_p_update (register-staged, double-buffered [k][column] slabs, one barrier per
+// slab), with the operands of TWO MFMA blocks fetched by ONE 8-byte LDS read.  On this chip the return traffic of the
+// operand reads takes cycles from the matrix pipe: with one 4-byte read per operand and k-step (32 per wavefront and slab) the
+// pure loop at three workgroups per CU runs 292 us at m = 1014, with 16-byte reads 266 us, with none 261 us
+// (scripts/micro/pu_bench.hip, profiles/r03_pu_bench.txt).  Lane (klane, idx) therefore reads the PAIR of adjacent columns
+// 2 idx, 2 idx + 1 of its wavefront's 64 rows (and of its 64 columns) at k-row k + klane: block (ea, eb) of the wavefront's
+// 2 x 2 MFMA blocks then holds the outputs (row 2 i + ea, column 2 j + eb) instead of a contiguous 32 x 32 square.  Nothing
+// else moves: B stays k-major in HBM, slabs are copied as before, and the epilogue's accesses become 8 bytes wide (the two
+// column blocks of a register are adjacent columns), which also halves its load / store instruction count.
+template <bool AVG, bool RECT>
+__global__ void __launch_bounds__(256, 3)
+k_p_update_f32(float *P, int ldp, int n, const float *B, int ldb, int m_k, int per_xcd, const int4 *units, RowMap rm, int stagger)
+{
+    using M = Mma<float>;
+    constexpr int MB = 32, TM = 128, BK = PU_BK, VEC = 4;
+    constexpr int LOADS = BK * TM / (256 * VEC);
+    constexpr int TS = 2 * MB + 2;         // transpose scratch: [32 column pairs][64 rows + 2]
+    static_assert(LOADS == 2, "two 16-byte pieces per thread, operand and slab");
+    // [I-slab x2 | J-slab x2]; re-used by the epilogue as per-wavefront transpose scratch (32 x 66 floats each)
+    __shared__ __attribute__((aligned(16))) float smem[(4 * BK * TM > 4 * MB * TS) ? 4 * BK * TM : 4 * MB * TS];
+    float(*sI)[BK][TM] = reinterpret_cast<float(*)[BK][TM]>(smem);
+    float(*sJ)[BK][TM] = reinterpret_cast<float(*)[BK][TM]>(smem + 2 * BK * TM);
+
+    const int4 unit = units[(size_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)]; // XCD-aware work order, see k_p_update
+    if (unit.x < 0) return;
+    if (stagger > 0) { // short k-loops: de-phase the three workgroups of a CU, see k_p_update
+        const int slot = (blockIdx.x >> 3) / 32;
+        if (slot == 1 || slot == 2) {
+            const int n_sleep = slot * m_k / stagger;
+            for (int i = 0; i < n_sleep; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+    const int ti = unit.x, tj = unit.y;
+    const bool full = unit.z < 0;
+    const bool diag = RECT || (ti == tj);
+    const int I0 = RECT ? (ti == 0 ? 0 : rm.r0 + (ti - 1) * TM) : ti * TM, J0 = tj * TM;
+    const int p_off = RECT ? (ti == 0 ? 0 : rm.base - rm.r0) : 0;
+    const int ilim = RECT ? (ti == 0 ? 13 : rm.r1) : n;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int rbase = full ? wr * 2 * MB : unit.z * 2 * MB + wr * MB; // first tile row of the wavefront (64 or 32 rows)
+    const int cbase = wc * 2 * MB;
+    const int klane = lane >> 5, idx = lane & 31;
+
+    // c<ea><eb>: rows rbase + 2 i + ea (whole unit) or rbase + i (half unit, ea = 0 only), columns cbase + 2 j + eb
+    typename M::acc_t c00, c01, c10, c11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c00[r] = c01[r] = c10[r] = c11[r] = 0.f;
+
+    const int nk = m_k / BK;
+    const size_t slab = (size_t)BK * ldb;
+#define PUF_PIECE(q) const int lk##q = ((tid + q * 256) * VEC) / TM, lc##q = ((tid + q * 256) * VEC) % TM; \
+                     const float *gI##q = B + (size_t)lk##q * ldb + I0 + lc##q; const float *gJ##q = B + (size_t)lk##q * ldb + J0 + lc##q; \
+                     float4 rI##q = *(const float4 *)gI##q, rJ##q = *(const float4 *)gJ##q;
+    PUF_PIECE(0)
+    PUF_PIECE(1)
+#undef PUF_PIECE
+#define PUF_STORE(q, b) *(float4 *)(&sI[b][lk##q][lc##q]) = rI##q; *(float4 *)(&sJ[b][lk##q][lc##q]) = rJ##q;
+#define PUF_LOAD(q, off) rI##q = *(const float4 *)(gI##q + off); rJ##q = *(const float4 *)(gJ##q + off);
+    PUF_STORE(0, 0)
+    PUF_STORE(1, 0)
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) { // the next slab travels to registers while this one is multiplied
+            const size_t off = (size_t)(kt + 1) * slab;
+            PUF_LOAD(0, off)
+            PUF_LOAD(1, off)
+        }
+        // operands of k-step kk + 2 are requested before the MFMAs of k-step kk are issued (a wavefront issues in order).
+        // Issuing all sixteen reads of a slab before its first MFMA instead was measured slower (350 against 332 us at
+        // m = 1014): every wavefront of the workgroup then waits out the LDS latency right after the barrier.
+        if (full) {
+            const float *pa = &sI[buf][klane][rbase + 2 * idx], *pb = &sJ[buf][klane][cbase + 2 * idx];
+            float2 a = *(const float2 *)pa, b = *(const float2 *)pb;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                float2 na = a, nb = b;
+                if (kk + 2 < BK) {
+                    na = *(const float2 *)(pa + (kk + 2) * TM);
+                    nb = *(const float2 *)(pb + (kk + 2) * TM);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                c00 = M::mma(a.x, b.x, c00);
+                c01 = M::mma(a.x, b.y, c01);
+                c10 = M::mma(a.y, b.x, c10);
+                c11 = M::mma(a.y, b.y, c11);
+                __builtin_amdgcn_sched_barrier(0);
+                a = na;
+                b = nb;
+            }
+        } else {
+            const float *pa = &sI[buf][klane][rbase + idx], *pb = &sJ[buf][klane][cbase + 2 * idx];
+            float a = *pa;
+            float2 b = *(const float2 *)pb;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                float na = a;
+                float2 nb = b;
+                if (kk + 2 < BK) {
+                    na = pa[(kk + 2) * TM];
+                    nb = *(const float2 *)(pb + (kk + 2) * TM);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                c00 = M::mma(a, b.x, c00);
+                c01 = M::mma(a, b.y, c01);
+                __builtin_amdgcn_sched_barrier(0);
+                a = na;
+                b = nb;
+            }
+        }
+        if (more) {
+            PUF_STORE(0, buf ^ 1)
+            PUF_STORE(1, buf ^ 1)
+        }
+        __syncthreads();
+    }
+#undef PUF_STORE
+#undef PUF_LOAD
+
+    // epilogue.  P is bitwise symmetric on entry (engine invariant) unless AVG; every (row, column pair) of a register is one
+    // 8-byte access.  Off-diagonal tiles also write the mirror image: the two row blocks of one column parity go through
+    // a per-wavefront LDS transpose ([column pair][row]) and leave as 8-byte stores of adjacent mirror columns.
+    const int gjp = J0 + cbase + 2 * M::col(lane); // first column of this lane's pair
+    if (AVG) { // first update after an arbitrary upload: P(i,j) <- 0.5 (P(i,j) + P(j,i)) - acc on i <= j, mirrored
+#pragma unroll
+        for (int ea = 0; ea < 2; ++ea)
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) {
+                if (ea == 1 && !full) continue;
+                const typename M::acc_t &cc = ea == 0 ? (eb == 0 ? c00 : c01) : (eb == 0 ? c10 : c11);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gi = I0 + rbase + (full ? 2 * M::row(r, lane) + ea : M::row(r, lane)), gj = gjp + eb;
+                    if (!RECT && gi < n && gj < n && gi <= gj) {
+                        float *pu = P + (size_t)gi * ldp + gj, *pl = P + (size_t)gj * ldp + gi;
+                        const float v = (0.5f * (*pu) + 0.5f * (*pl)) - cc[r];
+                        *pu = v;
+                        *pl = v;
+                    }
+                }
+            }
+        return;
+    }
+    float *sT = smem + wv * MB * TS;
+#pragma unroll
+    for (int ea = 0; ea < 2; ++ea) {
+        if (ea == 1 && !full) continue;
+        typename M::acc_t &ca = ea == 0 ? c00 : c10, &cb = ea == 0 ? c01 : c11;
+        float2 pv[16]; // all sixteen row values are requested before the first is used
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gi = I0 + rbase + (full ? 2 * M::row(r, lane) + ea : M::row(r, lane));
+            pv[r] = (gi < ilim && gjp < n) ? *(const float2 *)(P + (size_t)(gi + p_off) * ldp + gjp) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gi = I0 + rbase + (full ? 2 * M::row(r, lane) + ea : M::row(r, lane));
+            ca[r] = pv[r].x - ca[r]; // the accumulators now hold the new values of P (the mirror pass reads them)
+            cb[r] = pv[r].y - cb[r];
+            if (gi < ilim) {
+                float *dst = P + (size_t)(gi + p_off) * ldp + gjp;
+                if (gjp + 1 < n) *(float2 *)dst = make_float2(ca[r], cb[r]);
+                else if (gjp < n) *dst = ca[r]; // n is odd: the last column has no partner (the padding stays untouched)
+            }
+        }
+    }
+    if (diag) return;
+    // mirror image: P[column][row].  Rows of an off-diagonal tile are all < n (its row range ends before its column range starts).
+    const int ni = full ? 2 * MB : MB; // rows of the wavefront
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) {
+        const typename M::acc_t &c0 = eb == 0 ? c00 : c01, &c1 = eb == 0 ? c10 : c11;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int li = M::row(r, lane), lj = M::col(lane);
+            if (full) {
+                sT[lj * TS + 2 * li] = c0[r];
+                sT[lj * TS + 2 * li + 1] = c1[r];
+            } else {
+                sT[lj * TS + li] = c0[r];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        const int hp = ni / 2;                 // row pairs per mirror row: 32 or 16
+        const int ip = lane % hp, cq = lane / hp, cstep = 64 / hp;
+#pragma unroll
+        for (int it = 0; it < MB / 2; ++it) {
+            if (it * cstep >= MB) break;
+            const int c = it * cstep + cq;     // column pair of the wavefront = mirror row 2 c + eb
+            const int gj = J0 + cbase + 2 * c + eb, gi = I0 + rbase + 2 * ip;
+            const float2 v = *(const float2 *)(sT + c * TS + 2 * ip);
+            if (gj < n) *(float2 *)(P + (size_t)gj * ldp + gi) = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // host-built work list.  Tiles: super-tiles of 8 x 8 tiles, row-major inside; upper triangle only (whole matrix on
 // one GPU) or all nrt x nt tiles of the owned row tiles (RECT).  The tail (ntiles mod #CUs tiles, i.e. what would
 // occupy only part of the chip for a whole tile time) is split into half units.
 static void build_units(EkfEngine *e, int nt, int nrt, bool rect, bool halves_first)
 {
-    const int key = (rect ? -(nt * 4096 + nrt) : nt) * 2 + (halves_first ? 1 : 0);
+    const long long key = ((long long)(rect ? -(nt * 4096 + nrt) : nt) * 2 + (halves_first ? 1 : 0)) * 4096 + e->pu_slots;
     if (e->pu_tilemap_nt == key && e->d.pu_tilemap) return;
     {   // the two orders of one geometry alternate every frame (LI / HI update): keep every list once built
         auto it = e->pu_tables.find(key);
@@ -276,7 +484,21 @@ static void build_units(EkfEngine *e, int nt, int nrt, bool rect, bool halves_fi
                     for (int j = (sj > i ? sj : i); j < sj + ST && j < nt; ++j) tiles.push_back(make_int4(i, j, -1, 0));
     }
     const int ntiles = (int)tiles.size();
-    const int n_full = ntiles >= NCU ? (ntiles / NCU) * NCU : 0;
+    // How many tiles stay whole.  The launch is one workgroup per unit and the device keeps `slots` of them resident
+    // (workgroups per CU x CUs); a freed slot takes the next unit of its XCD's list.  Whole tiles take the same time T and a
+    // half unit T / 2, so the launch is `rounds` half-rounds long when every slot is dealt the same number of half units:
+    // floor(rounds / 2) whole tiles and, for an odd count, one half.  At N = 1000 (1128 tiles, 768 slots): 752 slots x (one
+    // whole tile + one half).  The rule of rounds 1-2 (whole tiles in multiples of the CU count: 1024 + 208 halves) left a
+    // third round of whole tiles on a third of the CUs: the MFMA stream alone took 318 us where the balanced list takes 260
+    // (scripts/micro/pu_bench.hip, profiles/r03_pu_bench.txt).
+    int n_full;
+    if (e->pu_slots > 0) {
+        const int rounds = (2 * ntiles + e->pu_slots - 1) / e->pu_slots; // half-rounds of the whole launch
+        const int used = (2 * ntiles + rounds - 1) / rounds;              // slots that get `rounds` half units
+        n_full = rounds <= 1 ? 0 : std::min(ntiles, (rounds / 2) * used);
+    } else {
+        n_full = ntiles >= NCU ? (ntiles / NCU) * NCU : 0;
+    }
     std::vector<int4> halves;
     for (int t = n_full; t < ntiles; ++t) {
         halves.push_back(make_int4(tiles[t].x, tiles[t].y, 0, 0));
@@ -310,12 +532,19 @@ static void launch_p_update_t(EkfEngine *e, int m_pad, int grid, const int4 *tm,
     hipStream_t s = e->stream;
     T *P = (T *)e->d.P;
     const T *B = (const T *)e->d.A;
+    const int stagger = (m_pad < 512 && grid >= 768) ? 80 : 0;
+    if constexpr (sizeof(T) == 4 && PU_F32_PAIRS) {
+        if (rect) k_p_update_f32<false, true><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger);
+        else if (avg) k_p_update_f32<true, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger);
+        else k_p_update_f32<false, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger);
+        return;
+    }
     if (rect)
-        k_p_update<T, false, true><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, (m_pad < 512 && grid >= 768) ? 80 : 0);
+        k_p_update<T, false, true><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger);
     else if (avg)
-        k_p_update<T, true, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, (m_pad < 512 && grid >= 768) ? 80 : 0);
+        k_p_update<T, true, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger);
     else
-        k_p_update<T, false, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, (m_pad < 512 && grid >= 768) ? 80 : 0);
+        k_p_update<T, false, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger);
 }
 
 void launch_p_update(EkfEngine *e, int m_pad, int m)
@@ -327,6 +556,17 @@ void launch_p_update(EkfEngine *e, int m_pad, int m)
     const bool rect = e->shard_world > 1;
     const int owned = e->rm.r1 - e->rm.r0;
     const int nrt = 1 + (owned + TM - 1) / TM; // camera tile + owned row tiles
+    if (e->pu_slots == 0) { // workgroups of this kernel the device keeps resident: the unit list is balanced against it
+        int per_cu = 0;
+        hipError_t st;
+        if (e->f32 && PU_F32_PAIRS) st = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_p_update_f32<false, false>, 256, 0);
+        else if (e->f32) st = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_p_update<float, false, false>, 256, 0);
+        else st = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_p_update<double, false, false>, 256, 0);
+        e->pu_slots = (st == hipSuccess && per_cu > 0) ? per_cu * e->n_cus : -1; // -1: the CU-count rule of rounds 1-2
+    }
+    // the kernels walk B in slabs of PU_BK rows: rows m .. m_pad of B are zero, so the k-loop may stop at the next multiple
+    // of the slab depth instead of the Cholesky panel width (m = 298: 304 rows instead of 320)
+    m_pad = round_up(m, PU_BK);
     build_units(e, nt, nrt, rect, m_pad >= 512);
     const int grid = e->pu_per_xcd * 8;
     const int4 *tm = (const int4 *)e->d.pu_tilemap;
@@ -343,7 +583,7 @@ void launch_p_update(EkfEngine *e, int m_pad, int m)
         (void)hipEventRecord(e1, s);
         e->pu_events.emplace_back(e0, e1);
         // flops of this launch / 1 (n^2 m counts the symmetric downdate; a rank computes owned x n x m x 2 / 2)
-        // algorithmic work of the launch from the UN-padded m (the kernel runs m rounded up to 32 rows of B, the rest zero)
+        // algorithmic work of the launch from the UN-padded m (the kernel runs m rounded up to 16 rows of B, the rest zero)
         e->pu_work.push_back(rect ? (double)(owned + 13) * (double)n * (double)m * 2.0 : (double)n * (double)n * (double)m);
         e->pu_m.push_back(m);
     }

@@ -1,0 +1,68 @@
+"""Which entries of the fp32-computed covariance carry the next frame's component-wise state error?  GPU box.
+After t0 frames on the engine (fp32 covariance) and on the oracle (fp64), build hybrids: the ORACLE's P with one class of
+entries replaced by the ENGINE's values (diagonal / off-diagonal entries of the per-feature 6x6 blocks / camera rows and
+columns / cross-feature blocks / everything), step the oracle ONE frame from each hybrid (fp64 arithmetic, oracle state) and
+compare with the pure oracle.  Also prints the engine's own error after that frame and the size of the P error by class."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import oracle_lib as ol
+from openekfmonoslam_amd import engine
+from openekfmonoslam_amd.synth import SyntheticSequence
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+t0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+path = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+kw = eval(sys.argv[4]) if len(sys.argv) > 4 else {}
+ol.build()
+seq = SyntheticSequence(N, t0 + 1, **kw)
+o = ol.Oracle(seq.cam, seq.par, N + 8)
+e = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=1)
+e.set_update_path(path)
+for h in (o, e):
+    h.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+for t in range(t0):
+    o.step(*seq.frames[t], ol.ALGORITHMIC)
+    e.step(*seq.frames[t])
+xo, fo, Po = o.x13(), o.feature_pos(), o.P()
+xg, fg, Pg = e.get_state()
+n = Po.shape[0]
+cls = np.zeros((n, n), dtype=np.int8)  # 0 cross-feature, 1 diagonal, 2 block off-diagonal, 3 camera rows/cols
+cls[:13, :] = 3
+cls[:, :13] = 3
+for f in range(N):
+    p = 13 + 6 * f
+    cls[p:p + 6, p:p + 6] = 2
+cls[np.arange(13, n), np.arange(13, n)] = 1
+names = {0: "cross-feature blocks", 1: "feature diagonal", 2: "6x6 block off-diagonals", 3: "camera rows/cols"}
+d = np.abs(Pg - Po)
+for c, nm in names.items():
+    m = cls == c
+    print(f"P error after {t0} frame(s), {nm:24s}: max abs {d[m].max():.2e}  rms {np.sqrt((d[m] ** 2).mean()):.2e}  (max |P| there {np.abs(Po[m]).max():.2e})")
+o.step(*seq.frames[t0], ol.ALGORITHMIC)
+fe = o.feature_pos()
+
+
+def report(tag, fv):
+    er = np.abs(fv - fe) / np.maximum(np.abs(fe), 1e-4)
+    k = np.unravel_index(er.argmax(), er.shape)
+    print(f"frame {t0} from {tag:44s}: componentwise {er.max():.2e} (feature {k[0]} comp {k[1]} value {fe[k]:.3e} err {abs(fv[k] - fe[k]):.2e})", flush=True)
+
+
+e.step(*seq.frames[t0])
+report("the engine itself", e.get_state()[1])
+hybrids = [("oracle P, ENGINE state", None, True)]
+for c, nm in names.items():
+    hybrids.append((f"oracle state, P: engine's {nm}", cls == c, False))
+hybrids.append(("oracle state, engine's whole P", np.ones((n, n), dtype=bool), False))
+for tag, mask, use_state in hybrids:
+    Ph = Po if mask is None else np.where(mask, Pg, Po)
+    oh = ol.Oracle(seq.cam, seq.par, N + 8)
+    oh.set_state(xg if use_state else xo, fg if use_state else fo, seq.feature_type, seq.feature_desc, Ph)
+    oh.step(*seq.frames[t0], ol.ALGORITHMIC)
+    report(tag, oh.feature_pos())
