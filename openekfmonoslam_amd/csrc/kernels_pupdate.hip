@@ -374,6 +374,12 @@ k_p_update_f32(float *P, int ldp, int n, const float *B, int ldb, int m_k, int p
 #undef PUF_STORE
 #undef PUF_LOAD
 
+#ifdef PU_F32_ABL // timing ablations of scripts/micro/pu_bench.hip only (wrong results): 1 no epilogue, 4 direct part only, 8 mirror part only
+    if (PU_F32_ABL & 1) {
+        if (c00[0] + c01[1] + c10[2] + c11[3] == 12345.f) P[0] = 0.f;
+        return;
+    }
+#endif
     // epilogue.  P is bitwise symmetric on entry (engine invariant) unless AVG; every (row, column pair) of a register is one
     // 8-byte access.  Off-diagonal tiles also write the mirror image: the two row blocks of one column parity go through
     // a per-wavefront LDS transpose ([column pair][row]) and leave as 8-byte stores of adjacent mirror columns.
@@ -399,29 +405,42 @@ k_p_update_f32(float *P, int ldp, int n, const float *B, int ldb, int m_k, int p
         return;
     }
     float *sT = smem + wv * MB * TS;
+#ifdef PU_F32_ABL
+    if (!(PU_F32_ABL & 8))
+#endif
 #pragma unroll
     for (int ea = 0; ea < 2; ++ea) {
         if (ea == 1 && !full) continue;
         typename M::acc_t &ca = ea == 0 ? c00 : c10, &cb = ea == 0 ? c01 : c11;
-        float2 pv[16]; // all sixteen row values are requested before the first is used
+        // All sixteen row values are requested before the first is used.  Measured and not kept: requesting the first row
+        // block's values before the k-loop (they do not depend on it) costs 32 live registers, the kernel spills: 133 against
+        // 113 us at m = 298; an instance for four workgroups per CU (128 registers, 108 bytes of scratch): 163 against 115 us.
+        constexpr int RH = 16;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int gi = I0 + rbase + (full ? 2 * M::row(r, lane) + ea : M::row(r, lane));
-            pv[r] = (gi < ilim && gjp < n) ? *(const float2 *)(P + (size_t)(gi + p_off) * ldp + gjp) : make_float2(0.f, 0.f);
-        }
+        for (int r0 = 0; r0 < 16; r0 += RH) {
+            float2 pv[RH];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int gi = I0 + rbase + (full ? 2 * M::row(r, lane) + ea : M::row(r, lane));
-            ca[r] = pv[r].x - ca[r]; // the accumulators now hold the new values of P (the mirror pass reads them)
-            cb[r] = pv[r].y - cb[r];
-            if (gi < ilim) {
-                float *dst = P + (size_t)(gi + p_off) * ldp + gjp;
-                if (gjp + 1 < n) *(float2 *)dst = make_float2(ca[r], cb[r]);
-                else if (gjp < n) *dst = ca[r]; // n is odd: the last column has no partner (the padding stays untouched)
+            for (int r = 0; r < RH; ++r) {
+                const int gi = I0 + rbase + (full ? 2 * M::row(r0 + r, lane) + ea : M::row(r0 + r, lane));
+                pv[r] = (gi < ilim && gjp < n) ? *(const float2 *)(P + (size_t)(gi + p_off) * ldp + gjp) : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                const int gi = I0 + rbase + (full ? 2 * M::row(r0 + r, lane) + ea : M::row(r0 + r, lane));
+                ca[r0 + r] = pv[r].x - ca[r0 + r]; // the accumulators now hold the new values of P (the mirror pass reads them)
+                cb[r0 + r] = pv[r].y - cb[r0 + r];
+                if (gi < ilim) {
+                    float *dst = P + (size_t)(gi + p_off) * ldp + gjp;
+                    if (gjp + 1 < n) *(float2 *)dst = make_float2(ca[r0 + r], cb[r0 + r]);
+                    else if (gjp < n) *dst = ca[r0 + r]; // n is odd: the last column has no partner (the padding stays untouched)
+                }
             }
         }
     }
     if (diag) return;
+#ifdef PU_F32_ABL
+    if (PU_F32_ABL & 4) return;
+#endif
     // mirror image: P[column][row].  Rows of an off-diagonal tile are all < n (its row range ends before its column range starts).
     const int ni = full ? 2 * MB : MB; // rows of the wavefront
 #pragma unroll
@@ -457,9 +476,13 @@ k_p_update_f32(float *P, int ldp, int n, const float *B, int ldb, int m_k, int p
 // host-built work list.  Tiles: super-tiles of 8 x 8 tiles, row-major inside; upper triangle only (whole matrix on
 // one GPU) or all nrt x nt tiles of the owned row tiles (RECT).  The tail (ntiles mod #CUs tiles, i.e. what would
 // occupy only part of the chip for a whole tile time) is split into half units.
-static void build_units(EkfEngine *e, int nt, int nrt, bool rect, bool halves_first)
+int g_pu_order_override = -1; // scripts/micro/pu_bench.hip only
+
+// order: 0 half units last, 1 half units first, 2 mixed first round (see below)
+static void build_units(EkfEngine *e, int nt, int nrt, bool rect, int order)
 {
-    const long long key = ((long long)(rect ? -(nt * 4096 + nrt) : nt) * 2 + (halves_first ? 1 : 0)) * 4096 + e->pu_slots;
+    if (g_pu_order_override >= 0) order = g_pu_order_override;
+    const long long key = ((long long)(rect ? -(nt * 4096 + nrt) : nt) * 4 + order) * 4096 + e->pu_slots;
     if (e->pu_tilemap_nt == key && e->d.pu_tilemap) return;
     {   // the two orders of one geometry alternate every frame (LI / HI update): keep every list once built
         auto it = e->pu_tables.find(key);
@@ -508,14 +531,33 @@ static void build_units(EkfEngine *e, int nt, int nrt, bool rect, bool halves_fi
     const int per = fchunk + hchunk;
     std::vector<int4> table((size_t)NX * per, make_int4(-1, -1, -1, 0));
     for (int x = 0; x < NX; ++x) {
-        // Two orders share the list.  Long k-loops (m >= 512): half units FIRST -- every tile takes the same time, so the
-        // resident workgroups would otherwise run in lockstep and all hit their HBM-bound epilogue at once; starting a
-        // third of them on half-length units spreads the epilogues under the others' MFMA phases (measured: 0.384 ->
-        // 0.368 ms at m = 1056).  Short k-loops: half units LAST, where they shorten the tail.
-        const int hoff = halves_first ? 0 : fchunk, foff = halves_first ? hchunk : 0;
-        for (int k = 0; k < hchunk && x * hchunk + k < (int)halves.size(); ++k)
-            table[(size_t)x * per + hoff + k] = halves[x * hchunk + k];
-        for (int k = 0; k < fchunk && x * fchunk + k < n_full; ++k) table[(size_t)x * per + foff + k] = tiles[x * fchunk + k];
+        // order 0 (what launch_p_update asks for): whole tiles first, half units last.  Orders 1-3 are kept for the bench
+        // (round 2 ran long k-loops with the half units first; against a balanced list that is the slower order).
+        std::vector<int4> hl, fl, out;
+        for (int k = 0; k < hchunk && x * hchunk + k < (int)halves.size(); ++k) hl.push_back(halves[x * hchunk + k]);
+        for (int k = 0; k < fchunk && x * fchunk + k < n_full; ++k) fl.push_back(tiles[x * fchunk + k]);
+        size_t ih = 0, jf = 0;
+        if (order == 2 || order == 3) {
+            // mixed: the slots of the first round alternate between a half unit and a whole tile, so that with a balanced
+            // list (every slot: one of each) half of the slots run [half, tile] and the others [tile, half]: the epilogues of
+            // the first units fall at T/3 and 2T/3 under the other slots' MFMA phases, and the launch ends with a mix of
+            // tile and half-unit epilogues instead of every slot's tile epilogue at once
+            const int first = e->pu_slots > 0 ? e->pu_slots / NX : 0;
+            for (int i = 0; i < first && (ih < hl.size() || jf < fl.size()); ++i) {
+                const bool want_h = (((i / 32) & 1) == 0) == (order == 2); // 32 CUs per XCD, handed one workgroup each in turn
+                if ((want_h && ih < hl.size()) || jf >= fl.size()) out.push_back(hl[ih++]);
+                else out.push_back(fl[jf++]);
+            }
+            while (jf < fl.size()) out.push_back(fl[jf++]);
+            while (ih < hl.size()) out.push_back(hl[ih++]);
+        } else if (order == 1) {
+            out = hl;
+            out.insert(out.end(), fl.begin(), fl.end());
+        } else {
+            out = fl;
+            out.insert(out.end(), hl.begin(), hl.end());
+        }
+        for (size_t k = 0; k < out.size(); ++k) table[(size_t)x * per + k] = out[k];
     }
     e->d.pu_tilemap = nullptr;
     (void)hipMalloc((void **)&e->d.pu_tilemap, table.size() * sizeof(int4));
@@ -567,7 +609,13 @@ void launch_p_update(EkfEngine *e, int m_pad, int m)
     // the kernels walk B in slabs of PU_BK rows: rows m .. m_pad of B are zero, so the k-loop may stop at the next multiple
     // of the slab depth instead of the Cholesky panel width (m = 298: 304 rows instead of 320)
     m_pad = round_up(m, PU_BK);
-    build_units(e, nt, nrt, rect, m_pad >= 512);
+    // Whole tiles first, half units last, in both regimes (scripts/micro/pu_bench.hip, 15 interleaved rounds, m = 1014: half
+    // units first 332 us, mixed first round 323-347 us, whole tiles first 323 us).  Short k-loops keep the CU-count split of
+    // rounds 1-2 (m = 298: 113 against 116.5 us with the balanced list): there the launch is mostly epilogue traffic.
+    const int slots_saved = e->pu_slots;
+    if (m_pad < 512 && !rect) e->pu_slots = -1;
+    build_units(e, nt, nrt, rect, 0);
+    e->pu_slots = slots_saved;
     const int grid = e->pu_per_xcd * 8;
     const int4 *tm = (const int4 *)e->d.pu_tilemap;
     hipEvent_t e0 = nullptr, e1 = nullptr;

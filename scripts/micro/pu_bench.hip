@@ -65,9 +65,24 @@ int main(int argc, char **argv)
     e.d.P = dP; e.d.A = dB;
 
     std::vector<Variant> variants;
-    // legacy: whole tiles in multiples of the CU count (rounds 1-2); balanced: against the resident workgroup count
-    variants.push_back({"legacy_split", [](EkfEngine *en, int m_pad, int m) { en->pu_slots = -1; launch_p_update(en, m_pad, m); }});
-    variants.push_back({"balanced", [](EkfEngine *en, int m_pad, int m) { en->pu_slots = 0; launch_p_update(en, m_pad, m); }});
+    // shipped: launch_p_update's own choice of split and order; the others force one
+    variants.push_back({"shipped", [](EkfEngine *en, int m_pad, int m) { en->pu_slots = 0; launch_p_update(en, m_pad, m); }});
+    variants.push_back({"legacy_split", [](EkfEngine *en, int m_pad, int m) { en->pu_slots = -1; g_pu_order_override = m_pad >= 512 ? 1 : 0; launch_p_update(en, m_pad, m); g_pu_order_override = -1; }});
+    if (getenv("PU_ORDERS")) {
+        variants.push_back({"bal_halves_first", [](EkfEngine *en, int m_pad, int m) { en->pu_slots = 0; g_pu_order_override = 1; launch_p_update(en, m_pad, m); g_pu_order_override = -1; }});
+        variants.push_back({"bal_mixed_HFH", [](EkfEngine *en, int m_pad, int m) { en->pu_slots = 0; g_pu_order_override = 2; launch_p_update(en, m_pad, m); g_pu_order_override = -1; }});
+        variants.push_back({"bal_mixed_FHF", [](EkfEngine *en, int m_pad, int m) { en->pu_slots = 0; g_pu_order_override = 3; launch_p_update(en, m_pad, m); g_pu_order_override = -1; }});
+    }
+#ifdef PU_BENCH_ABLATIONS
+#define ABLV(name, A) variants.push_back({name, [](EkfEngine *en, int m_pad, int m) { en->pu_slots = 768; launch_pu_abl<A>(en, m_pad, m); }});
+    ABLV("abl3_noepi_noload(read2_b32 x16)", 3)
+    ABLV("abl7_no_lds_reads", 7)
+    ABLV("abl19_b128x8_upfront", 19)
+    ABLV("abl67_b64x16_interleaved", 67)
+    ABLV("abl195_b64x16_upfront", 195)
+    ABLV("abl259_b128x8_interleaved", 259)
+    ABLV("abl15_mfma_only", 15)
+#endif
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int m : ms) {

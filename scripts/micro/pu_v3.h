@@ -169,7 +169,7 @@ static void launch_pu3(EkfEngine *e, int m_pad, int m)
 {
     const int n = e->n, nt = (n + 127) / 128;
     const int m_k = round_up(m, BK);
-    build_units(e, nt, 0, false, m_pad >= 512);
+    build_units(e, nt, 0, false, m_pad >= 512 ? 1 : 0);
     k_pu3<BK, NST, MINW, ABL><<<e->pu_per_xcd * 8, 256, 0, e->stream>>>((float *)e->d.P, e->ldP, n, (const float *)e->d.A, e->ldP, m_k,
                                                                         e->pu_per_xcd, (const int4 *)e->d.pu_tilemap);
 }
@@ -240,6 +240,47 @@ k_pu_abl(float *P, int ldp, int n, const float *B, int ldb, int m_pad, int per_x
                         c11 = M::mma(a1[e], b1[e], c11);
                     }
                 }
+            }
+        } else if (ABL & 64) { // 8-byte operand pairs (the shipped fp32 kernel's reads), interleaved with the MFMAs or (ABL & 128) all up-front
+            const float *pa = &sI[buf][klane][(rbase + 2 * idx) & 127], *pb = &sJ[buf][klane][wc * 64 + 2 * idx];
+            if (ABL & 128) {
+                float2 a[8], b[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { a[q] = *(const float2 *)(pa + 2 * q * TM); b[q] = *(const float2 *)(pb + 2 * q * TM); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    c00 = M::mma(a[q].x, b[q].x, c00); c01 = M::mma(a[q].x, b[q].y, c01);
+                    if (full) { c10 = M::mma(a[q].y, b[q].x, c10); c11 = M::mma(a[q].y, b[q].y, c11); }
+                }
+            } else {
+                float2 a = *(const float2 *)pa, b = *(const float2 *)pb;
+#pragma unroll
+                for (int kk = 0; kk < PU_BK; kk += 2) {
+                    float2 na = a, nb = b;
+                    if (kk + 2 < PU_BK) { na = *(const float2 *)(pa + (kk + 2) * TM); nb = *(const float2 *)(pb + (kk + 2) * TM); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    c00 = M::mma(a.x, b.x, c00); c01 = M::mma(a.x, b.y, c01);
+                    if (full) { c10 = M::mma(a.y, b.x, c10); c11 = M::mma(a.y, b.y, c11); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    a = na; b = nb;
+                }
+            }
+        } else if (ABL & 256) { // 16-byte reads, two per EIGHT MFMAs, interleaved (garbage values): the K2 layout's instruction stream
+            const float4 *q = reinterpret_cast<const float4 *>(&sI[buf][0][0]) + klane * 64 + idx + wr * 128;
+            const float4 *qj = reinterpret_cast<const float4 *>(&sJ[buf][0][0]) + klane * 64 + idx + wc * 128;
+            float4 a = q[0], b = qj[0];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                float4 na = a, nb = b;
+                if (h + 1 < 4) { na = q[(h + 1) * 256 % 448]; nb = qj[(h + 1) * 256 % 448]; }
+                __builtin_amdgcn_sched_barrier(0);
+                c00 = M::mma(a.x, b.x, c00); c01 = M::mma(a.x, b.z, c01);
+                if (full) { c10 = M::mma(a.z, b.x, c10); c11 = M::mma(a.z, b.z, c11); }
+                c00 = M::mma(a.y, b.y, c00); c01 = M::mma(a.y, b.w, c01);
+                if (full) { c10 = M::mma(a.w, b.y, c10); c11 = M::mma(a.w, b.w, c11); }
+                __builtin_amdgcn_sched_barrier(0);
+                a = na; b = nb;
             }
         } else if (ABL & 32) { // 16x16x4 MFMA shape: 16 accumulators of 4 registers, same LDS read count (garbage values)
             typedef float f4 __attribute__((ext_vector_type(4)));
@@ -344,7 +385,7 @@ template <int ABL>
 static void launch_pu_abl(EkfEngine *e, int m_pad, int m)
 {
     const int n = e->n, nt = (n + 127) / 128;
-    build_units(e, nt, 0, false, m_pad >= 512);
+    build_units(e, nt, 0, false, m_pad >= 512 ? 1 : 0);
     k_pu_abl<ABL><<<e->pu_per_xcd * 8, 256, 0, e->stream>>>((float *)e->d.P, e->ldP, n, (const float *)e->d.A, e->ldP, round_up(m, 16),
                                                             e->pu_per_xcd, (const int4 *)e->d.pu_tilemap);
 }
