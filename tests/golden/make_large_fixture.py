@@ -6,6 +6,7 @@ decision counters of every frame.  Oracle variant: ALGORITHMIC (validated agains
 tests/test_oracle_selfcheck.py).  ORACLE-minted (the reference cannot be built in this image).
 
     python tests/golden/make_large_fixture.py 5000 1
+    python tests/golden/make_large_fixture.py 5000 3     # F > 1: the summary of EVERY frame is kept (keys <name>_t<frame>)
 """
 import os
 import sys
@@ -53,6 +54,12 @@ def main():
         i = o.step(kps, desc, ol.ALGORITHMIC)
         infos.append([i.n_predicted, i.n_matches, i.n_hypotheses, i.n_inliers, i.n_outliers, i.n_rescued, i.status])
         print(f"frame {t}: {infos[-1]}  {time.time() - t0:.1f} s", flush=True)
+        if F > 1:  # per-frame summaries: the GPU test compares after every frame
+            out[f"x13_t{t}"] = o.x13()
+            out[f"feature_pos_t{t}"] = o.feature_pos()
+            for k, v in summary(o.P()).items():
+                if k != "sample_idx":
+                    out[f"{k}_t{t}"] = v
     out["info"] = np.array(infos, dtype=np.int32)
     out["x13"] = o.x13()
     out["feature_pos"] = o.feature_pos()

@@ -36,4 +36,4 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
     pv = cb["parity_vs_oracle"]
-    assert pv["decisions_identical"] is True and pv["P_max_rel"] <= 1e-9 and pv["state_max_rel"] <= 1e-9
+    assert pv["decisions_identical"] is True and pv["P_max_rel"] <= 1e-9 and pv["state_max_rel_componentwise"] <= 1e-9

@@ -158,7 +158,7 @@ def test_fp32_covariance_drift_over_90_frames(eng_mod, oracle_lib):
     pm, pf = rel_max(P, o.P()), rel_fro(P, o.P())
     print(f"fp32 drift after 90 frames: P max {pm:.2e} fro {pf:.2e} blocks {be}")
     assert pm <= F32_TOL and pf <= F32_TOL
-    for name in ("r", "q", "v", "features"):
+    for name in ("r", "q", "v", "features_blockwise"):
         assert be[name] <= F32_TOL, (name, be[name])
     assert be["w"] <= F32_TOL_OMEGA
 

@@ -190,7 +190,7 @@ def test_update_state_and_covariance(eng_mod, oracle_lib, nfeat, precision, tol)
         x, fp, P = e.get_state()
         be = block_errs(x, fp, o.x13(), o.feature_pos())
         assert rel_fro(P, o.P()) <= tol and rel_max(P, o.P()) <= tol
-        assert all(be[k] <= tol for k in ("r", "q", "v", "features")) and be["w"] <= F32_TOL_OMEGA, be
+        assert all(be[k] <= tol for k in ("r", "q", "v", "features_blockwise", "features_componentwise")) and be["w"] <= F32_TOL_OMEGA, be
     _, _, P = e.get_state()
     assert np.array_equal(P, P.T)
 
@@ -333,7 +333,7 @@ def test_n200_fp32_frames_vs_oracle(eng_mod, oracle_lib, path):
         x, fp, P = e.get_state()
         assert rel_fro(P, o.P()) <= F32_TOL and rel_max(P, o.P()) <= F32_TOL, (t, rel_fro(P, o.P()), rel_max(P, o.P()))
         be = block_errs(x, fp, o.x13(), o.feature_pos())
-        assert all(be[k] <= F32_TOL for k in ("r", "q", "v", "features")) and be["w"] <= F32_TOL_OMEGA, (t, be)
+        assert all(be[k] <= F32_TOL for k in ("r", "q", "v", "features_blockwise", "features_componentwise")) and be["w"] <= F32_TOL_OMEGA, (t, be)
 
 
 def _float_descriptor_sequence(nfeat, frames, cols, seed=11):
