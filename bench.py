@@ -228,10 +228,14 @@ def committed_pmc_traffic(workload):
     here = os.path.dirname(os.path.abspath(__file__))
     for path in sorted(glob.glob(os.path.join(here, "profiles", f"r*_pmc_hbm_p_update_{workload}.csv")), reverse=True):
         with open(path) as f:
-            m = re.search(r"# mean per launch: .* total ([0-9.]+) MB", f.read())
+            text = f.read()
+        m = re.search(r"# mean per launch: .* total ([0-9.]+) MB", text)
         if m:
-            return float(m.group(1)) * 1e6, os.path.relpath(path, here)
-    return None, None
+            by_class = {c: {"fetch_MB": float(a), "write_MB": float(b), "total_MB": float(t), "profiled_mean_us": float(u)}
+                        for c, u, a, b, t in re.findall(
+                            r"# class (\S+): launches \d+ mean ([0-9.]+) us fetch ([0-9.]+) MB write ([0-9.]+) MB total ([0-9.]+) MB", text)}
+            return float(m.group(1)) * 1e6, os.path.relpath(path, here), by_class
+    return None, None, {}
 
 
 def main():
@@ -370,8 +374,8 @@ def main():
     elapsed, infos = run(False)
     elapsed = ranks.max_over_ranks(elapsed)
 
-    roof, stages = None, None
-    pmc_traffic = committed_pmc_traffic(args.workload) if args.matcher == "descriptors" else (None, None)
+    roof, stages, roof_sweep = None, None, None
+    pmc_traffic = committed_pmc_traffic(args.workload) if args.matcher == "descriptors" else (None, None, {})
     if not args.no_roofline_pass:
         _, _ = run(True)
         tm = eng.timing_get()
@@ -406,8 +410,33 @@ def main():
                     by_class[name] = {"launches": int(sel.sum()), "mean_m": float(mm[sel].mean()),
                                       "avg_ms": 1e3 * tt / int(sel.sum()), "tflops": fl / tt / 1e12,
                                       "algorithmic_GBps": 2.0 * n_state * n_state * (4 if precision else 8)
-                                      * int(sel.sum()) / tt / 1e9}
+                                      * int(sel.sum()) / tt / 1e9,
+                                      "frac": fl / tt / 1e12 / PEAK_TFLOPS[dtype],
+                                      # HBM bytes per launch of this class from the committed PMC passes over this bench's
+                                      # own timed frames (FETCH_SIZE x2, WRITE_SIZE; null without a profile)
+                                      "traffic": (pmc_traffic[2].get(name) or {}).get("total_MB", None),
+                                      "traffic_detail": pmc_traffic[2].get(name)}
             roof["by_launch_class"] = by_class
+        if roof is not None and hasattr(eng, "sweep_timing"):
+            sw = eng.sweep_timing()
+            if sw["panels"] > 0:
+                # the #2 kernel of the frame: the blocked Cholesky sweep of S (one launch per 32-row panel; the launches also
+                # form B = inv(L) (H P)).  Latency-bound: the figure to watch is us per panel, the flop rate is for scale.
+                fl = sw["flops_fp64"] + sw["flops_b"]
+                roof_sweep = {
+                    "kernel": "k_chol_step (blocked Cholesky of S = H P H' + R, 32-row panels, one launch each; rows of B in the same launches)",
+                    "bound": "latency (dependent launches)",
+                    "us_per_panel": 1e3 * sw["ms"] / sw["panels"],
+                    "panels_per_frame": sw["panels"] / max(int(tm.steps), 1),
+                    "ms_per_frame": sw["ms"] / max(int(tm.steps), 1),
+                    "achieved": fl / (sw["ms"] * 1e-3) / 1e12,
+                    "unit": "TFLOP/s",
+                    "flops_fp64_cholesky": sw["flops_fp64"] / sw["updates"],
+                    "flops_rows_of_B": sw["flops_b"] / sw["updates"],
+                    "updates": sw["updates"],
+                    "floor_note": "scripts/micro/persist_chol.hip: a persistent critical workgroup reaches 7.3 us per panel for the "
+                                  "chain alone (profiles/r03_persist_chol_micro.txt); 4.2 us of a panel are the 32x32 factor-and-invert",
+                }
         st = max(int(tm.steps), 1)
         stages = {k: getattr(tm, k) / st for k in ("prediction_ms", "matching_ms", "ransac_ms", "update_li_ms",
                                                    "rescue_ms", "update_hi_ms")}
@@ -474,6 +503,7 @@ def main():
             "mean_ransac_hypotheses": float(np.mean([i.n_hypotheses for i in infos])),
         },
         "roofline": roof,
+        "roofline_sweep": roof_sweep,
         "stage_ms_per_step": stages,
     }
     if single_ref is not None:

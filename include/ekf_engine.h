@@ -244,6 +244,11 @@ int ekf_synchronize(EkfEngine *e);
 /* Per-launch record of the P-update kernel since the last ekf_timing_reset: rows m of B (k-depth) and the
  * HIP-event duration in ms.  Writes at most `capacity` entries; *count receives the number available. */
 int ekf_timing_p_update_launches(EkfEngine *e, int capacity, int32_t *m_rows, float *ms, int *count);
+/* The blocked Cholesky sweep of S = H P H' + R (replaces S.inv(), EKF/Update.cpp:108) since the last ekf_timing_reset:
+ * HIP-event time over the sweep's launches of every update, their number (panels of 32 rows) and of updates, the fp64
+ * flops of the factorisation (m^3 / 3 each) and the flops of B = inv(L) (H P) formed in the same launches (m^2 n each;
+ * 0 for updates that went through the explicit inverse + GEMM).  Any output pointer may be null. */
+int ekf_timing_sweep(EkfEngine *e, double *kernel_ms, int64_t *panels, int64_t *updates, double *flops_fp64, double *flops_b);
 
 /* -- row-sharded filter (multi-GPU) ----------------------------------------------------------
  * One engine per GPU / rank.  Rank g stores the 13 camera rows of P (replicated, updated identically everywhere)

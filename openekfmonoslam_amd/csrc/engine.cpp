@@ -130,6 +130,10 @@ void ekf_engine_destroy(EkfEngine *e)
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
+    for (auto &pr : e->sw_events) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
     if (e->comm && rccl_api().ok) (void)rccl_api().CommDestroy((ncclComm_t)e->comm);
     if (e->h_mirror) (void)hipHostFree(e->h_mirror);
     if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
@@ -1135,6 +1139,21 @@ static void harvest_pu_events(EkfEngine *e)
     e->pu_events.clear();
     e->pu_work.clear();
     e->pu_m.clear();
+    for (size_t i = 0; i < e->sw_events.size(); ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->sw_events[i].first, e->sw_events[i].second) == hipSuccess) {
+            const double m = std::abs(e->sw_m[i]);
+            e->sweep_ms += ms;
+            e->sweep_panels += ((long long)m + NB - 1) / NB;
+            e->sweep_updates += 1;
+            e->sweep_flops_f64 += m * m * m / 3.0;                        // Cholesky of S
+            if (e->sw_m[i] > 0) e->sweep_flops_b += m * m * (double)e->n;  // B = inv(L) (H P): forward substitution, m^2 n
+        }
+        (void)hipEventDestroy(e->sw_events[i].first);
+        (void)hipEventDestroy(e->sw_events[i].second);
+    }
+    e->sw_events.clear();
+    e->sw_m.clear();
 }
 
 struct StageTimer {
@@ -1702,6 +1721,8 @@ int ekf_timing_reset(EkfEngine *e)
     harvest_pu_events(e);
     e->pu_log.clear();
     std::memset(&e->times, 0, sizeof(e->times));
+    e->sweep_ms = e->sweep_flops_f64 = e->sweep_flops_b = 0.0;
+    e->sweep_panels = e->sweep_updates = 0;
     return EKF_OK;
 }
 
@@ -1711,6 +1732,19 @@ int ekf_timing_get(EkfEngine *e, EkfStageTimes *out)
     (void)hipStreamSynchronize(e->stream);
     harvest_pu_events(e);
     *out = e->times;
+    return EKF_OK;
+}
+
+int ekf_timing_sweep(EkfEngine *e, double *kernel_ms, int64_t *panels, int64_t *updates, double *flops_fp64, double *flops_b)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    (void)hipStreamSynchronize(e->stream);
+    harvest_pu_events(e);
+    if (kernel_ms) *kernel_ms = e->sweep_ms;
+    if (panels) *panels = e->sweep_panels;
+    if (updates) *updates = e->sweep_updates;
+    if (flops_fp64) *flops_fp64 = e->sweep_flops_f64;
+    if (flops_b) *flops_b = e->sweep_flops_b;
     return EKF_OK;
 }
 

@@ -199,6 +199,10 @@ struct EkfEngine {
     std::vector<double> pu_work;                               // n^2 m of each bracket
     std::vector<int> pu_m;                                     // m of each bracket
     std::vector<std::pair<int, float>> pu_log;                 // harvested (m, ms) per launch
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> sw_events;  // brackets of the Cholesky sweep's launches of one update
+    std::vector<int> sw_m;                                     // m of each bracket
+    double sweep_ms = 0.0, sweep_flops_f64 = 0.0, sweep_flops_b = 0.0; // harvested totals (ekf_timing_sweep)
+    long long sweep_panels = 0, sweep_updates = 0;
     // host scratch
     std::vector<int> h_counts;
     int *h_mirror = nullptr, *d_mirror = nullptr; // GPU-writable host page: counters + sequence number (read_counts)

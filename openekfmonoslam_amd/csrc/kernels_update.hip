@@ -189,6 +189,7 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
             double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc, const T *G, T *Bout, int ld,
             int n_bblocks, int n_rhs, int tiles_first, int spacer, unsigned long long *trace, int abl)
 {
+#ifdef EKF_SWEEP_TRACE // debug builds only (scripts/sweep_trace.py): per-role time stamps and role ablations
     const unsigned long long t_in = trace ? wall_clock64() : 0ull;
 #define SWEEP_TRACE(role)                                                                      \
     if (trace && threadIdx.x == 0) {                                                           \
@@ -197,6 +198,11 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         if ((role) == 2) atomicMax(trace + 6, t_in);                                           \
         if ((role) == 3) atomicMax(trace + 7, t_in);                                           \
     }
+#else
+#define SWEEP_TRACE(role)
+    (void)trace;
+    (void)abl;
+#endif
     constexpr int NR = 14; // right-hand sides: nu + 13 camera columns
     // tile role: S_ik, S_jk, L_ik, L_jk; B role: two partial sums, G_k - sum; right-hand sides: R, Z, W
     __shared__ double pool[4][NB][NB + 1];
@@ -234,11 +240,13 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
             b -= n_bblocks + n_rhs;
         }
     }
-    if (abl) { // timing experiments only (scripts/sweep_trace.py): a role returns at once
+#ifdef EKF_SWEEP_TRACE
+    if (abl) { // timing experiments only (scripts/sweep_trace.py): a role returns at once -- WRONG filter results
         if ((abl & 1) && bcol >= 0) return;
         if ((abl & 2) && bcol < 0 && b >= n_stiles) return;
         if ((abl & 4) && bcol < 0 && b > 0 && b < n_stiles) return;
     }
+#endif
     // every global load of the prologue is issued before the first LDS store waits on one of them (the look-ahead
     // workgroup's inputs are cold: they were written by the previous launch on other XCDs)
     double gv[4];
@@ -652,9 +660,12 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
 #undef SWEEP_TRACE
 }
 
-// Debug aid (scripts/sweep_trace.py): per launch of the sweep, the earliest workgroup start and the latest end of each
-// role (0 look-ahead published, 1 row block of B, 2 tiles, 3 right-hand sides), in 10 ns ticks of the constant clock.
+// Debug aid (scripts/sweep_trace.py), compiled only with -DEKF_SWEEP_TRACE (EKF_EXTRA_FLAGS of openekfmonoslam_amd/build.py):
+// per launch of the sweep, the earliest workgroup start and the latest end of each role (0 look-ahead published, 1 row
+// block of B, 2 tiles, 3 right-hand sides), in 10 ns ticks of the constant clock.  The state below is process-global and
+// the ablation bits (enable >> 8) make roles return early: it is NOT part of the product library.
 constexpr int TRACE_SLOTS = 8, TRACE_MAX = 4096;
+#ifdef EKF_SWEEP_TRACE
 static unsigned long long *g_trace = nullptr;
 static int g_trace_n = 0;
 static int g_trace_abl = 0;
@@ -678,6 +689,7 @@ extern "C" int ekf_debug_sweep_trace(int enable, unsigned long long *out, int *c
     if (!enable && g_trace) { (void)hipFree(g_trace); g_trace = nullptr; }
     return 0;
 }
+#endif
 
 // ------------------------------------------------------------------------------- inverse of a diagonal chunk of L
 // X_cc = inverse of the 128 x 128 diagonal block of L that a chunk of 4 panels covers, by block columns:
@@ -1161,6 +1173,12 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts);
     }
     const int n_bblocks = b_in_sweep ? n_pad / NB : 0; // row block k of B = inv(L) G rides in the launch of panel k
+    hipEvent_t sw0 = nullptr, sw1 = nullptr;
+    if (e->timing) { // the sweep's launches of this update, bracketed on the engine's stream (ekf_timing_sweep)
+        (void)hipEventCreate(&sw0);
+        (void)hipEventCreate(&sw1);
+        (void)hipEventRecord(sw0, s);
+    }
     for (int k0 = 0; k0 < m; k0 += NB) {
         const int kb = min(NB, m - k0);
         const int k1 = k0 + kb;
@@ -1170,18 +1188,27 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const int n_rhs_blocks = max(1, (m - k1 + 63) / 64); // right-hand-side blocks, 64 rows each
         const int n_wgs = n_stiles + n_rhs_blocks + n_bblocks;
         unsigned long long *tr = nullptr;
+        int tr_abl = 0;
+#ifdef EKF_SWEEP_TRACE
         if (g_trace && g_trace_n < TRACE_MAX) {
             tr = g_trace + (size_t)TRACE_SLOTS * g_trace_n++;
             static unsigned long long tags[TRACE_MAX];
             tags[g_trace_n - 1] = ((unsigned long long)k0 << 32) | (unsigned long long)m;
             (void)hipMemcpyAsync(tr + 5, &tags[g_trace_n - 1], sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+            tr_abl = g_trace_abl;
         }
+#endif
         const int spacer = n_wgs > e->n_cus ? e->n_cus : 0; // see k_chol_step: empty blocks where the look-ahead workgroup's CU comes round again
         const int n_spacers = spacer ? (n_wgs - 1) / (spacer - 1) : 0; // blocks spacer, 2 spacer, ... among n_wgs + n_spacers
         k_chol_step<T><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(T) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles,
                                                                            V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
                                                                            e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks,
-                                             n_wgs > e->n_cus ? 1 : 0, spacer, tr, tr ? g_trace_abl : 0);
+                                             n_wgs > e->n_cus ? 1 : 0, spacer, tr, tr_abl);
+    }
+    if (e->timing) {
+        (void)hipEventRecord(sw1, s);
+        e->sw_events.emplace_back(sw0, sw1);
+        e->sw_m.push_back(b_in_sweep ? m : -m); // negative: the rows of B were not formed in these launches
     }
     // inv(L): the 128 x 128 diagonal chunks in one launch, then by doubling 128 -> 256 -> ... until one block covers all rows
     const bool need_inverse = !b_in_sweep;

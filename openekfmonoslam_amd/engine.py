@@ -99,6 +99,8 @@ ABI = {
     "ekf_timing_get": (_i, [_vp, C.POINTER(EkfStageTimes)]),
     "ekf_synchronize": (_i, [_vp]),
     "ekf_timing_p_update_launches": (_i, [_vp, _i, _vp, _vp, C.POINTER(_i)]),
+    "ekf_timing_sweep": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                              C.POINTER(C.c_double)]),
     "ekf_shard_rows": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "ekf_engine_create_sharded": (_i, [C.POINTER(EkfEngineConfig), _i, _i, C.POINTER(_vp)]),
     "ekf_set_exchange": (_i, [_vp, _vp, _vp]),
@@ -494,6 +496,14 @@ class EkfEngine:
         ms = np.zeros(max(k.value, 1), dtype=np.float32)
         self._chk(self.L.ekf_timing_p_update_launches(self.h, k.value, _p(m), _p(ms), C.byref(k)))
         return m[: k.value], ms[: k.value]
+
+    def sweep_timing(self):
+        """dict: HIP-event ms over the Cholesky sweep's launches, panels, updates, fp64 flops of the factorisations, flops of
+        the rows of B formed in the same launches (since the last timing_reset)."""
+        ms, fl64, flb = C.c_double(0), C.c_double(0), C.c_double(0)
+        panels, updates = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.ekf_timing_sweep(self.h, C.byref(ms), C.byref(panels), C.byref(updates), C.byref(fl64), C.byref(flb)))
+        return {"ms": ms.value, "panels": panels.value, "updates": updates.value, "flops_fp64": fl64.value, "flops_b": flb.value}
 
     def synchronize(self):
         self._chk(self.L.ekf_synchronize(self.h))

@@ -8,8 +8,7 @@ python bench.py --workload n200_f64 --steps 60 --warmup 10 > "$out/bench_n200_f6
 python bench.py --workload n1000_f64 --steps 20 --warmup 5 > "$out/bench_n1000_f64.json" 2> /dev/null
 python bench.py --workload n2000_f32 --steps 20 --warmup 5 > "$out/bench_n2000_f32.json" 2> /dev/null
 python bench.py --workload n5000_f32 --steps 3 --warmup 1 > "$out/bench_n5000_f32.json" 2> /dev/null
-python scripts/sweep_trace.py 1000 15 > "$out/sweep_trace_n1000_f32.txt" 2>&1
-python scripts/sweep_trace.py 2000 8 > "$out/sweep_trace_n2000_f32.txt" 2>&1
+# the per-role sweep trace needs a debug build (scripts/sweep_trace.py); it is not part of the round's standard artifacts
 bash scripts/profile_all.sh "$out/prof"
 for w in n1000_f32 n200_f64 n2000_f32 n5000_f32; do
   db=$(find "$out/prof/$w" -name "*.db" | head -1)
@@ -20,6 +19,6 @@ bash scripts/pmc_p_update.sh "$out/pmc"
 dbs=""
 for i in 1 2 3 4; do dbs="$dbs $(find $out/pmc/pass$i -name '*.db' | head -1)"; done
 python3 scripts/profile_summary.py pmc_sq "$out/pmc_sq_p_update_n1000_f32.csv" $dbs
-python3 scripts/profile_summary.py pmc "$(find $out/pmc/pass5 -name '*.db' | head -1)" "$(find $out/pmc/pass6 -name '*.db' | head -1)" "$out/pmc_hbm_p_update_n1000_f32.csv"
+python3 scripts/profile_summary.py pmc "$(find $out/pmc/pass5 -name '*.db' | head -1)" "$(find $out/pmc/pass6 -name '*.db' | head -1)" "$out/pmc_hbm_p_update_n1000_f32.csv" 21
 rm -rf "$out/pmc"/pass*/ 
 tail -3 "$out/pytest_gpu.log"; tail -c 600 "$out/bench_n1000_f32.json"

@@ -1,5 +1,8 @@
 """Per-launch timeline of the Cholesky sweep (GPU box): for one steady-state frame, when each role of a k_chol_step launch
-ends relative to the launch's first workgroup.  usage: sweep_trace.py [N] [warm frames]"""
+ends relative to the launch's first workgroup.  usage: sweep_trace.py [N] [warm frames]
+Needs a DEBUG build of the engine (the trace and its role ablations are not in the product library):
+    EKF_EXTRA_FLAGS=-DEKF_SWEEP_TRACE python -c "from openekfmonoslam_amd import build; build.build_engine(force=True)"
+(scripts/build_variant.sh-style: build it into variants/ and point EKF_ENGINE_LIB at it)."""
 import ctypes as C
 import os
 import sys
@@ -18,6 +21,8 @@ e = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 
 e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
 e.set_update_path(int(os.environ.get('UPDATE_PATH', '0')))
 L = engine.load_library()
+if not hasattr(L, "ekf_debug_sweep_trace"):
+    sys.exit("this libekf_engine.so was built without -DEKF_SWEEP_TRACE (see the docstring)")
 fn = L.ekf_debug_sweep_trace
 fn.restype = C.c_int
 fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
