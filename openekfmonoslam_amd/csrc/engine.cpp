@@ -115,7 +115,7 @@ void ekf_engine_destroy(EkfEngine *e)
     DeviceArrays &d = e->d;
     void *ptrs[] = {d.state,     d.feat_pos,  d.feat_type, d.feat_covpos, d.feat_desc, d.feat_times_predicted, d.feat_times_matched, d.P, d.P2, d.mm_scratch, d.mm_index,        d.pred_vis, d.pred_vis_full, d.step_preds,
                     d.pred_uv,   d.pred_vis2, d.pred_uv2,  d.pred_S,      d.Hs,        d.Hf,       d.HP,
-                    d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts,    d.kps,      d.kdesc,
+                    d.work_idx,  d.work_flag, d.plist,     d.plist_sub,   d.counts, d.shard_feat,    d.kps,      d.kdesc,
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
                     d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.W, d.Wf, d.G, d.LL, d.LLf, d.Tbuf, d.gates, d.cell_resp, d.cell_xy,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.sq_part, d.diag_save, d.cam_part, d.cam_save, d.HPc, d.Gc, d.Bc, d.zvec, d.yvec,
@@ -233,6 +233,7 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     ALLOC(d.plist, cap);
     ALLOC(d.plist_sub, cap);
     ALLOC(d.counts, CNT_COUNT);
+    ALLOC(d.shard_feat, MAX_SHARD_WORLD + 1);
     ALLOC(d.kps, (size_t)e->kcap);
     ALLOC(d.kdesc, (size_t)e->kcap * e->desc_bytes);
     ALLOC(d.mt_valid, cap);
@@ -301,6 +302,7 @@ int ekf_engine_create(const EkfEngineConfig *cfg, EkfEngine **out) { return crea
 
 int ekf_engine_create_sharded(const EkfEngineConfig *cfg, int rank, int world, EkfEngine **out)
 {
+    if (world > MAX_SHARD_WORLD) return EKF_ERR_INVALID_ARG;
     return create_impl(cfg, rank, world, out);
 }
 
@@ -419,6 +421,8 @@ static void refresh_row_map(EkfEngine *e)
     const int f0 = e->shard_feat_begin[e->shard_rank], f1 = e->shard_feat_begin[e->shard_rank + 1];
     auto row_of = [&](int f) { return f < N ? e->h_covpos[f] : e->n; };
     e->rm = RowMap{row_of(f0), row_of(f1), SHARD_BASE};
+    (void)hipMemcpyAsync(e->d.shard_feat, e->shard_feat_begin.data(), (size_t)(W + 1) * sizeof(int), hipMemcpyHostToDevice, e->stream);
+    (void)hipStreamSynchronize(e->stream); // the host vector may be reassigned before the copy would otherwise run
 }
 
 #define NOT_WHEN_SHARDED(e)                                                \
@@ -874,8 +878,28 @@ int ekf_predict(EkfEngine *e)
     return check_async(e);
 }
 
-// device-side core of predictCameraMeasurements; leaves the count in h_counts
-static int predict_measurements_dev(EkfEngine *e, const int *d_idx, int count, int *n_out, bool count_predicted = false)
+// Sharded filter: the FULL exchange of the H.P table (2N x ldP: 192 MB at N = 2000, 1.2 GB at N = 5000 in fp32) and of its
+// fp64 camera columns -- what rounds 1-2 did after every prediction.  EKF::step no longer needs it (see `lean` below); the
+// stateless stage calls of the ABI (ekf_ransac / ekf_update / ... on a caller-ordered match list) still do.
+static int complete_hp_table(EkfEngine *e)
+{
+    if (e->shard_world <= 1 || e->hp_complete) return EKF_OK;
+    int rc;
+    std::vector<int32_t> rb(e->shard_world + 1);
+    for (int r = 0; r <= e->shard_world; ++r) rb[r] = 2 * e->shard_feat_begin[r];
+    if ((rc = exchange_rows(e, EKF_XCHG_HP, e->d.HP, (size_t)e->ldP * (e->f32 ? 4 : 8), rb, "the H.P row blocks"))) return rc;
+    if (e->f32 && (rc = exchange_rows(e, EKF_XCHG_HPC, e->d.HPc, 16 * sizeof(double), rb, "the fp64 camera columns of H.P"))) return rc;
+    e->hp_complete = true;
+    return EKF_OK;
+}
+
+// device-side core of predictCameraMeasurements; leaves the count in h_counts.
+// lean (sharded EKF::step): only the 2x2 innovation blocks S_i travel after a prediction (32 bytes per feature; every rank
+// gates and matches all predictions).  The H.P rows stay with their owners until somebody consumes them: the rows of a
+// RANSAC batch's hypotheses (ransac_dev) and the rows of the matches an update selects (lean_gather_exchange) -- 2M of
+// the 2N rows, and for the outlier re-prediction nothing but the S_i (missing 2a / EKF.cpp:473).
+static int predict_measurements_dev(EkfEngine *e, const int *d_idx, int count, int *n_out, bool count_predicted = false,
+                                    bool lean = false)
 {
     launch_predict_features(e, d_idx, d_idx ? count : e->N, false);
     int rc = read_counts(e);
@@ -885,11 +909,10 @@ static int predict_measurements_dev(EkfEngine *e, const int *d_idx, int count, i
     if (!d_idx) e->n_pred = np;
     *n_out = np;
     if (e->shard_world > 1 && np > 0) {
-        // every rank wrote the H.P rows and S_i of the features it owns: complete both tables
+        // every rank wrote the H.P rows and S_i of the features it owns
+        e->hp_complete = false;
+        if (!lean && (rc = complete_hp_table(e))) return rc;
         std::vector<int32_t> rb(e->shard_world + 1);
-        for (int r = 0; r <= e->shard_world; ++r) rb[r] = 2 * e->shard_feat_begin[r];
-        if ((rc = exchange_rows(e, EKF_XCHG_HP, e->d.HP, (size_t)e->ldP * (e->f32 ? 4 : 8), rb, "the H.P row blocks"))) return rc;
-        if (e->f32 && (rc = exchange_rows(e, EKF_XCHG_HPC, e->d.HPc, 16 * sizeof(double), rb, "the fp64 camera columns of H.P"))) return rc;
         for (int r = 0; r <= e->shard_world; ++r) rb[r] = e->shard_feat_begin[r];
         if ((rc = exchange_rows(e, EKF_XCHG_PRED_S, e->d.pred_S, 4 * sizeof(double), rb, "the innovation covariance blocks"))) return rc;
     }
@@ -1009,13 +1032,31 @@ int ekf_match(EkfEngine *e, const EkfKeypoint *kps, const uint8_t *desc32, int n
     return EKF_OK;
 }
 
-// RANSAC over e->d.matches[0..M); on return best_flags holds the inlier mask, h_counts the loop state
-static int ransac_dev(EkfEngine *e, int M)
+// RANSAC over e->d.matches[0..M); on return best_flags holds the inlier mask, h_counts the loop state.
+// lean (sharded EKF::step, feature-ordered match list): a batch's hypotheses use the H.P rows of THEIR features as gain
+// columns; those features lie between the batch's first and last featureIndex, so that slice of the table is completed
+// before the batch runs (~80 rows instead of 2N; one batch is the rule).
+static int ransac_dev(EkfEngine *e, int M, bool lean = false)
 {
     launch_ransac_init(e, M);
     launch_match_index(e, M);
     const int batch = e->cfg.ransac_batch;
     for (int h0 = 0; h0 < M; h0 += batch) {
+        if (lean && e->shard_world > 1 && !e->hp_complete) {
+            const int h1 = std::min(M, h0 + batch);
+            launch_slice_bounds(e, e->d.matches, h0, h1);
+            int rc = read_counts(e);
+            if (rc) return rc;
+            const int f_lo = e->h_counts[CNT_AUX0], f_hi = e->h_counts[CNT_AUX1];
+            if (f_lo < 0 || f_hi < f_lo || f_hi >= e->N) {
+                e->err = "sharded RANSAC: the match list is not in feature order";
+                return EKF_ERR_INVALID_ARG;
+            }
+            std::vector<int32_t> rb(e->shard_world + 1);
+            for (int r = 0; r <= e->shard_world; ++r) rb[r] = 2 * std::min(std::max(e->shard_feat_begin[r], f_lo), f_hi + 1);
+            if ((rc = exchange_rows(e, EKF_XCHG_HP, e->d.HP, (size_t)e->ldP * (e->f32 ? 4 : 8), rb, "the H.P rows of a RANSAC batch"))) return rc;
+            if (e->f32 && (rc = exchange_rows(e, EKF_XCHG_HPC, e->d.HPc, 16 * sizeof(double), rb, "their fp64 camera columns"))) return rc;
+        }
         launch_ransac_batch(e, M, h0, batch);
         int rc = read_counts(e);
         if (rc) return rc;
@@ -1047,6 +1088,7 @@ int ekf_ransac(EkfEngine *e, const EkfMatch *matches, int M, uint8_t *inlier_mas
     if (M == 0) return EKF_OK;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->d.matches, matches, (size_t)M * sizeof(EkfMatch), hipMemcpyHostToDevice, e->stream));
+    if ((rc = complete_hp_table(e))) return rc; // a sharded step leaves the H.P table with the owners' rows only
     rc = ransac_dev(e, M);
     if (rc) return rc;
     HIPCHK(hipMemcpy(inlier_mask, e->d.best_flags, (size_t)M, hipMemcpyDeviceToHost));
@@ -1054,14 +1096,41 @@ int ekf_ransac(EkfEngine *e, const EkfMatch *matches, int M, uint8_t *inlier_mas
     return EKF_OK;
 }
 
-// update with the matches in e->d.msel[0..M)
-static int update_dev(EkfEngine *e, int M, bool update_cov)
+// Sharded EKF::step: k_gather has copied the H.P rows of the selected matches out of this rank's table, of which only the
+// rows of OWNED features are valid.  The list is in feature order, so rank r's rows are rows [shard_rb[r], shard_rb[r+1])
+// of the gathered matrix: the usual row-block exchange completes it (and the fp64 camera columns beside it).
+static int lean_gather_exchange(EkfEngine *e, int M)
+{
+    (void)M;
+    int rc;
+    if ((rc = exchange_rows(e, EKF_XCHG_HP, e->d.G, (size_t)e->ldP * (e->f32 ? 4 : 8), e->shard_rb, "the gathered H.P rows"))) return rc;
+    if (e->f32 && (rc = exchange_rows(e, EKF_XCHG_HPC, e->d.Gc, 16 * sizeof(double), e->shard_rb, "their fp64 camera columns"))) return rc;
+    return EKF_OK;
+}
+
+// update with the matches in e->d.msel[0..M); lean: see lean_gather_exchange
+static int update_dev(EkfEngine *e, int M, bool update_cov, bool lean = false)
 {
     if (M <= 0) return EKF_OK; // Update.cpp:292
+    lean = lean && e->shard_world > 1 && !e->hp_complete;
+    if (lean) { // where each rank's run of the (feature-ordered) selected matches starts
+        launch_shard_bounds(e, e->d.msel, M);
+        int rc = read_counts(e);
+        if (rc) return rc;
+        e->shard_rb.assign(e->shard_world + 1, 0);
+        for (int r = 0; r <= e->shard_world; ++r) e->shard_rb[r] = 2 * e->h_counts[CNT_SHARD0 + r];
+        if (e->shard_rb[0] != 0 || e->shard_rb[e->shard_world] != 2 * M) {
+            e->err = "sharded update: the match list is not in feature order";
+            return EKF_ERR_INVALID_ARG;
+        }
+    }
     EkfMatch *save = e->d.matches;
     e->d.matches = e->d.msel;
+    e->after_gather = lean ? lean_gather_exchange : nullptr;
     launch_update(e, M, update_cov);
+    e->after_gather = nullptr;
     e->d.matches = save;
+    if (e->hook_rc) return e->hook_rc;
     return check_async(e);
 }
 
@@ -1086,6 +1155,7 @@ int ekf_update(EkfEngine *e, const EkfMatch *matches, int M)
     if (M == 0) return EKF_OK;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->d.msel, matches, (size_t)M * sizeof(EkfMatch), hipMemcpyHostToDevice, e->stream));
+    if ((rc = complete_hp_table(e))) return rc;
     rc = update_dev(e, M, true);
     if (rc) return rc;
     return finish_update(e);
@@ -1099,6 +1169,7 @@ int ekf_update_only_state(EkfEngine *e, const EkfMatch *matches, int M)
     if (M == 0) return EKF_OK;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->d.msel, matches, (size_t)M * sizeof(EkfMatch), hipMemcpyHostToDevice, e->stream));
+    if ((rc = complete_hp_table(e))) return rc;
     rc = update_dev(e, M, false);
     if (rc) return rc;
     return finish_update(e);
@@ -1206,7 +1277,8 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
     // 1-2. prediction (:273-284)
     launch_predict(e);
     int np = 0;
-    if ((rc = predict_measurements_dev(e, nullptr, e->N, &np, true))) return rc; // + timesPredicted++ (EKF.cpp:572)
+    const bool lean = e->shard_world > 1; // sharded: rows of H.P travel when consumed, not after every prediction
+    if ((rc = predict_measurements_dev(e, nullptr, e->N, &np, true, lean))) return rc; // + timesPredicted++ (EKF.cpp:572)
     li.n_predicted = np;
     tm.mark();
     // 4. matching (:337)
@@ -1217,7 +1289,7 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
     // 6. 1-point RANSAC (:402); predictions/Jacobians are looked up by featureIndex (:368-392)
     int ni = 0, no = 0;
     if (M > 0) {
-        if ((rc = ransac_dev(e, M))) return rc;
+        if ((rc = ransac_dev(e, M, lean))) return rc;
         li.n_hypotheses = e->h_counts[CNT_RS_NEXT];
         ni = e->h_counts[CNT_RS_BEST];
         no = M - ni;
@@ -1228,13 +1300,13 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
     li.n_outliers = no;
     tm.mark();
     // 7. low-innovation update (:430)
-    if ((rc = update_dev(e, ni, true))) return rc;
+    if ((rc = update_dev(e, ni, true, lean))) return rc;
     tm.mark();
     // 8-9. re-predict the outliers with the updated state / covariance, rescue (:473-506)
     int nr = 0;
     if (no > 0) {
         int nop = 0;
-        if ((rc = predict_measurements_dev(e, e->d.work_idx, no, &nop))) return rc;
+        if ((rc = predict_measurements_dev(e, e->d.work_idx, no, &nop, false, lean))) return rc;
         if (e->h_counts[CNT_ERR]) status = e->h_counts[CNT_ERR];
         if (nop > 0) {
             EkfMatch *save = e->d.matches;
@@ -1249,7 +1321,7 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
     li.n_rescued = nr;
     tm.mark();
     // 10. high-innovation update (:529-532)
-    if ((rc = update_dev(e, nr, true))) return rc;
+    if ((rc = update_dev(e, nr, true, lean))) return rc;
     tm.mark();
     if ((rc = read_counts(e))) return rc;
     if (e->h_counts[CNT_ERR]) {

@@ -42,8 +42,13 @@ enum {
     CNT_RS_NEXT,      // RANSAC: next hypothesis to examine
     CNT_RS_DONE,      // RANSAC: loop finished
     CNT_NRESC,        // rescued count
-    CNT_COUNT = 16
+    CNT_AUX0,         // sharded filter: featureIndex of the first / last hypothesis of a RANSAC batch (k_slice_bounds)
+    CNT_AUX1,
+    CNT_SHARD0,       // sharded filter: CNT_SHARD0 + r = first entry of a feature-sorted match list that rank r owns
+                      // (r = 0 .. world, at most 16 ranks: slots 12 .. 28; k_shard_bounds)
+    CNT_COUNT = 32
 };
+constexpr int MAX_SHARD_WORLD = 16;
 
 // doubles in the device state block
 enum { ST_X = 0, ST_R = 13, ST_F = 32, ST_GQG = 32 + 169, ST_JN = 32 + 338, ST_COUNT = 32 + 338 + 16 };
@@ -78,6 +83,7 @@ struct DeviceArrays {
     int *plist = nullptr;      // compacted feature indices, full prediction
     int *plist_sub = nullptr;  // compacted feature indices, subset prediction
     int *counts = nullptr;     // CNT_COUNT ints
+    int *shard_feat = nullptr; // sharded filter: first feature of every rank, world + 1 ints
     // keypoints of the current frame
     EkfKeypoint *kps = nullptr;
     uint8_t *kdesc = nullptr;
@@ -169,6 +175,10 @@ struct EkfEngine {
     std::vector<int> shard_feat_begin;   // [world + 1] first feature of each rank
     EkfExchangeFn xchg = nullptr;        // all-gather of per-feature row blocks between the ranks
     void *comm = nullptr;                // ncclComm_t of the in-engine transport (ekf_comm_init), or null
+    bool hp_complete = true;             // sharded: the H.P table holds EVERY rank's rows since the last prediction
+    int (*after_gather)(EkfEngine *, int) = nullptr; // sharded step: completes the gathered rows right after k_gather
+    int hook_rc = 0;                     // its status (launch_update returns nothing)
+    std::vector<int32_t> shard_rb;       // row boundaries of the gathered rows by owner (from CNT_SHARD0..)
     void *xchg_user = nullptr;
     int n_cus = 256;           // compute units of the device (launch-shape decisions)
     int b_path = 0;            // ekf_set_update_path: 0 by size (B_SWEEP_MAX), 1 B in the sweep, 2 inverse + GEMM
@@ -264,6 +274,10 @@ void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_pred
 void launch_match(EkfEngine *e, int n_pred, int n_kp, const int *d_npred = nullptr);
 // d_M != nullptr (RANSAC launchers): M is an upper bound, the number of matches is read on the device
 void launch_match_index(EkfEngine *e, int M, const int *d_M = nullptr);
+// sharded filter: per-rank boundaries of a feature-sorted match list -> counts[CNT_SHARD0 ..]; featureIndex of list[h0] and
+// list[h1 - 1] -> counts[CNT_AUX0], counts[CNT_AUX1]
+void launch_shard_bounds(EkfEngine *e, const EkfMatch *list, int count);
+void launch_slice_bounds(EkfEngine *e, const EkfMatch *list, int h0, int h1);
 // publish_seq > 0: the batch's bookkeeping kernel also publishes the counter block (see publish_counts_block)
 void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M = nullptr, int publish_seq = 0);
 void launch_ransac_init(EkfEngine *e, int M);

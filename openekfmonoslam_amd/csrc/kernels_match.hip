@@ -250,6 +250,39 @@ void launch_partition(EkfEngine *e, const EkfMatch *src, int M, const uint8_t *f
 
 
 
+// Sharded filter.  The match lists of a step are in feature order (predictions are compacted in feature
+// order, partitions are stable) and features are dealt to the ranks in contiguous index ranges, so the entries a rank owns
+// form ONE run of the list: thread r finds where rank r's run starts (lower bound of its first feature).
+__global__ void k_shard_bounds(const EkfMatch *list, int count, const int *feat_begin, int world, int *counts)
+{
+    const int r = threadIdx.x;
+    if (r > world) return;
+    const int f = feat_begin[r];
+    int lo = 0, hi = count;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (list[mid].featureIndex < f) lo = mid + 1;
+        else hi = mid;
+    }
+    counts[CNT_SHARD0 + r] = lo;
+}
+
+void launch_shard_bounds(EkfEngine *e, const EkfMatch *list, int count)
+{
+    k_shard_bounds<<<1, 64, 0, e->stream>>>(list, count, e->d.shard_feat, e->shard_world, e->d.counts);
+}
+
+__global__ void k_slice_bounds(const EkfMatch *list, int h0, int h1, int *counts)
+{
+    counts[CNT_AUX0] = list[h0].featureIndex;
+    counts[CNT_AUX1] = list[h1 - 1].featureIndex;
+}
+
+void launch_slice_bounds(EkfEngine *e, const EkfMatch *list, int h0, int h1)
+{
+    if (h1 > h0) k_slice_bounds<<<1, 1, 0, e->stream>>>(list, h0, h1, e->d.counts);
+}
+
 __global__ void __launch_bounds__(256) k_outlier_idx(const EkfMatch *src, int M, int *idx)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;

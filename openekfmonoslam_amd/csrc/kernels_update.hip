@@ -1167,6 +1167,9 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
                                          e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc);
     }
+    // sharded step: every rank gathered the rows of the matches it owns; the others arrive here (engine.cpp)
+    e->hook_rc = e->after_gather ? e->after_gather(e, M) : 0;
+    if (e->hook_rc) return;
     {
         dim3 grid((M + 15) / 16, (M + 15) / 16);
         k_assemble_S<T><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
