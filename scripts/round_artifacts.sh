@@ -8,6 +8,8 @@ python bench.py --workload n200_f64 --steps 60 --warmup 10 > "$out/bench_n200_f6
 python bench.py --workload n1000_f64 --steps 20 --warmup 5 > "$out/bench_n1000_f64.json" 2> /dev/null
 python bench.py --workload n2000_f32 --steps 20 --warmup 5 > "$out/bench_n2000_f32.json" 2> /dev/null
 python bench.py --workload n5000_f32 --steps 3 --warmup 1 > "$out/bench_n5000_f32.json" 2> /dev/null
+python bench.py --matcher ncc --workload n2000_f32 --steps 20 --warmup 5 > "$out/bench_n2000_f32_ncc.json" 2> /dev/null
+scripts/micro/pu_bench 1000 298,1014,2000 15 > "$out/pu_bench.txt" 2>&1
 # the per-role sweep trace needs a debug build (scripts/sweep_trace.py); it is not part of the round's standard artifacts
 bash scripts/profile_all.sh "$out/prof"
 for w in n1000_f32 n200_f64 n2000_f32 n5000_f32; do
@@ -15,6 +17,10 @@ for w in n1000_f32 n200_f64 n2000_f32 n5000_f32; do
   [ -n "$db" ] && python3 scripts/profile_summary.py stats "$db" "$out/kernel_stats_$w.csv"
   rm -rf "$out/prof/$w"
 done
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$out/prof/ncc" -- python3 "$root/bench.py" --matcher ncc --workload n2000_f32 --steps 12 --warmup 3 --no-cpu-baseline > /dev/null 2>&1 )
+db=$(find "$out/prof/ncc" -name "*.db" | head -1)
+[ -n "$db" ] && python3 scripts/profile_summary.py stats "$db" "$out/kernel_stats_n2000_f32_ncc.csv"
+rm -rf "$out/prof/ncc"
 bash scripts/pmc_p_update.sh "$out/pmc"
 dbs=""
 for i in 1 2 3 4; do dbs="$dbs $(find $out/pmc/pass$i -name '*.db' | head -1)"; done
