@@ -568,13 +568,15 @@ static void build_units(EkfEngine *e, int nt, int nrt, bool rect, int order)
     e->pu_tables[key] = std::make_pair(e->d.pu_tilemap, per);
 }
 
+int g_pu_stagger_override = -1; // scripts/micro/pu_bench.hip only
+
 template <typename T>
 static void launch_p_update_t(EkfEngine *e, int m_pad, int grid, const int4 *tm, bool avg, bool rect)
 {
     hipStream_t s = e->stream;
     T *P = (T *)e->d.P;
     const T *B = (const T *)e->d.A;
-    const int stagger = (m_pad < 512 && grid >= 768) ? 80 : 0;
+    const int stagger = g_pu_stagger_override >= 0 ? g_pu_stagger_override : ((m_pad < 512 && grid >= 768) ? 80 : 0);
     if constexpr (sizeof(T) == 4 && PU_F32_PAIRS) {
         if (rect) k_p_update_f32<false, true><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger);
         else if (avg) k_p_update_f32<true, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger);

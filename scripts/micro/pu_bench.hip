@@ -68,6 +68,11 @@ int main(int argc, char **argv)
     // shipped: launch_p_update's own choice of split and order; the others force one
     variants.push_back({"shipped", [](EkfEngine *en, int m_pad, int m) { en->pu_slots = 0; launch_p_update(en, m_pad, m); }});
     variants.push_back({"legacy_split", [](EkfEngine *en, int m_pad, int m) { en->pu_slots = -1; g_pu_order_override = m_pad >= 512 ? 1 : 0; launch_p_update(en, m_pad, m); g_pu_order_override = -1; }});
+    if (getenv("PU_STAGGER")) {
+        static const int vals[] = {0, 40, 60, 120, 160, 240};
+        for (int v : vals)
+            variants.push_back({"stagger" + std::to_string(v), [v](EkfEngine *en, int m_pad, int m) { en->pu_slots = 0; g_pu_stagger_override = v; launch_p_update(en, m_pad, m); g_pu_stagger_override = -1; }});
+    }
     if (getenv("PU_ORDERS")) {
         variants.push_back({"bal_halves_first", [](EkfEngine *en, int m_pad, int m) { en->pu_slots = 0; g_pu_order_override = 1; launch_p_update(en, m_pad, m); g_pu_order_override = -1; }});
         variants.push_back({"bal_mixed_HFH", [](EkfEngine *en, int m_pad, int m) { en->pu_slots = 0; g_pu_order_override = 2; launch_p_update(en, m_pad, m); g_pu_order_override = -1; }});
