@@ -37,3 +37,37 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
     pv = cb["parity_vs_oracle"]
     assert pv["decisions_identical"] is True and pv["P_max_rel"] <= 1e-9 and pv["state_max_rel_componentwise"] <= 1e-9
+    # round 3: the #2 kernel of the frame is on the line too, and every launch class of the downdate carries its fraction
+    sw = d["roofline_sweep"]
+    assert sw["us_per_panel"] > 0 and sw["panels_per_frame"] > 0 and sw["updates"] > 0 and sw["achieved"] > 0
+    assert abs(sw["ms_per_frame"] - 1e-3 * sw["us_per_panel"] * sw["panels_per_frame"]) <= 1e-9
+    for name, c in roof["by_launch_class"].items():
+        assert name in ("m>=512", "m<512") and 0 < c["frac"] <= 1.0 and "traffic" in c
+    assert d["parity_ok"] is True
+
+
+def test_sweep_timing_through_the_abi():
+    """ekf_timing_sweep: HIP-event time, panels and flops of the Cholesky sweep of every update since the last reset."""
+    import numpy as np  # noqa: F401
+
+    from openekfmonoslam_amd import engine
+    from openekfmonoslam_amd.synth import SyntheticSequence
+
+    seq = SyntheticSequence(50, 3)
+    e = engine.EkfEngine(seq.cam, seq.par, 50, max_keypoints=264, precision=1)
+    e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    e.timing(True)
+    e.timing_reset()
+    infos = [e.step(*seq.frames[t]) for t in range(3)]
+    sw = e.sweep_timing()
+    updates = sum((1 if i.n_inliers > 0 else 0) + (1 if i.n_rescued > 0 else 0) for i in infos)
+    panels = sum(-(-2 * i.n_inliers // 32) + -(-2 * i.n_rescued // 32) for i in infos)
+    assert sw["updates"] == updates and sw["panels"] == panels and sw["ms"] > 0
+    n = 13 + 6 * 50
+    fl = sum((2.0 * M) ** 3 / 3.0 for i in infos for M in (i.n_inliers, i.n_rescued) if M > 0)
+    assert abs(sw["flops_fp64"] - fl) <= 1e-9 * fl
+    flb = sum((2.0 * M) ** 2 * n for i in infos for M in (i.n_inliers, i.n_rescued) if M > 0)
+    assert abs(sw["flops_b"] - flb) <= 1e-9 * flb
+    e.timing_reset()
+    assert e.sweep_timing()["panels"] == 0
+    e.close()
