@@ -261,6 +261,10 @@ k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, co
 // 2 x 2 MFMA blocks then holds the outputs (row 2 i + ea, column 2 j + eb) instead of a contiguous 32 x 32 square.  Nothing
 // else moves: B stays k-major in HBM, slabs are copied as before, and the epilogue's accesses become 8 bytes wide (the two
 // column blocks of a register are adjacent columns), which also halves its load / store instruction count.
+#ifdef PU_STAMPS
+__device__ unsigned long long *g_pu_stamps = nullptr;
+#endif
+
 template <bool AVG, bool RECT>
 __global__ void __launch_bounds__(256, 3)
 k_p_update_f32(float *P, int ldp, int n, const float *B, int ldb, int m_k, int per_xcd, const int4 *units, RowMap rm, int stagger)
@@ -277,6 +281,9 @@ k_p_update_f32(float *P, int ldp, int n, const float *B, int ldb, int m_k, int p
 
     const int4 unit = units[(size_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)]; // XCD-aware work order, see k_p_update
     if (unit.x < 0) return;
+#ifdef PU_STAMPS // scripts/micro/pu_bench.hip only: when a unit starts, leaves its k-loop and ends (100 MHz clock)
+    if (g_pu_stamps && threadIdx.x == 0) g_pu_stamps[4 * blockIdx.x] = wall_clock64();
+#endif
     if (stagger > 0) { // short k-loops: de-phase the three workgroups of a CU, see k_p_update
         const int slot = (blockIdx.x >> 3) / 32;
         if (slot == 1 || slot == 2) {
@@ -374,6 +381,12 @@ k_p_update_f32(float *P, int ldp, int n, const float *B, int ldb, int m_k, int p
 #undef PUF_STORE
 #undef PUF_LOAD
 
+#ifdef PU_STAMPS
+    if (g_pu_stamps && threadIdx.x == 0) {
+        g_pu_stamps[4 * blockIdx.x + 1] = wall_clock64();
+        g_pu_stamps[4 * blockIdx.x + 3] = (unsigned long long)(full ? 1 : 0) | ((unsigned long long)(diag ? 1 : 0) << 1);
+    }
+#endif
 #ifdef PU_F32_ABL // timing ablations of scripts/micro/pu_bench.hip only (wrong results): 1 no epilogue, 4 direct part only, 8 mirror part only
     if (PU_F32_ABL & 1) {
         if (c00[0] + c01[1] + c10[2] + c11[3] == 12345.f) P[0] = 0.f;
@@ -437,6 +450,13 @@ k_p_update_f32(float *P, int ldp, int n, const float *B, int ldb, int m_k, int p
             }
         }
     }
+#ifdef PU_STAMPS
+    if (diag) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (g_pu_stamps && threadIdx.x == 0) g_pu_stamps[4 * blockIdx.x + 2] = wall_clock64();
+    }
+#endif
     if (diag) return;
 #ifdef PU_F32_ABL
     if (PU_F32_ABL & 4) return;
@@ -471,6 +491,11 @@ k_p_update_f32(float *P, int ldp, int n, const float *B, int ldb, int m_k, int p
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
+#ifdef PU_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the unit ends when its stores have left the wavefront
+    __syncthreads();
+    if (g_pu_stamps && threadIdx.x == 0) g_pu_stamps[4 * blockIdx.x + 2] = wall_clock64();
+#endif
 }
 
 // host-built work list.  Tiles: super-tiles of 8 x 8 tiles, row-major inside; upper triangle only (whole matrix on
