@@ -260,6 +260,8 @@ def main():
                     help="descriptors: matcher mode A, keypoints + 32-byte descriptors per frame (the reference's "
                          "matcher downstream of its detector); ncc: mode B, rendered frames staged in HBM, gray "
                          "pyramid + template NCC per frame (BASELINE configs[3-4])")
+    ap.add_argument("--sweep-mode", type=int, default=0, choices=[0, 1],
+                    help="ekf_set_sweep_mode: 0 two panels of the Cholesky sweep per launch (default), 1 one panel per launch")
     ap.add_argument("--update-path", type=int, default=0, choices=[0, 1, 2],
                     help="ekf_set_update_path: 0 by size (default), 1 B inside the Cholesky sweep, 2 inverse + GEMM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -330,6 +332,7 @@ def main():
         eng.upload_frames(seq.frames)
     for e in (group.engines if group else [eng]):
         e.set_update_path(args.update_path)
+        e.set_sweep_mode(args.sweep_mode)
         e.set_async_errors(True)  # no read-back after a frame's last update: a failed factorisation surfaces at the next step
     P0 = 0.5 * (seq.P0 + seq.P0.T) if (sharded or group) else seq.P0
     ncc = args.matcher == "ncc"

@@ -1449,6 +1449,13 @@ int ekf_set_update_path(EkfEngine *e, int path)
     return EKF_OK;
 }
 
+int ekf_set_sweep_mode(EkfEngine *e, int mode)
+{
+    if (!e || mode < EKF_SWEEP_PAIRS || mode > EKF_SWEEP_SINGLE) return EKF_ERR_INVALID_ARG;
+    e->sweep_mode = mode;
+    return EKF_OK;
+}
+
 int ekf_step(EkfEngine *e, const EkfKeypoint *kps, const uint8_t *desc32, int n_kp, EkfStepInfo *info)
 {
     if (!e || n_kp < 0 || (n_kp > 0 && (!kps || !desc32))) return EKF_ERR_INVALID_ARG;

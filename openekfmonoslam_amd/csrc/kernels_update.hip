@@ -660,6 +660,8 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
 #undef SWEEP_TRACE
 }
 
+#include "chol_pair.h"
+
 // Debug aid (scripts/sweep_trace.py), compiled only with -DEKF_SWEEP_TRACE (EKF_EXTRA_FLAGS of openekfmonoslam_amd/build.py):
 // per launch of the sweep, the earliest workgroup start and the latest end of each role (0 look-ahead published, 1 row
 // block of B, 2 tiles, 3 right-hand sides), in 10 ns ticks of the constant clock.  The state below is process-global and
@@ -1182,7 +1184,28 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         (void)hipEventCreate(&sw1);
         (void)hipEventRecord(sw0, s);
     }
-    for (int k0 = 0; k0 < m; k0 += NB) {
+    bool pairs = e->sweep_mode == 0;
+#ifdef EKF_SWEEP_TRACE
+    if (g_trace) pairs = false; // the per-role trace instruments the one-panel launches
+#endif
+    // two panels per launch (chol_pair.h): launch 0 eliminates panel 0 alone and prepares the pair (1, 2), launch 1 the pair
+    // (1, 2) and prepares (3, 4), ...
+    for (int k0 = 0, first = 1; pairs && k0 < m; k0 += first ? NB : 2 * NB, first = 0) {
+        const int kbA = min(NB, m - k0);
+        const int kbB = first ? 0 : max(0, min(NB, m - k0 - NB));
+        const int k2 = k0 + kbA + kbB;          // first row of the trailing matrix (= m: nothing below)
+        const int nrb = (m - k2 + NB - 1) / NB;
+        const int nsr = (nrb + 1) / 2;
+        const int n_stiles = nrb == 0 ? 0 : 1 + (nrb >= 2 ? nsr * (nsr + 1) / 2 : 0);
+        const int n_rhs_blocks = max(1, (m - k2 + 63) / 64);
+        const int n_wgs = n_stiles + n_rhs_blocks + n_bblocks;
+        const int spacer = n_wgs > e->n_cus ? e->n_cus : 0;
+        const int n_spacers = spacer ? (n_wgs - 1) / (spacer - 1) : 0;
+        k_chol_pair<T><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(T) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, kbB, k2,
+                                                         e->d.nu, n_stiles, V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
+                                                         e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks, n_wgs > e->n_cus ? 1 : 0, spacer);
+    }
+    for (int k0 = 0; !pairs && k0 < m; k0 += NB) {
         const int kb = min(NB, m - k0);
         const int k1 = k0 + kb;
         const int nrb = (m - k1 + NB - 1) / NB; // row blocks below the panel

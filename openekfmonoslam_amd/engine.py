@@ -85,6 +85,7 @@ ABI = {
     "ekf_step_frame": (_i, [_vp, _i, C.POINTER(EkfStepInfo)]),
     "ekf_set_async_errors": (_i, [_vp, _i]),
     "ekf_set_update_path": (_i, [_vp, _i]),
+    "ekf_set_sweep_mode": (_i, [_vp, _i]),
     "ekf_image_upload": (_i, [_vp, _vp, _i, _i, _i, _i]),
     "ekf_get_image_level": (_i, [_vp, _i, _vp, C.POINTER(_i), C.POINTER(_i)]),
     "ekf_capture_templates": (_i, [_vp, _vp, _vp, _i]),
@@ -293,6 +294,10 @@ class EkfEngine:
     def set_update_path(self, path):
         """0: by size, 1: B = inv(L) H P inside the Cholesky sweep, 2: explicit inverse + GEMM (ekf_engine.h)"""
         self._chk(self.L.ekf_set_update_path(self.h, int(path)))
+
+    def set_sweep_mode(self, mode):
+        """0: two panels of the Cholesky sweep per launch (default), 1: one panel per launch (ekf_engine.h)"""
+        self._chk(self.L.ekf_set_sweep_mode(self.h, int(mode)))
 
     def keep_step_predictions(self, on=True):
         self._chk(self.L.ekf_keep_step_predictions(self.h, 1 if on else 0))

@@ -118,3 +118,41 @@ def test_n5000_fp32_against_committed_summary(eng_mod):
     assert not bad, bad
     assert be["features_componentwise"] <= F32_COMPONENT_TOL, be["features_componentwise"]
     assert p13_own <= 1e-4, p13_own
+
+
+def test_n5000_fp32_three_frames_against_committed_summary(eng_mod):
+    """configs[4] map size over THREE frames: after every frame the engine's decisions, state blocks, camera
+    block, diagonal, trace, Frobenius norm and a 64 x 64 sample of P against the per-frame oracle summaries of
+    tests/golden/oracle_n5000_f3_summary.npz (77 minutes of oracle time, minted once by make_large_fixture.py 5000 3)."""
+    path = os.path.join(GOLDEN, "oracle_n5000_f3_summary.npz")
+    if not os.path.exists(path):
+        pytest.skip("summary fixture not minted")
+    z = np.load(path)
+    N, F = int(z["n_features"]), int(z["frames"])
+    assert F == 3
+    seq = SyntheticSequence(N, F, width=int(z["width"]), height=int(z["height"]))
+    assert np.isclose(np.trace(seq.P0), float(z["input_P0_trace"]), rtol=1e-13, atol=0)
+    assert np.isclose(seq.frames[0][0]["x"].astype(np.float64).sum(), float(z["input_kps0_sum"]), rtol=1e-13, atol=0)
+    e = eng_mod.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=1)
+    e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    idx = z["sample_idx"]
+    for t in range(F):
+        i = e.step(*seq.frames[t])
+        assert [i.n_predicted, i.n_matches, i.n_hypotheses, i.n_inliers, i.n_outliers, i.n_rescued, i.status] == list(z["info"][t]), t
+        x, fp, P = e.get_state()
+        be = block_errs(x, fp, z[f"x13_t{t}"], z[f"feature_pos_t{t}"])
+        maxabs = float(z[f"maxabs_t{t}"])
+        be["P13_max"] = float(np.abs(P[:13, :13] - z[f"P13_t{t}"]).max() / maxabs)
+        p13_own = float(np.abs(P[:13, :13] - z[f"P13_t{t}"]).max() / np.abs(z[f"P13_t{t}"]).max())
+        be["P_sample_max"] = float(np.abs(P[np.ix_(idx, idx)] - z[f"sample_t{t}"]).max() / maxabs)
+        be["P_diag_max"] = float(np.abs(np.diag(P) - z[f"diag_t{t}"]).max() / maxabs)
+        be["trace"] = abs(float(np.trace(P)) - float(z[f"trace_t{t}"])) / float(z[f"trace_t{t}"])
+        be["fro"] = abs(float(np.linalg.norm(P)) - float(z[f"fro_t{t}"])) / float(z[f"fro_t{t}"])
+        del P
+        print(f"N=5000 fp32 frame {t} vs committed oracle summary:", {k: f"{v:.2e}" for k, v in be.items()},
+              f"camera block vs its own max {p13_own:.2e}")
+        bad = {k: v for k, v in be.items() if k != "features_componentwise" and not v <= F32_TOL}
+        assert not bad, (t, bad)
+        assert be["features_componentwise"] <= F32_COMPONENT_TOL, (t, be["features_componentwise"])
+        assert p13_own <= 1e-4, (t, p13_own)
+    e.close()
