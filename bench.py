@@ -34,6 +34,7 @@ WORKLOADS = {
     "n1000_f64": (1000, 640, 480, 0, "f64"),
     "n2000_f32": (2000, 1280, 720, 1, "f32"),
     "n5000_f32": (5000, 1920, 1080, 1, "f32"),
+    "n5000_f64": (5000, 1920, 1080, 0, "f64"),
 }
 # f32: MI355X_MICROARCH.md (256 CUs x 256 flop/clk x 2.4 GHz).  f64: not in the guide; 256 CUs x 128 flop/clk (one
 # v_mfma_f64_16x16x4 = 2048 flop per 64 cycles per SIMD) x 2.4 GHz = 78.6, the datasheet figure.  What a pure MFMA loop
@@ -260,8 +261,8 @@ def main():
                     help="descriptors: matcher mode A, keypoints + 32-byte descriptors per frame (the reference's "
                          "matcher downstream of its detector); ncc: mode B, rendered frames staged in HBM, gray "
                          "pyramid + template NCC per frame (BASELINE configs[3-4])")
-    ap.add_argument("--sweep-mode", type=int, default=0, choices=[0, 1],
-                    help="ekf_set_sweep_mode: 0 two panels of the Cholesky sweep per launch (default), 1 one panel per launch")
+    ap.add_argument("--sweep-mode", type=int, default=1, choices=[0, 1],
+                    help="ekf_set_sweep_mode: 1 one panel of the Cholesky sweep per launch (default), 0 two panels per launch")
     ap.add_argument("--update-path", type=int, default=0, choices=[0, 1, 2],
                     help="ekf_set_update_path: 0 by size (default), 1 B inside the Cholesky sweep, 2 inverse + GEMM")
     ap.add_argument("--no-cpu-baseline", action="store_true")

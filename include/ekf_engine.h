@@ -199,9 +199,9 @@ int ekf_set_async_errors(EkfEngine *e, int on);
  * always by inverting L and one GEMM.  Same result to rounding; a tuning / test knob. */
 enum { EKF_UPDATE_PATH_AUTO = 0, EKF_UPDATE_PATH_SWEEP = 1, EKF_UPDATE_PATH_GEMM = 2 };
 int ekf_set_update_path(EkfEngine *e, int path);
-/* How the blocked Cholesky sweep of S (replaces S.inv(), EKF/Update.cpp:108) is launched: EKF_SWEEP_PAIRS two 32-row panels
- * per launch (the default), EKF_SWEEP_SINGLE one panel per launch (the round-2 scheme).  Same result to rounding; a
- * tuning / test knob. */
+/* How the blocked Cholesky sweep of S (replaces S.inv(), EKF/Update.cpp:108) is launched: EKF_SWEEP_SINGLE one 32-row panel per
+ * launch (the default), EKF_SWEEP_PAIRS two panels per launch with a 64 x 64 look-ahead inverse (measured slower on gfx950:
+ * DESIGN.md 4.3).  Same result to rounding; a tuning / test knob. */
 enum { EKF_SWEEP_PAIRS = 0, EKF_SWEEP_SINGLE = 1 };
 int ekf_set_sweep_mode(EkfEngine *e, int mode);
 

@@ -20,7 +20,13 @@
 //                       T_QQ - L_QP L_QP' factorised (Linv_Q), C' = - Linv_Q L_QP Linv_P; all three published
 //
 // The first launch of a sweep has only Linv_0 (k_assemble_S): it runs with kbB = 0 (every B term vanishes) and prepares the
-// pair (1, 2).  Chain per launch: 1.5 + 2 + 1.5 + 4.2 + 0.8 + 4.2 + 0.6 + 0.7 = 15.5 us for two panels.
+// pair (1, 2).
+//
+// MEASURED (round 3, N = 1000, scripts/sweep_trace.py, profiles/r03_sweep_trace_pairs_n1000_f32.txt): NOT faster, and therefore
+// not the default (ekf_set_sweep_mode).  The look-ahead workgroup of a pair launch needs 17.6 us -- loads 2.2, the twelve
+// 32^3 fp64 products of the pair update 3.7 (the matrix pipes of ONE CU: 96 x v_mfma_f64_16x16x4 per wavefront), factor P 4.8,
+// L_QP / its update / C 1.5, factor Q 4.6, publish 0.8 -- against 2 x 7.6 for two one-panel launches: the extra algebra of
+// the 64-wide inverse costs what the saved kernel boundary (1.7 us) and cold-load round (2) bring, 9.65 against 9.29 us per panel.
 #pragma once
 
 typedef double acc4_t __attribute__((ext_vector_type(4)));
@@ -100,8 +106,19 @@ template <typename T>
 __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) // fp32: 239 registers, two workgroups per CU (LDS: 70 KB each)
 k_chol_pair(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0, int kbA, int kbB, int k2, double *nu, int n_stiles,
             double *V, double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc, const T *G, T *Bout, int ld,
-            int n_bblocks, int n_rhs, int tiles_first, int spacer)
+            int n_bblocks, int n_rhs, int tiles_first, int spacer, unsigned long long *trace)
 {
+#ifdef EKF_SWEEP_TRACE // debug builds only (scripts/sweep_trace.py): slot 0 first start, 1..4 end of role 0..3, 8.. milestones
+    const unsigned long long t_in = trace ? wall_clock64() : 0ull;
+#define PAIR_TRACE(slot)                                                                       \
+    if (trace && threadIdx.x == 0) {                                                           \
+        atomicMin(trace, t_in);                                                                \
+        atomicMax(trace + (slot), (unsigned long long)wall_clock64());                         \
+    }
+#else
+#define PAIR_TRACE(slot)
+    (void)trace;
+#endif
     constexpr int NR = 14; // right-hand sides: nu + 13 camera columns
     __shared__ double pool[7][NB][NB + 1];
     __shared__ double sLi[NB][NB + 1]; // inv(L_AA)
@@ -175,6 +192,7 @@ k_chol_pair(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
             b_row_sums<T, 1>(Lt, Bout, ldS, ld, k0, c0, kp, wv, lm, lq, accA, accA);
             if (two) b_row_sums<T, 1>(Lt, Bout, ldS, ld, kB0, c0, kp, wv, lm, lq, accB, accB);
         }
+        PAIR_TRACE(14)
 #pragma unroll
         for (int q = 0; q < 4; ++q) sLi[(tid + q * 256) / NB][(tid + q * 256) % NB] = gv[q];
         if (wv >= 2) {
@@ -221,25 +239,22 @@ k_chol_pair(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
             }
         }
         __syncthreads();
-        double oa[4] = {0.0, 0.0, 0.0, 0.0}, ob[4] = {0.0, 0.0, 0.0, 0.0};
+        // B_A = Linv_A R_A, B_B = C R_A + Linv_B R_B on the fp64 MFMA, one 16 x 16 quadrant per wavefront (as scalar loops of
+        // LDS reads the three products took 4 of this role's 6 us after the sums)
+        {
+            const int bi = wv >> 1, bj = wv & 1, lr = lane & 15, lk = lane >> 4;
+            const acc4_t z4 = {0, 0, 0, 0};
+            const acc4_t oa = quad_prod<false>(z4, sLi, sRA, bi, bj, lr, lk);
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            const double l = sLi[r][q];
+            for (int q = 0; q < 4; ++q) Bout[(size_t)(k0 + 16 * bi + lk + 4 * q) * ld + c0 + 16 * bj + lr] = (T)oa[q];
+            if (two) {
+                acc4_t ob = quad_prod<false>(z4, sC, sRA, bi, bj, lr, lk);
+                ob = quad_prod<false>(ob, sLB, sRB, bi, bj, lr, lk);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) oa[e] += l * sRA[q][cg + e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Bout[(size_t)(k0 + r) * ld + c0 + cg + e] = (T)oa[e];
-        if (two) {
-#pragma unroll
-            for (int q = 0; q < NB; ++q) {
-                const double lc = sC[r][q], lb = sLB[r][q];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ob[e] += lc * sRA[q][cg + e] + lb * sRB[q][cg + e];
+                for (int q = 0; q < 4; ++q) Bout[(size_t)(kB0 + 16 * bi + lk + 4 * q) * ld + c0 + 16 * bj + lr] = (T)ob[q];
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) Bout[(size_t)(kB0 + r) * ld + c0 + cg + e] = (T)ob[e];
         }
+        PAIR_TRACE(2)
         return;
     }
 
@@ -361,6 +376,7 @@ k_chol_pair(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
                         if (r < m && c <= r) S[(size_t)r * ldS + c] = v[bi][bj][q] - u[bi][bj][q];
                     }
         }
+        PAIR_TRACE(3)
         return;
     }
 
@@ -400,7 +416,9 @@ k_chol_pair(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
             for (int blk = 0; blk < 4; ++blk) pool[blk][r][c] = g[blk][q];
         }
         __syncthreads();
+        PAIR_TRACE(8)
         const acc4_t z4 = {0, 0, 0, 0};
+        // (one product after the other: a fused k-loop over six independent accumulators was measured SLOWER, 4.9 against 3.7 us)
         acc4_t lpa = quad_prod<true>(z4, pool[0], sLi, bi, bj, lr, lk);
         acc4_t lpb = z4, lqa = z4, lqb = z4;
         if (two) {
@@ -451,38 +469,42 @@ k_chol_pair(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
             pool[6][r][c] = vqp[q];
         }
         __syncthreads();
+        PAIR_TRACE(9)
         bool ok = block_chol_inv32_v4(pool[4], pool[5]); // Linv_P in pool[5]
+        PAIR_TRACE(10)
+        // everything that does not need Linv_Q leaves before the second factorisation (only C' and Linv_Q follow it)
+        store_linv(V, W, Wf, ldw, k2, pool[5]);
+        if (n_stiles == 1) { // P's rows of L when there is no tile group to store them
+            store_l_block(LL, LLf, W != nullptr, ldS, m_pad, k2, k0, kbA, pool[0]);
+            if (two) store_l_block(LL, LLf, W != nullptr, ldS, m_pad, k2, kB0, kbB, pool[1]);
+        }
         if (hasQ) {
             const acc4_t lqp = quad_prod<true>(z4, pool[6], pool[5], bi, bj, lr, lk); // L_QP = T_QP Linv_P'
 #pragma unroll
             for (int q = 0; q < 4; ++q) sLi[16 * bi + lk + 4 * q][16 * bj + lr] = lqp[q];
             __syncthreads();
             const acc4_t u = quad_prod<true>(z4, sLi, sLi, bi, bj, lr, lk);
+            const acc4_t m1 = quad_prod<false>(z4, sLi, pool[5], bi, bj, lr, lk); // L_QP Linv_P
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = 16 * bi + lk + 4 * q, c = 16 * bj + lr;
                 pool[4][r][c] = lqq[q] ? vqq[q] - u[q] : ((r == c) ? 1.0 : 0.0);
+                pool[2][r][c] = m1[q];
             }
+            // L_QP itself: only the inverse + GEMM path reads it (row-major, k_inv_diag); the rows of B never need it (C does its work)
+            if (W) store_l_block(LL, LLf, true, ldS, m_pad, kQ, k2, NB, sLi);
             __syncthreads();
+            PAIR_TRACE(11)
             ok = block_chol_inv32_v4(pool[4], pool[6]) && ok; // Linv_Q in pool[6]
-            const acc4_t m1 = quad_prod<false>(z4, sLi, pool[5], bi, bj, lr, lk); // L_QP Linv_P
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pool[4][16 * bi + lk + 4 * q][16 * bj + lr] = m1[q];
-            __syncthreads();
-            const acc4_t cq = quad_prod<false>(z4, pool[6], pool[4], bi, bj, lr, lk); // Linv_Q (L_QP Linv_P)
+            PAIR_TRACE(12)
+            const acc4_t cq = quad_prod<false>(z4, pool[6], pool[2], bi, bj, lr, lk); // Linv_Q (L_QP Linv_P)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 V[(size_t)(kQ + 16 * bi + lk + 4 * q) * ldw + k2 + 16 * bj + lr] = -cq[q];
             store_linv(V, W, Wf, ldw, kQ, pool[6]);
         }
-        store_linv(V, W, Wf, ldw, k2, pool[5]);
         if (!ok && tid == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
-        // rows of L nobody else stores: L_QP (the next launch never forms it), and P's own when there is no tile group
-        if (hasQ) store_l_block(LL, LLf, W != nullptr, ldS, m_pad, kQ, k2, NB, sLi);
-        if (n_stiles == 1) {
-            store_l_block(LL, LLf, W != nullptr, ldS, m_pad, k2, k0, kbA, pool[0]);
-            if (two) store_l_block(LL, LLf, W != nullptr, ldS, m_pad, k2, kB0, kbB, pool[1]);
-        }
+        PAIR_TRACE(1)
         return;
     }
 
@@ -637,4 +659,6 @@ k_chol_pair(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
             }
         }
     }
+    PAIR_TRACE(4)
+#undef PAIR_TRACE
 }

@@ -162,6 +162,8 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
     store_linv(V, W, Wf, ldw, 0, sx);
 }
 
+#include "chol_pair.h" // the two-panels-per-launch variant of the sweep below, and the 32^3 product helpers both use
+
 // -------------------------------------------------------------------------------------- blocked Cholesky sweep
 // Right-looking sweep over [ S | nu ], panel width NB = 32, ONE launch per panel (k_chol_step).  The only serial
 // piece is the 32x32 diagonal block: its Cholesky factor and the inverse of that factor.  It is computed by one
@@ -342,15 +344,13 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         for (int e = 0; e < 4; ++e)
             sR[r][cg + e] = (double)g4[e] - ((double)red[0][r][cg + e] + (double)red[1][r][cg + e]);
         __syncthreads();
-        double o[4] = {0.0, 0.0, 0.0, 0.0};
+        {   // B_k = Linv_k R on the fp64 MFMA, one 16 x 16 quadrant per wavefront (as a scalar loop of LDS reads this product
+            // took 1.5 of the role's 8-9 us on the late panels, where the rows of B outlast the look-ahead workgroup)
+            const int bi = wv >> 1, bj = wv & 1, lr = lane & 15, lk = lane >> 4;
+            const acc4_t o = quad_prod<false>(acc4_t{0, 0, 0, 0}, sLi, sR, bi, bj, lr, lk);
 #pragma unroll
-        for (int q = 0; q < NB; ++q) { // inv(L_kk) is stored with its zeros above the diagonal: a fixed trip count, so the
-            const double l = sLi[r][q]; // LDS reads are all in flight together
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] += l * sR[q][cg + e];
+            for (int q = 0; q < 4; ++q) Bout[(size_t)(k0 + 16 * bi + lk + 4 * q) * ld + c0 + 16 * bj + lr] = (T)o[q];
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Bout[(size_t)(k0 + r) * ld + c0 + cg + e] = (T)o[e];
         SWEEP_TRACE(1)
         return;
     }
@@ -660,13 +660,11 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
 #undef SWEEP_TRACE
 }
 
-#include "chol_pair.h"
-
 // Debug aid (scripts/sweep_trace.py), compiled only with -DEKF_SWEEP_TRACE (EKF_EXTRA_FLAGS of openekfmonoslam_amd/build.py):
 // per launch of the sweep, the earliest workgroup start and the latest end of each role (0 look-ahead published, 1 row
 // block of B, 2 tiles, 3 right-hand sides), in 10 ns ticks of the constant clock.  The state below is process-global and
 // the ablation bits (enable >> 8) make roles return early: it is NOT part of the product library.
-constexpr int TRACE_SLOTS = 8, TRACE_MAX = 4096;
+constexpr int TRACE_SLOTS = 16, TRACE_MAX = 4096;
 #ifdef EKF_SWEEP_TRACE
 static unsigned long long *g_trace = nullptr;
 static int g_trace_n = 0;
@@ -1184,10 +1182,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         (void)hipEventCreate(&sw1);
         (void)hipEventRecord(sw0, s);
     }
-    bool pairs = e->sweep_mode == 0;
-#ifdef EKF_SWEEP_TRACE
-    if (g_trace) pairs = false; // the per-role trace instruments the one-panel launches
-#endif
+    const bool pairs = e->sweep_mode == 0;
     // two panels per launch (chol_pair.h): launch 0 eliminates panel 0 alone and prepares the pair (1, 2), launch 1 the pair
     // (1, 2) and prepares (3, 4), ...
     for (int k0 = 0, first = 1; pairs && k0 < m; k0 += first ? NB : 2 * NB, first = 0) {
@@ -1201,9 +1196,18 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const int n_wgs = n_stiles + n_rhs_blocks + n_bblocks;
         const int spacer = n_wgs > e->n_cus ? e->n_cus : 0;
         const int n_spacers = spacer ? (n_wgs - 1) / (spacer - 1) : 0;
+        unsigned long long *tr = nullptr;
+#ifdef EKF_SWEEP_TRACE
+        if (g_trace && g_trace_n < TRACE_MAX) {
+            tr = g_trace + (size_t)TRACE_SLOTS * g_trace_n++;
+            static unsigned long long tags[TRACE_MAX];
+            tags[g_trace_n - 1] = ((unsigned long long)k0 << 32) | (unsigned long long)m;
+            (void)hipMemcpyAsync(tr + 5, &tags[g_trace_n - 1], sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+        }
+#endif
         k_chol_pair<T><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(T) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, kbB, k2,
                                                          e->d.nu, n_stiles, V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
-                                                         e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks, n_wgs > e->n_cus ? 1 : 0, spacer);
+                                                         e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks, n_wgs > e->n_cus ? 1 : 0, spacer, tr);
     }
     for (int k0 = 0; !pairs && k0 < m; k0 += NB) {
         const int kb = min(NB, m - k0);

@@ -20,6 +20,7 @@ seq = SyntheticSequence(N, F + 1)
 e = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=1 if N >= 1000 else 0)
 e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
 e.set_update_path(int(os.environ.get('UPDATE_PATH', '0')))
+e.set_sweep_mode(int(os.environ.get('SWEEP_MODE', '1')))
 L = engine.load_library()
 if not hasattr(L, "ekf_debug_sweep_trace"):
     sys.exit("this libekf_engine.so was built without -DEKF_SWEEP_TRACE (see the docstring)")
@@ -34,15 +35,24 @@ try:
 except Exception as ex:  # an ablated role leaves a wrong factor: the timeline is still valid
     print('step failed (expected with ABL):', ex)
     info = None
-buf = np.zeros(8 * 4096, dtype=np.uint64)
+SL = 16
+buf = np.zeros(SL * 4096, dtype=np.uint64)
 cnt = C.c_int(0)
 fn(0, buf.ctypes.data_as(C.c_void_p), C.byref(cnt))
-rows = buf[: 8 * cnt.value].reshape(-1, 8)
+rows = buf[: SL * cnt.value].reshape(-1, SL)
 print(f"frame: {(info.n_matches, info.n_inliers, info.n_rescued) if info else None}; {cnt.value} sweep launches")
-print("   k0     m   lookahead   B-role   tiles     rhs   (us after the launch's first workgroup started)  last tile start  last rhs start")
-prev_start = None
-for i, r in enumerate(rows):
-    t0 = int(r[0])
-    d = [(int(x) - t0) / 100.0 if int(x) else float("nan") for x in r[1:5]]
-    st = [(int(x) - t0) / 100.0 if int(x) else float("nan") for x in r[6:8]]
-    print(f"{int(r[5]) >> 32:5d} {int(r[5]) & 0xffffffff:5d}   {d[0]:8.2f} {d[1]:8.2f} {d[2]:8.2f} {d[3]:8.2f}   {st[0]:8.2f} {st[1]:8.2f}")
+us = lambda x, t0: (int(x) - t0) / 100.0 if int(x) else float("nan")
+if int(os.environ.get("SWEEP_MODE", "1")) == 1:
+    print("   k0     m   lookahead   B-role   tiles     rhs   (us after the launch's first workgroup started)  last tile start  last rhs start")
+    for r in rows:
+        t0 = int(r[0])
+        d = [us(x, t0) for x in r[1:5]]
+        st = [us(x, t0) for x in r[6:8]]
+        print(f"{int(r[5]) >> 32:5d} {int(r[5]) & 0xffffffff:5d}   {d[0]:8.2f} {d[1]:8.2f} {d[2]:8.2f} {d[3]:8.2f}   {st[0]:8.2f} {st[1]:8.2f}")
+else:  # two panels per launch (chol_pair.h): role ends, and the look-ahead workgroup's milestones
+    print("   k0     m | look-ahead: loaded  updated  factor P  Q ready  factor Q      end | B sums    B end    tiles      rhs   (us after the launch's first workgroup started)")
+    for r in rows:
+        t0 = int(r[0])
+        la = [us(r[i], t0) for i in (8, 9, 10, 11, 12, 1)]
+        ro = [us(r[i], t0) for i in (14, 2, 3, 4)]
+        print(f"{int(r[5]) >> 32:5d} {int(r[5]) & 0xffffffff:5d} | " + " ".join(f"{x:8.2f}" for x in la) + " | " + " ".join(f"{x:8.2f}" for x in ro))

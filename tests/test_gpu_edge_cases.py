@@ -96,6 +96,44 @@ def test_update_sizes_across_block_boundaries(eng_mod, oracle_lib, M, path):
     assert_state_close(e, o, F64_TOL, f"update with M = {M}")
 
 
+@pytest.mark.parametrize("path", [pytest.param(1, id="sweep"), pytest.param(2, id="gemm")])
+@pytest.mark.parametrize("M", [1, 16, 17, 32, 33, 48, 49, 64, 65, 80, 96, 97, 128, 129, 160])
+def test_update_sizes_two_panels_per_launch(eng_mod, oracle_lib, M, path):
+    """the same sizes with the Cholesky sweep in its two-panels-per-launch form (ekf_set_sweep_mode(EKF_SWEEP_PAIRS),
+    csrc/chol_pair.h): odd and even panel counts, a short last panel in either half of a pair, both ways of forming B"""
+    seq = SyntheticSequence(170, 1, outlier_fraction=0.0, distractors_per_feature=0.0, max_bit_flips=0)
+    e, o = make_pair(eng_mod, oracle_lib, seq)
+    e.set_update_path(path)
+    e.set_sweep_mode(0)
+    e.predict()
+    o.predict()
+    e.predict_measurements()
+    preds, Hs, Hf = o.predict_measurements()
+    mo = _matches_from_predictions(preds, M)
+    mp, mHs, mHf = align_to_matches(preds, Hs, Hf, mo)
+    assert o.update(mo, mp, mHs, mHf, ALGORITHMIC) == 0
+    e.update(mo)
+    assert_state_close(e, o, F64_TOL, f"update with M = {M}, two panels per launch")
+
+
+def test_sweep_modes_agree_over_frames(eng_mod):
+    """N = 1000, fp32 covariance, four frames: one panel per launch (default) against two panels per launch -- identical
+    decisions, states equal to rounding (the 64 x 64 look-ahead inverse is the same algebra in another order)"""
+    seq = SyntheticSequence(1000, 4)
+    out = []
+    for mode in (1, 0):
+        e = eng_mod.EkfEngine(seq.cam, seq.par, 1000, max_keypoints=len(seq.frames[0][0]) + 64, precision=1)
+        e.set_sweep_mode(mode)
+        e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+        infos = [e.step(*seq.frames[t]) for t in range(4)]
+        out.append((infos, e.get_state()))
+        e.close()
+    for a, b in zip(out[0][0], out[1][0]):
+        assert (a.n_matches, a.n_hypotheses, a.n_inliers, a.n_rescued) == (b.n_matches, b.n_hypotheses, b.n_inliers, b.n_rescued)
+    (xa, fa, Pa), (xb, fb, Pb) = out[0][1], out[1][1]
+    assert rel_max(Pb, Pa) <= 1e-6 and np.abs(xa - xb).max() <= 1e-7 and np.abs(fa - fb).max() <= 1e-6
+
+
 def test_update_sizes_fp32(eng_mod, oracle_lib):
     seq = SyntheticSequence(170, 1, outlier_fraction=0.0, distractors_per_feature=0.0, max_bit_flips=0)
     for M, path in ((17, 1), (64, 1), (129, 1), (160, 1), (17, 2), (129, 2), (160, 2)):
