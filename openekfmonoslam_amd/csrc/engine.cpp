@@ -19,7 +19,7 @@ using namespace ekf;
 namespace ekf {
 void launch_partition(EkfEngine *e, const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0,
                       int *cnt1, bool map_update = false, const uint8_t *d_kdesc = nullptr, int *d_idx0 = nullptr,
-                      int publish_seq = 0);
+                      int publish_seq = 0, bool rescue = false);
 void launch_outlier_idx(EkfEngine *e, const EkfMatch *src, int M, int *idx);
 } // namespace ekf
 
@@ -184,9 +184,17 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     };
     hipError_t st;
     if ((st = hipSetDevice(e->device)) != hipSuccess) return fail(st, "hipSetDevice");
-    if ((st = hipStreamCreate(&e->stream)) != hipSuccess) return fail(st, "hipStreamCreate");
     (void)hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, e->device);
     if (e->n_cus <= 0) e->n_cus = 256;
+    if (const char *cm = std::getenv("EKF_PROBE_CU_MASK")) { // scripts/contention_probe.py only: "first,count" of the CU mask of the main stream
+        int first = 0, count = 0;
+        if (std::sscanf(cm, "%d,%d", &first, &count) == 2 && count > 0) {
+            std::vector<uint32_t> mask((e->n_cus + 31) / 32, 0u);
+            for (int c = first; c < first + count && c < e->n_cus; ++c) mask[c / 32] |= 1u << (c % 32);
+            if ((st = hipExtStreamCreateWithCUMask(&e->stream, (uint32_t)mask.size(), mask.data())) != hipSuccess) return fail(st, "hipExtStreamCreateWithCUMask");
+        }
+    }
+    if (!e->stream && (st = hipStreamCreate(&e->stream)) != hipSuccess) return fail(st, "hipStreamCreate");
     if ((st = hipStreamCreate(&e->stream2)) != hipSuccess) return fail(st, "hipStreamCreate");
     if ((st = hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
     if ((st = hipEventCreateWithFlags(&e->ev_prefetch, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");
@@ -1368,15 +1376,13 @@ static int step_dev_fast(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *
         uint8_t *save_d = e->d.kdesc;
         e->d.kps = const_cast<EkfKeypoint *>(d_kps);
         e->d.kdesc = const_cast<uint8_t *>(d_desc);
-        launch_match(e, N, n_kp, cnt + CNT_NPRED);
+        launch_match(e, N, n_kp, cnt + CNT_NPRED, true); // + the RANSAC loop state and the feature -> match index (same launch)
         e->d.kps = save_k;
         e->d.kdesc = save_d;
     }
     tm.mark();
     // 6. 1-point RANSAC (:402): the first batch is launched before anything is known on the host
     const int batch = e->cfg.ransac_batch;
-    launch_ransac_init(e, N);
-    launch_match_index(e, N, cnt + CNT_NMATCH);
     const int seq_r = next_publish_seq(e);
     launch_ransac_batch(e, N, 0, batch, cnt + CNT_NMATCH, seq_r);
     if ((rc = wait_counts(e, seq_r))) return rc;
@@ -1410,12 +1416,9 @@ static int step_dev_fast(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *
     if (no > 0) {
         launch_predict_features(e, e->d.work_idx, no, false);
         launch_hp_rows(e, e->d.plist_sub, no, false, cnt + CNT_NPRED_SUB);
-        EkfMatch *save = e->d.matches;
-        e->d.matches = e->d.mout;
-        launch_rescue(e, no);
-        e->d.matches = save;
         const int seq_p = next_publish_seq(e);
-        launch_partition(e, e->d.mout, no, e->d.mask, e->d.msel, nullptr, cnt + CNT_NRESC, true, d_desc, nullptr, seq_p); // rescued matches join the inliers (EKF.cpp:552-556)
+        // rescueOutliers (EKF.cpp:84-97) and the partition it feeds in one launch: rescued matches join the inliers (EKF.cpp:552-556)
+        launch_partition(e, e->d.mout, no, e->d.mask, e->d.msel, nullptr, cnt + CNT_NRESC, true, d_desc, nullptr, seq_p, true);
         if ((rc = wait_counts(e, seq_p))) return rc;
         take_error();
         nr = e->h_counts[CNT_NRESC];

@@ -272,7 +272,7 @@ void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool tab
 // d_count != nullptr: n_list is an upper bound, the list's length is read on the device
 void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_predicted = false, const int *d_count = nullptr);
 // d_npred != nullptr: n_pred is an upper bound, the number of predictions is read on the device
-void launch_match(EkfEngine *e, int n_pred, int n_kp, const int *d_npred = nullptr);
+void launch_match(EkfEngine *e, int n_pred, int n_kp, const int *d_npred = nullptr, bool with_ransac_init = false);
 // d_M != nullptr (RANSAC launchers): M is an upper bound, the number of matches is read on the device
 void launch_match_index(EkfEngine *e, int M, const int *d_M = nullptr);
 // sharded filter: per-rank boundaries of a feature-sorted match list -> counts[CNT_SHARD0 ..]; featureIndex of list[h0] and

@@ -123,11 +123,28 @@ k_match(const int *plist, const double *uv_tab, const double *S_tab, const uint8
 // compacted match list in prediction order (matches.push_back order, Matching.cpp:247-262)
 __global__ void __launch_bounds__(1024)
 k_match_compact(const int *plist, int n_pred, const int *mt_valid, const int *mt_kp, const float *mt_dist,
-                const EkfKeypoint *kps, int by_slot, EkfMatch *out, int *out_count, const int *d_npred)
+                const EkfKeypoint *kps, int by_slot, EkfMatch *out, int *out_count, const int *d_npred,
+                int *rs_counts, int *match_of_feat, uint8_t *best_flags, int N)
 {
     if (d_npred) n_pred = *d_npred;
     __shared__ int wtot[16];
     const int tid = threadIdx.x;
+    if (rs_counts) {
+        // what k_ransac_init + k_match_index do for an arbitrary match list (1PointRansac.cpp:58-82, :116), folded in for the
+        // matcher's own list: a feature appears in it at most once, so "the first match of feature f" is the match itself
+        if (tid == 0) {
+            rs_counts[CNT_RS_BEST] = 0;
+            rs_counts[CNT_RS_BESTH] = -1;
+            rs_counts[CNT_RS_NHYP] = 1000;
+            rs_counts[CNT_RS_NEXT] = 0;
+            rs_counts[CNT_RS_DONE] = 0;
+        }
+        for (int i = tid; i < N; i += 1024) {
+            match_of_feat[i] = 0x7fffffff;
+            best_flags[i] = 0;
+        }
+        __syncthreads();
+    }
     const int per = (n_pred + 1023) / 1024;
     const int b = tid * per, e = min(n_pred, b + per);
     int c = 0;
@@ -145,28 +162,31 @@ k_match_compact(const int *plist, int n_pred, const int *mt_valid, const int *mt
             m.imagePos[1] = (double)kps[kp].y;
             m.distance = mt_dist[i];
             m._pad = 0.f;
+            if (rs_counts) match_of_feat[m.featureIndex] = pos;
             out[pos++] = m;
         }
     if (tid == 1023) *out_count = total;
 }
 
-void launch_match(EkfEngine *e, int n_pred, int n_kp, const int *d_npred)
+void launch_match(EkfEngine *e, int n_pred, int n_kp, const int *d_npred, bool with_ransac_init)
 {
     if (n_pred <= 0) {
         (void)hipMemsetAsync(e->d.counts + CNT_NMATCH, 0, sizeof(int), e->stream);
+        if (with_ransac_init) launch_ransac_init(e, e->N);
         return;
     }
     k_match<<<n_pred, 256, 0, e->stream>>>(e->d.plist, e->d.pred_uv, e->d.pred_S, e->d.feat_desc, e->d.kps,
                                            e->d.kdesc, n_kp, e->cfg.par.matchingCompCoefSecondBestVSFirst,
                                            e->d.mt_valid, e->d.mt_kp, e->d.mt_dist, e->desc_bytes, e->desc_f32 ? 1 : 0, d_npred);
     k_match_compact<<<1, 1024, 0, e->stream>>>(e->d.plist, n_pred, e->d.mt_valid, e->d.mt_kp, e->d.mt_dist,
-                                               e->d.kps, 0, e->d.matches, e->d.counts + CNT_NMATCH, d_npred);
+                                               e->d.kps, 0, e->d.matches, e->d.counts + CNT_NMATCH, d_npred,
+                                               with_ransac_init ? e->d.counts : nullptr, e->d.match_of_feat, e->d.best_flags, e->N);
 }
 
 void launch_match_compact_slots(EkfEngine *e, int n_pred, const EkfKeypoint *d_slot_xy)
 {
     k_match_compact<<<1, 1024, 0, e->stream>>>(e->d.plist, n_pred, e->d.mt_valid, e->d.mt_kp, e->d.mt_dist, d_slot_xy,
-                                               1, e->d.matches, e->d.counts + CNT_NMATCH, nullptr);
+                                               1, e->d.matches, e->d.counts + CNT_NMATCH, nullptr, nullptr, nullptr, nullptr, 0);
 }
 
 // match_of_feat[f] = smallest match index whose featureIndex is f, or -1 (the linear searches of
@@ -198,12 +218,28 @@ void launch_match_index(EkfEngine *e, int M, const int *d_M)
 __global__ void __launch_bounds__(1024)
 k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0, int *cnt1, const uint8_t *kdesc,
             uint8_t *feat_desc, unsigned *times_matched, int desc_bytes, int *idx0, const int *counts, int *mirror,
-            int publish_seq)
+            int publish_seq, uint8_t *rescue_mask, const int *vis, const double *uv_tab, const double *S_tab, double chi2)
 {
     __shared__ int wtot[16];
     const int tid = threadIdx.x;
     const int per = (M + 1023) / 1024;
     const int b = tid * per, e = min(M, b + per);
+    if (rescue_mask) {
+        // rescueOutliers (EKF.cpp:84-97) in the same launch: the flags of this partition are nu' inv(S_i) nu < chi2 against
+        // the re-predicted measurements -- k_rescue's expression, thread-private entries of the mask
+        for (int i = b; i < e; ++i) {
+            const int fi = src[i].featureIndex;
+            const double d0 = src[i].imagePos[0] - uv_tab[2 * fi];
+            const double d1 = src[i].imagePos[1] - uv_tab[2 * fi + 1];
+            double Si[4];
+            inv2(S_tab + 4 * fi, Si);
+            const double t0 = d0 * Si[0] + d1 * Si[2];
+            const double t1 = d0 * Si[1] + d1 * Si[3];
+            const double v = t0 * d0 + t1 * d1;
+            rescue_mask[i] = (vis[fi] && v < chi2) ? 1 : 0;
+        }
+        flags = rescue_mask;
+    }
     int c = 0;
     for (int i = b; i < e; ++i) c += flags[i] ? 1 : 0;
     int total;
@@ -235,7 +271,7 @@ k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, Ek
 }
 
 void launch_partition(EkfEngine *e, const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, EkfMatch *dst0,
-                      int *cnt1, bool map_update, const uint8_t *d_kdesc, int *d_idx0, int publish_seq)
+                      int *cnt1, bool map_update, const uint8_t *d_kdesc, int *d_idx0, int publish_seq, bool rescue)
 {
     if (M <= 0) {
         if (cnt1) (void)hipMemsetAsync(cnt1, 0, sizeof(int), e->stream);
@@ -243,7 +279,8 @@ void launch_partition(EkfEngine *e, const EkfMatch *src, int M, const uint8_t *f
     }
     k_partition<<<1, 1024, 0, e->stream>>>(src, M, flags, dst1, dst0, cnt1, d_kdesc, e->d.feat_desc,
                                            map_update ? e->d.feat_times_matched : nullptr, e->desc_bytes, d_idx0, e->d.counts,
-                                           e->d_mirror, e->d_mirror ? publish_seq : 0);
+                                           e->d_mirror, e->d_mirror ? publish_seq : 0, rescue ? e->d.mask : nullptr, e->d.pred_vis,
+                                           e->d.pred_uv, e->d.pred_S, e->cfg.par.ransacChi2Threshold);
 }
 
 
