@@ -261,8 +261,8 @@ def main():
                     help="descriptors: matcher mode A, keypoints + 32-byte descriptors per frame (the reference's "
                          "matcher downstream of its detector); ncc: mode B, rendered frames staged in HBM, gray "
                          "pyramid + template NCC per frame (BASELINE configs[3-4])")
-    ap.add_argument("--sweep-mode", type=int, default=1, choices=[0, 1],
-                    help="ekf_set_sweep_mode: 1 one panel of the Cholesky sweep per launch (default), 0 two panels per launch")
+    ap.add_argument("--sweep-mode", type=int, default=2, choices=[0, 1, 2],
+                    help="ekf_set_sweep_mode: 2 by size (default), 1 one panel of the Cholesky sweep per launch, 0 two panels per launch")
     ap.add_argument("--update-path", type=int, default=0, choices=[0, 1, 2],
                     help="ekf_set_update_path: 0 by size (default), 1 B inside the Cholesky sweep, 2 inverse + GEMM")
     ap.add_argument("--no-cpu-baseline", action="store_true")

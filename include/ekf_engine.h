@@ -200,9 +200,10 @@ int ekf_set_async_errors(EkfEngine *e, int on);
 enum { EKF_UPDATE_PATH_AUTO = 0, EKF_UPDATE_PATH_SWEEP = 1, EKF_UPDATE_PATH_GEMM = 2 };
 int ekf_set_update_path(EkfEngine *e, int path);
 /* How the blocked Cholesky sweep of S (replaces S.inv(), EKF/Update.cpp:108) is launched: EKF_SWEEP_SINGLE one 32-row panel per
- * launch (the default), EKF_SWEEP_PAIRS two panels per launch with a 64 x 64 look-ahead inverse (measured slower on gfx950:
- * DESIGN.md 4.3).  Same result to rounding; a tuning / test knob. */
-enum { EKF_SWEEP_PAIRS = 0, EKF_SWEEP_SINGLE = 1 };
+ * launch, EKF_SWEEP_PAIRS two panels per launch with a 64 x 64 look-ahead inverse, EKF_SWEEP_AUTO (the default) single launches
+ * while a launch is bound by its look-ahead factorisation and pairs once the rows of B = inv(L) H P are the longest role
+ * (large maps).  Same result to rounding; a tuning / test knob. */
+enum { EKF_SWEEP_PAIRS = 0, EKF_SWEEP_SINGLE = 1, EKF_SWEEP_AUTO = 2 };
 int ekf_set_sweep_mode(EkfEngine *e, int mode);
 
 /* -- matcher mode B: image in, no detector ----------------------------------------------------------------

@@ -1454,7 +1454,7 @@ int ekf_set_update_path(EkfEngine *e, int path)
 
 int ekf_set_sweep_mode(EkfEngine *e, int mode)
 {
-    if (!e || mode < EKF_SWEEP_PAIRS || mode > EKF_SWEEP_SINGLE) return EKF_ERR_INVALID_ARG;
+    if (!e || mode < EKF_SWEEP_PAIRS || mode > EKF_SWEEP_AUTO) return EKF_ERR_INVALID_ARG;
     e->sweep_mode = mode;
     return EKF_OK;
 }

@@ -182,7 +182,7 @@ struct EkfEngine {
     void *xchg_user = nullptr;
     int n_cus = 256;           // compute units of the device (launch-shape decisions)
     int b_path = 0;            // ekf_set_update_path: 0 by size (B_SWEEP_MAX), 1 B in the sweep, 2 inverse + GEMM
-    int sweep_mode = 1;        // ekf_set_sweep_mode: 1 one panel per launch (k_chol_step, the default), 0 two panels per launch (chol_pair.h)
+    int sweep_mode = 2;        // ekf_set_sweep_mode: 2 by size (default), 1 one panel per launch (k_chol_step), 0 two panels per launch (chol_pair.h)
     bool async_errors = false; // ekf_set_async_errors: no read-back at the end of a step
     bool p_exact_sym = false; // P known to be bitwise symmetric (engine-maintained invariant)
     int n_pred = 0;           // predictions of the last full prediction

@@ -16,6 +16,7 @@
 // both give the same x and P up to rounding (S is symmetric positive definite: R = pixelErrorX * I).
 #include "engine.h"
 #include <vector>
+#include <cstdlib>
 #include <cstdio>
 #include "chol32.h"
 #include "mma_tile.h"
@@ -1182,58 +1183,54 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         (void)hipEventCreate(&sw1);
         (void)hipEventRecord(sw0, s);
     }
-    const bool pairs = e->sweep_mode == 0;
-    // two panels per launch (chol_pair.h): launch 0 eliminates panel 0 alone and prepares the pair (1, 2), launch 1 the pair
-    // (1, 2) and prepares (3, 4), ...
-    for (int k0 = 0, first = 1; pairs && k0 < m; k0 += first ? NB : 2 * NB, first = 0) {
+    // One panel per launch (k_chol_step) while the launch is as long as its look-ahead workgroup; two panels per launch
+    // (chol_pair.h) once the rows of B are the longest role -- a pair launch reads the finished rows of B once for both panels
+    // (the left-looking sum re-reads ALL of them every launch: at n = 12013 that traffic, not the factorisation, sets the pace).
+    // Measured: N = 1000 9.1 us per panel in single launches against 9.55 in pairs; N = 2000 19.2 against 16.7.
+    // A launch of the pair kernel with kbB = 0 eliminates one panel and prepares the first pair (it is also how a sweep in
+    // EKF_SWEEP_PAIRS mode starts); once the 64 x 64 inverse exists the sweep stays in pairs.
+    // (panels before this one) x n_pad from which a launch is in pairs.  Measured at N = 2000: 16.7 us per panel from the first
+    // launch on, 16.9 from 60 k ... 195 k, 17.05 from 250 k (single launches: 19.2); 195 k keeps N = 1000 (<= 190 k) in single launches.
+    constexpr long long PAIR_FROM = 195000;
+    bool have_pair = false;
+    for (int k0 = 0; k0 < m;) {
+        const bool want_pairs = e->sweep_mode == EKF_SWEEP_PAIRS ||
+                                (e->sweep_mode == EKF_SWEEP_AUTO && b_in_sweep && (long long)(k0 / NB) * n_pad >= PAIR_FROM);
+        const bool pair_launch = have_pair || want_pairs;
         const int kbA = min(NB, m - k0);
-        const int kbB = first ? 0 : max(0, min(NB, m - k0 - NB));
-        const int k2 = k0 + kbA + kbB;          // first row of the trailing matrix (= m: nothing below)
-        const int nrb = (m - k2 + NB - 1) / NB;
-        const int nsr = (nrb + 1) / 2;
-        const int n_stiles = nrb == 0 ? 0 : 1 + (nrb >= 2 ? nsr * (nsr + 1) / 2 : 0);
-        const int n_rhs_blocks = max(1, (m - k2 + 63) / 64);
-        const int n_wgs = n_stiles + n_rhs_blocks + n_bblocks;
-        const int spacer = n_wgs > e->n_cus ? e->n_cus : 0;
-        const int n_spacers = spacer ? (n_wgs - 1) / (spacer - 1) : 0;
-        unsigned long long *tr = nullptr;
-#ifdef EKF_SWEEP_TRACE
-        if (g_trace && g_trace_n < TRACE_MAX) {
-            tr = g_trace + (size_t)TRACE_SLOTS * g_trace_n++;
-            static unsigned long long tags[TRACE_MAX];
-            tags[g_trace_n - 1] = ((unsigned long long)k0 << 32) | (unsigned long long)m;
-            (void)hipMemcpyAsync(tr + 5, &tags[g_trace_n - 1], sizeof(unsigned long long), hipMemcpyHostToDevice, s);
-        }
-#endif
-        k_chol_pair<T><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(T) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, kbB, k2,
-                                                         e->d.nu, n_stiles, V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
-                                                         e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks, n_wgs > e->n_cus ? 1 : 0, spacer, tr);
-    }
-    for (int k0 = 0; !pairs && k0 < m; k0 += NB) {
-        const int kb = min(NB, m - k0);
-        const int k1 = k0 + kb;
-        const int nrb = (m - k1 + NB - 1) / NB; // row blocks below the panel
+        const int kbB = have_pair ? max(0, min(NB, m - k0 - NB)) : 0;
+        const int k2 = k0 + kbA + (pair_launch ? kbB : 0); // first row of the trailing matrix (= m: nothing below)
+        const int nrb = (m - k2 + NB - 1) / NB; // row blocks below
         const int nsr = (nrb + 1) / 2;          // 2 x 2 groups of tiles per side
         const int n_stiles = nrb == 0 ? 0 : 1 + (nrb >= 2 ? nsr * (nsr + 1) / 2 : 0); // look-ahead tile + groups
-        const int n_rhs_blocks = max(1, (m - k1 + 63) / 64); // right-hand-side blocks, 64 rows each
+        const int n_rhs_blocks = max(1, (m - k2 + 63) / 64); // right-hand-side blocks, 64 rows each
         const int n_wgs = n_stiles + n_rhs_blocks + n_bblocks;
+        const int spacer = n_wgs > e->n_cus ? e->n_cus : 0; // see k_chol_step: empty blocks where the look-ahead workgroup's CU comes round again
+        const int n_spacers = spacer ? (n_wgs - 1) / (spacer - 1) : 0; // blocks spacer, 2 spacer, ... among n_wgs + n_spacers
         unsigned long long *tr = nullptr;
         int tr_abl = 0;
 #ifdef EKF_SWEEP_TRACE
         if (g_trace && g_trace_n < TRACE_MAX) {
             tr = g_trace + (size_t)TRACE_SLOTS * g_trace_n++;
             static unsigned long long tags[TRACE_MAX];
-            tags[g_trace_n - 1] = ((unsigned long long)k0 << 32) | (unsigned long long)m;
+            tags[g_trace_n - 1] = ((unsigned long long)k0 << 32) | (unsigned long long)m | (pair_launch ? 1ull << 31 : 0ull);
             (void)hipMemcpyAsync(tr + 5, &tags[g_trace_n - 1], sizeof(unsigned long long), hipMemcpyHostToDevice, s);
             tr_abl = g_trace_abl;
         }
 #endif
-        const int spacer = n_wgs > e->n_cus ? e->n_cus : 0; // see k_chol_step: empty blocks where the look-ahead workgroup's CU comes round again
-        const int n_spacers = spacer ? (n_wgs - 1) / (spacer - 1) : 0; // blocks spacer, 2 spacer, ... among n_wgs + n_spacers
-        k_chol_step<T><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(T) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kb, e->d.nu, n_stiles,
-                                                                           V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
-                                                                           e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks,
-                                             n_wgs > e->n_cus ? 1 : 0, spacer, tr, tr_abl);
+        if (pair_launch) {
+            k_chol_pair<T><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(T) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, kbB, k2,
+                                                             e->d.nu, n_stiles, V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
+                                                             e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks, n_wgs > e->n_cus ? 1 : 0, spacer, tr);
+            k0 += have_pair ? 2 * NB : NB;
+            have_pair = true;
+        } else {
+            k_chol_step<T><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(T) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, e->d.nu, n_stiles,
+                                                             V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
+                                                             e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks,
+                                                             n_wgs > e->n_cus ? 1 : 0, spacer, tr, tr_abl);
+            k0 += NB;
+        }
     }
     if (e->timing) {
         (void)hipEventRecord(sw1, s);

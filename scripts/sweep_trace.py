@@ -20,7 +20,7 @@ seq = SyntheticSequence(N, F + 1)
 e = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=1 if N >= 1000 else 0)
 e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
 e.set_update_path(int(os.environ.get('UPDATE_PATH', '0')))
-e.set_sweep_mode(int(os.environ.get('SWEEP_MODE', '1')))
+e.set_sweep_mode(int(os.environ.get('SWEEP_MODE', '2')))
 L = engine.load_library()
 if not hasattr(L, "ekf_debug_sweep_trace"):
     sys.exit("this libekf_engine.so was built without -DEKF_SWEEP_TRACE (see the docstring)")
