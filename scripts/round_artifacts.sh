@@ -8,9 +8,17 @@ python bench.py --workload n200_f64 --steps 60 --warmup 10 > "$out/bench_n200_f6
 python bench.py --workload n1000_f64 --steps 20 --warmup 5 > "$out/bench_n1000_f64.json" 2> /dev/null
 python bench.py --workload n2000_f32 --steps 20 --warmup 5 > "$out/bench_n2000_f32.json" 2> /dev/null
 python bench.py --workload n5000_f32 --steps 3 --warmup 1 > "$out/bench_n5000_f32.json" 2> /dev/null
+python bench.py --workload n5000_f64 --steps 3 --warmup 1 --no-cpu-baseline > "$out/bench_n5000_f64.json" 2> /dev/null
 python bench.py --matcher ncc --workload n2000_f32 --steps 20 --warmup 5 > "$out/bench_n2000_f32_ncc.json" 2> /dev/null
 scripts/micro/pu_bench 1000 298,1014,2000 15 > "$out/pu_bench.txt" 2>&1
-# the per-role sweep trace needs a debug build (scripts/sweep_trace.py); it is not part of the round's standard artifacts
+# per-role sweep traces: only when the debug build is there (scripts/build_trace_variant.sh)
+if [ -f variants/libekf_engine_trace.so ]; then
+  EKF_ENGINE_LIB=variants/libekf_engine_trace.so SWEEP_MODE=1 python scripts/sweep_trace.py 1000 15 2>/dev/null | grep -v amdgpu.ids > "$out/sweep_trace_n1000_f32.txt"
+  EKF_ENGINE_LIB=variants/libekf_engine_trace.so SWEEP_MODE=0 python scripts/sweep_trace.py 1000 15 2>/dev/null | grep -v amdgpu.ids > "$out/sweep_trace_pairs_n1000_f32.txt"
+  EKF_ENGINE_LIB=variants/libekf_engine_trace.so SWEEP_MODE=2 python scripts/sweep_trace.py 2000 6 2>/dev/null | grep -v amdgpu.ids > "$out/sweep_trace_n2000_f32.txt"
+fi
+python scripts/contention_probe.py 30 2>/dev/null | grep -v amdgpu.ids > "$out/contention_probe.txt"
+python scripts/diag_n5000_paths.py 0 1 2>/dev/null | grep -E "^path|^   " > "$out/n5000_three_frames_fp32.txt"
 bash scripts/profile_all.sh "$out/prof"
 for w in n1000_f32 n200_f64 n2000_f32 n5000_f32; do
   db=$(find "$out/prof/$w" -name "*.db" | head -1)
