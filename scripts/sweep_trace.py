@@ -50,9 +50,10 @@ if int(os.environ.get("SWEEP_MODE", "1")) == 1:
         st = [us(x, t0) for x in r[6:8]]
         print(f"{int(r[5]) >> 32:5d} {int(r[5]) & 0xffffffff:5d}   {d[0]:8.2f} {d[1]:8.2f} {d[2]:8.2f} {d[3]:8.2f}   {st[0]:8.2f} {st[1]:8.2f}")
 else:  # two panels per launch (chol_pair.h): role ends, and the look-ahead workgroup's milestones
-    print("   k0     m | look-ahead: loaded  updated  factor P  Q ready  factor Q      end | B sums    B end    tiles      rhs   (us after the launch's first workgroup started)")
+    print("   k0     m launch | look-ahead: loaded  updated  factor P  Q ready  factor Q      end | B sums    B end    tiles      rhs   (us after the launch's first workgroup started; single launches: look-ahead end, B end, tiles, rhs only)")
     for r in rows:
         t0 = int(r[0])
         la = [us(r[i], t0) for i in (8, 9, 10, 11, 12, 1)]
         ro = [us(r[i], t0) for i in (14, 2, 3, 4)]
-        print(f"{int(r[5]) >> 32:5d} {int(r[5]) & 0xffffffff:5d} | " + " ".join(f"{x:8.2f}" for x in la) + " | " + " ".join(f"{x:8.2f}" for x in ro))
+        pair = "pair  " if int(r[5]) & 0x80000000 else "single"
+        print(f"{int(r[5]) >> 32:5d} {int(r[5]) & 0x7fffffff:5d} {pair} | " + " ".join(f"{x:8.2f}" for x in la) + " | " + " ".join(f"{x:8.2f}" for x in ro))
