@@ -116,14 +116,15 @@ def test_update_sizes_two_panels_per_launch(eng_mod, oracle_lib, M, path):
     assert_state_close(e, o, F64_TOL, f"update with M = {M}, two panels per launch")
 
 
-def test_sweep_modes_agree_over_frames(eng_mod):
+@pytest.mark.parametrize("precision", [pytest.param(1, id="fp32"), pytest.param(0, id="fp64")])
+def test_sweep_modes_agree_over_frames(eng_mod, precision):
     """N = 1000, fp32 covariance, four frames: one panel per launch against two panels per launch and against the default
     (by size: pairs once the rows of B are the longest role) -- identical decisions, states equal to rounding (the 64 x 64
     look-ahead inverse is the same algebra in another order)"""
     seq = SyntheticSequence(1000, 4)
     out = []
     for mode in (1, 0, 2):
-        e = eng_mod.EkfEngine(seq.cam, seq.par, 1000, max_keypoints=len(seq.frames[0][0]) + 64, precision=1)
+        e = eng_mod.EkfEngine(seq.cam, seq.par, 1000, max_keypoints=len(seq.frames[0][0]) + 64, precision=precision)
         e.set_sweep_mode(mode)
         e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
         infos = [e.step(*seq.frames[t]) for t in range(4)]
@@ -133,7 +134,8 @@ def test_sweep_modes_agree_over_frames(eng_mod):
         for a, b in zip(out[0][0], other[0]):
             assert (a.n_matches, a.n_hypotheses, a.n_inliers, a.n_rescued) == (b.n_matches, b.n_hypotheses, b.n_inliers, b.n_rescued)
         (xa, fa, Pa), (xb, fb, Pb) = out[0][1], other[1]
-        assert rel_max(Pb, Pa) <= 1e-6 and np.abs(xa - xb).max() <= 1e-7 and np.abs(fa - fb).max() <= 1e-6
+        tol = 1.0 if precision == 1 else 1e-6  # fp64: the two launch schemes agree to 1e-12
+        assert rel_max(Pb, Pa) <= 1e-6 * tol and np.abs(xa - xb).max() <= 1e-7 * tol and np.abs(fa - fb).max() <= 1e-6 * tol
 
 
 def test_update_sizes_fp32(eng_mod, oracle_lib):
