@@ -594,6 +594,7 @@ static void build_units(EkfEngine *e, int nt, int nrt, bool rect, int order)
 }
 
 int g_pu_stagger_override = -1; // scripts/micro/pu_bench.hip only
+int g_pu_force_slots = 0;       // scripts/micro/pu_bench.hip only: the slot count the unit list is balanced against
 
 template <typename T>
 static void launch_p_update_t(EkfEngine *e, int m_pad, int grid, const int4 *tm, bool avg, bool rect)
@@ -640,7 +641,8 @@ void launch_p_update(EkfEngine *e, int m_pad, int m)
     // units first 332 us, mixed first round 323-347 us, whole tiles first 323 us).  Short k-loops keep the CU-count split of
     // rounds 1-2 (m = 298: 113 against 116.5 us with the balanced list): there the launch is mostly epilogue traffic.
     const int slots_saved = e->pu_slots;
-    if (m_pad < 512 && !rect) e->pu_slots = -1;
+    if (g_pu_force_slots) e->pu_slots = g_pu_force_slots;
+    else if (m_pad < 512 && !rect) e->pu_slots = -1;
     build_units(e, nt, nrt, rect, 0);
     e->pu_slots = slots_saved;
     const int grid = e->pu_per_xcd * 8;

@@ -73,6 +73,14 @@ int main(int argc, char **argv)
         for (int v : vals)
             variants.push_back({"stagger" + std::to_string(v), [v](EkfEngine *en, int m_pad, int m) { en->pu_slots = 0; g_pu_stagger_override = v; launch_p_update(en, m_pad, m); g_pu_stagger_override = -1; }});
     }
+    if (getenv("PU_SPLITS")) { // unit lists balanced against other slot counts (4096: half units only), with and without the stagger
+        static const int slots[] = {768, 1024, 1536, 4096};
+        for (int sl : slots)
+            for (int st : {0, 80}) {
+                variants.push_back({"slots" + std::to_string(sl) + (st ? "_st80" : "_st0"), [sl, st](EkfEngine *en, int m_pad, int m) {
+                    en->pu_slots = 0; g_pu_force_slots = sl; g_pu_stagger_override = st; launch_p_update(en, m_pad, m); g_pu_force_slots = 0; g_pu_stagger_override = -1; }});
+            }
+    }
     if (getenv("PU_ORDERS")) {
         variants.push_back({"bal_halves_first", [](EkfEngine *en, int m_pad, int m) { en->pu_slots = 0; g_pu_order_override = 1; launch_p_update(en, m_pad, m); g_pu_order_override = -1; }});
         variants.push_back({"bal_mixed_HFH", [](EkfEngine *en, int m_pad, int m) { en->pu_slots = 0; g_pu_order_override = 2; launch_p_update(en, m_pad, m); g_pu_order_override = -1; }});
