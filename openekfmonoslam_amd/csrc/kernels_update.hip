@@ -1192,10 +1192,14 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     // (panels before this one) x n_pad from which a launch is in pairs.  Measured at N = 2000: 16.7 us per panel from the first
     // launch on, 16.9 from 60 k ... 195 k, 17.05 from 250 k (single launches: 19.2); 195 k keeps N = 1000 (<= 190 k) in single launches.
     constexpr long long PAIR_FROM = 195000;
+    constexpr int PAIR_ROWS = 3072; // rows of the trailing matrix from which a sweep without the B role starts in pairs
     bool have_pair = false;
     for (int k0 = 0; k0 < m;) {
+        // (without the rows of B -- inverse + GEMM path -- a big sweep is bound by streaming the fp64 trailing matrix once per
+        // launch: 2 x 8 m^2 bytes; pairs stream it once per two panels: N = 5000, m = 3000-4500: 16.6 -> 15.4 us per panel)
         const bool want_pairs = e->sweep_mode == EKF_SWEEP_PAIRS ||
-                                (e->sweep_mode == EKF_SWEEP_AUTO && b_in_sweep && (long long)(k0 / NB) * n_pad >= PAIR_FROM);
+                                (e->sweep_mode == EKF_SWEEP_AUTO &&
+                                 (b_in_sweep ? (long long)(k0 / NB) * n_pad >= PAIR_FROM : m - k0 >= PAIR_ROWS));
         const bool pair_launch = have_pair || want_pairs;
         const int kbA = min(NB, m - k0);
         const int kbB = have_pair ? max(0, min(NB, m - k0 - NB)) : 0;
