@@ -102,11 +102,129 @@ __device__ __forceinline__ void b_row_sums(const T *Lt, const T *Bout, int ldS, 
 #undef CP_MMA
 }
 
+// Rows of B for a PAIR of panels, 64 columns per workgroup (fp32 covariance, large maps).  With 32-column workgroups the finished
+// rows of B are read as 128-byte pieces, one per 48 KB row and workgroup: at n = 12013 that strided stream -- up to 92 MB per launch
+// -- runs at a fraction of the HBM rate and the rows of B outlast the look-ahead workgroup 1.5 - 2.5x (50 against 18 us at panel 45,
+// N = 2000).  Here a lane takes the column PAIR (2 lm, 2 lm + 1) with one 8-byte load (256 contiguous bytes per row and wavefront,
+// half the workgroups, no second workgroup on the CU) and feeds the two values to two MFMA column blocks -- block q holds the columns
+// c0 + 2 c + q -- so one operand of L' serves four products.  Two operand stages in flight (three do not fit the register file).
+__device__ __forceinline__ void b_pair_rows_wide(const float *Lt, const float *G, float *Bout, int ldS, int ld, int k0, int c0, double (*pool)[NB][NB + 1],
+                                                 double (*sLi)[NB + 1], const double (&gv)[4], const double (&gC)[4], const double (&gB)[4])
+{
+    using M = Mma<float>;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lm = lane & 31, lq = lane >> 5;
+    const int kB0 = k0 + NB, kp = k0 / NB;
+    typename M::acc_t acc[2][2]; // [panel][column block]
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.f;
+    // this thread's elements of G_A, G_B: row r, logical columns cg .. cg + 3 of both column blocks = 8 consecutive floats
+    const int r = tid >> 3, cg = (tid & 7) * 4;
+    float2 gA[4], gBv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        gA[e] = *(const float2 *)(G + (size_t)(k0 + r) * ld + c0 + 2 * (cg + e));
+        gBv[e] = *(const float2 *)(G + (size_t)(kB0 + r) * ld + c0 + 2 * (cg + e));
+    }
+    float la[2][2][16];
+    float2 lb[2][16];
+#define BW_LOAD(S_, J_)                                                                                \
+    _Pragma("unroll") for (int st = 0; st < 16; ++st) {                                                \
+        const size_t kr = (size_t)(J_) * NB + st * 2 + lq;                                             \
+        la[S_][0][st] = Lt[kr * ldS + k0 + lm];                                                        \
+        la[S_][1][st] = Lt[kr * ldS + kB0 + lm];                                                       \
+        lb[S_][st] = *(const float2 *)(Bout + kr * ld + c0 + 2 * lm);                                  \
+    }
+#define BW_MMA(S_)                                                                                     \
+    _Pragma("unroll") for (int st = 0; st < 16; ++st) {                                                \
+        acc[0][0] = M::mma(la[S_][0][st], lb[S_][st].x, acc[0][0]);                                    \
+        acc[0][1] = M::mma(la[S_][0][st], lb[S_][st].y, acc[0][1]);                                    \
+        acc[1][0] = M::mma(la[S_][1][st], lb[S_][st].x, acc[1][0]);                                    \
+        acc[1][1] = M::mma(la[S_][1][st], lb[S_][st].y, acc[1][1]);                                    \
+    }
+    const int cnt = kp > wv ? (kp - wv + 3) / 4 : 0; // this wavefront's blocks j = wv, wv + 4, ...
+    if (cnt > 0) { BW_LOAD(0, wv) }
+    for (int i = 0; i < cnt; i += 2) {
+        if (i + 1 < cnt) { BW_LOAD(1, wv + 4 * (i + 1)) }
+        BW_MMA(0)
+        if (i + 1 < cnt) {
+            if (i + 2 < cnt) { BW_LOAD(0, wv + 4 * (i + 2)) }
+            BW_MMA(1)
+        }
+    }
+#undef BW_LOAD
+#undef BW_MMA
+    // partial sums: wavefronts 2, 3 through LDS to wavefronts 0, 1; red[(panel * 2 + half) * 2 + block], 8 x 4224 bytes = pool[0..3]
+    float(*red)[NB][NB + 1] = reinterpret_cast<float(*)[NB][NB + 1]>(&pool[0][0][0]);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) sLi[(tid + q4 * 256) / NB][(tid + q4 * 256) % NB] = gv[q4];
+    if (wv >= 2) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) red[(p * 2 + wv - 2) * 2 + q][M::row(rr, lane)][M::col(lane)] = acc[p][q][rr];
+    }
+    __syncthreads();
+    if (wv < 2) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) red[(p * 2 + wv) * 2 + q][M::row(rr, lane)][M::col(lane)] += acc[p][q][rr];
+    }
+    __syncthreads();
+    double ra[2][4], rb[2][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        ra[0][e] = (double)gA[e].x - ((double)red[0][r][cg + e] + (double)red[2][r][cg + e]);
+        ra[1][e] = (double)gA[e].y - ((double)red[1][r][cg + e] + (double)red[3][r][cg + e]);
+        rb[0][e] = (double)gBv[e].x - ((double)red[4][r][cg + e] + (double)red[6][r][cg + e]);
+        rb[1][e] = (double)gBv[e].y - ((double)red[5][r][cg + e] + (double)red[7][r][cg + e]);
+    }
+    __syncthreads(); // red is dead: pool[0..3] take R_A, R_B of both column blocks, pool[4..5] C and Linv_B
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            pool[q][r][cg + e] = ra[q][e];
+            pool[2 + q][r][cg + e] = rb[q][e];
+        }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        pool[4][(tid + q4 * 256) / NB][(tid + q4 * 256) % NB] = gC[q4];
+        pool[5][(tid + q4 * 256) / NB][(tid + q4 * 256) % NB] = gB[q4];
+    }
+    __syncthreads();
+    {   // B_A = Linv_A R_A, B_B = C R_A + Linv_B R_B on the fp64 MFMA, one 16 x 16 quadrant per wavefront and column block
+        const int bi = wv >> 1, bj = wv & 1, lr = lane & 15, lk = lane >> 4;
+        const acc4_t z4 = {0, 0, 0, 0};
+        const acc4_t oa0 = quad_prod<false>(z4, sLi, pool[0], bi, bj, lr, lk);
+        const acc4_t oa1 = quad_prod<false>(z4, sLi, pool[1], bi, bj, lr, lk);
+        acc4_t ob0 = quad_prod<false>(z4, pool[4], pool[0], bi, bj, lr, lk);
+        acc4_t ob1 = quad_prod<false>(z4, pool[4], pool[1], bi, bj, lr, lk);
+        ob0 = quad_prod<false>(ob0, pool[5], pool[2], bi, bj, lr, lk);
+        ob1 = quad_prod<false>(ob1, pool[5], pool[3], bi, bj, lr, lk);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int row = 16 * bi + lk + 4 * q4, col = c0 + 2 * (16 * bj + lr);
+            *(float2 *)(Bout + (size_t)(k0 + row) * ld + col) = make_float2((float)oa0[q4], (float)oa1[q4]);
+            *(float2 *)(Bout + (size_t)(kB0 + row) * ld + col) = make_float2((float)ob0[q4], (float)ob1[q4]);
+        }
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) // fp32: 239 registers, two workgroups per CU (LDS: 70 KB each)
 k_chol_pair(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0, int kbA, int kbB, int k2, double *nu, int n_stiles,
             double *V, double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc, const T *G, T *Bout, int ld,
-            int n_bblocks, int n_rhs, int tiles_first, int spacer, unsigned long long *trace)
+            int n_bblocks, int n_rhs, int tiles_first, int spacer, unsigned long long *trace, int b_wide)
 {
 #ifdef EKF_SWEEP_TRACE // debug builds only (scripts/sweep_trace.py): slot 0 first start, 1..4 end of role 0..3, 8.. milestones
     const unsigned long long t_in = trace ? wall_clock64() : 0ull;
@@ -159,6 +277,13 @@ k_chol_pair(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
     }
     const int lane = tid & 63, wv = tid >> 6;
 
+    if (bcol >= 0 && b_wide) { // (the host asks for it only with both panels present and the fp32 covariance)
+        if constexpr (sizeof(T) == 4) {
+            b_pair_rows_wide((const float *)LLf, (const float *)G, (float *)Bout, ldS, ld, k0, bcol * 2 * NB, pool, sLi, gv, gC, gB);
+            PAIR_TRACE(2)
+        }
+        return;
+    }
     if (bcol >= 0) {
         // ---- rows of B: B_A = Linv_A R_A, B_B = C R_A + Linv_B R_B, columns 32 bcol ..
         using M = Mma<T>;

@@ -1208,7 +1208,10 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const int nsr = (nrb + 1) / 2;          // 2 x 2 groups of tiles per side
         const int n_stiles = nrb == 0 ? 0 : 1 + (nrb >= 2 ? nsr * (nsr + 1) / 2 : 0); // look-ahead tile + groups
         const int n_rhs_blocks = max(1, (m - k2 + 63) / 64); // right-hand-side blocks, 64 rows each
-        const int n_wgs = n_stiles + n_rhs_blocks + n_bblocks;
+        // pair launches of a large fp32 map: 64 columns of B per workgroup (chol_pair.h, b_pair_rows_wide)
+        const bool b_wide = pair_launch && kbB > 0 && sizeof(T) == 4 && n_bblocks > e->n_cus;
+        const int n_bw = b_wide ? n_pad / (2 * NB) : n_bblocks;
+        const int n_wgs = n_stiles + n_rhs_blocks + n_bw;
         const int spacer = n_wgs > e->n_cus ? e->n_cus : 0; // see k_chol_step: empty blocks where the look-ahead workgroup's CU comes round again
         const int n_spacers = spacer ? (n_wgs - 1) / (spacer - 1) : 0; // blocks spacer, 2 spacer, ... among n_wgs + n_spacers
         unsigned long long *tr = nullptr;
@@ -1225,7 +1228,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         if (pair_launch) {
             k_chol_pair<T><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(T) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, kbB, k2,
                                                              e->d.nu, n_stiles, V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
-                                                             e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks, n_wgs > e->n_cus ? 1 : 0, spacer, tr);
+                                                             e->d.zvec, e->d.Bc, G, A, ld, n_bw, n_rhs_blocks, n_wgs > e->n_cus ? 1 : 0, spacer, tr, b_wide ? 1 : 0);
             k0 += have_pair ? 2 * NB : NB;
             have_pair = true;
         } else {
