@@ -16,7 +16,6 @@
 // both give the same x and P up to rounding (S is symmetric positive definite: R = pixelErrorX * I).
 #include "engine.h"
 #include <vector>
-#include <cstdlib>
 #include <cstdio>
 #include "chol32.h"
 #include "mma_tile.h"
@@ -1189,9 +1188,11 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     // Measured: N = 1000 9.1 us per panel in single launches against 9.55 in pairs; N = 2000 19.2 against 16.7.
     // A launch of the pair kernel with kbB = 0 eliminates one panel and prepares the first pair (it is also how a sweep in
     // EKF_SWEEP_PAIRS mode starts); once the 64 x 64 inverse exists the sweep stays in pairs.
-    // (panels before this one) x n_pad from which a launch is in pairs.  Measured at N = 2000: 16.7 us per panel from the first
-    // launch on, 16.9 from 60 k ... 195 k, 17.05 from 250 k (single launches: 19.2); 195 k keeps N = 1000 (<= 190 k) in single launches.
-    constexpr long long PAIR_FROM = 195000;
+    // (panels before this one) x n_pad from which a launch is in pairs.  Maps whose rows of B are more 32-column blocks than
+    // the chip has CUs (n_pad > 8192; they get the 64-column B role of chol_pair.h) run in pairs from the first launch --
+    // N = 2000: 14.0 us per panel from the start, 14.2 from 120 k, 14.5 from 195 k (single launches: 19.2); smaller maps
+    // stay in single launches up to 195 k, i.e. N = 1000 (<= 190 k) always: 9.1 against 9.55 us per panel in pairs.
+    const long long PAIR_FROM = n_bblocks > e->n_cus ? 0 : 195000;
     constexpr int PAIR_ROWS = 3072; // rows of the trailing matrix from which a sweep without the B role starts in pairs
     bool have_pair = false;
     for (int k0 = 0; k0 < m;) {
