@@ -101,3 +101,31 @@ def test_fp32_drift_90_frames_n1000_vs_fp64_engine(eng_mod):
     for t, be in report.items():
         assert not {k: v for k, v in be.items() if k != "features_componentwise" and not v <= F32_TOL}, (t, be)
         assert be["features_componentwise"] <= 2e-5, (t, be["features_componentwise"])
+
+
+def test_fp32_vs_fp64_engine_30_frames_n2000(eng_mod):
+    """N = 2000 / 1280x720, 30 frames: the fp32 configuration -- whose sweeps run two panels per launch with the 64-column B
+    role at this map size (csrc/chol_pair.h) -- against the fp64 engine on the same frames: identical decisions on every frame,
+    every block within 1e-5 and the component-wise reading within 2e-4 at frames 10 / 20 / 30."""
+    N, F = 2000, 30
+    seq = SyntheticSequence(N, F, width=1280, height=720)
+    kw = dict(max_keypoints=len(seq.frames[0][0]) + 64)
+    e32 = eng_mod.EkfEngine(seq.cam, seq.par, N, precision=1, **kw)
+    e64 = eng_mod.EkfEngine(seq.cam, seq.par, N, precision=0, **kw)
+    for e in (e32, e64):
+        e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+        e.upload_frames(seq.frames)
+    report = {}
+    for t in range(F):
+        a, b = e32.step_frame(t), e64.step_frame(t)
+        for f in COUNTERS:
+            assert getattr(a, f) == getattr(b, f), (t, f, getattr(a, f), getattr(b, f))
+        if t + 1 in (10, 20, 30):
+            x, fp, P = e32.get_state()
+            xo, fpo, Po = e64.get_state()
+            report[t + 1] = parity_report(x, fp, P, xo, fpo, Po)
+            print(f"N=2000 fp32 vs fp64 engine after {t + 1} frames:", {k: f"{v:.2e}" for k, v in report[t + 1].items()})
+    e32.close()
+    e64.close()
+    for t, be in report.items():
+        assert not over_tolerance(be, F32_TOL, N), (t, be)
