@@ -231,6 +231,9 @@ def test_abi_error_paths(eng_mod, seq12):
     with pytest.raises(eng_mod.EkfError) as ei:   # an update path that does not exist
         e.set_update_path(3)
     assert ei.value.code == 1
+    with pytest.raises(eng_mod.EkfError) as ei:   # a sweep launch scheme that does not exist
+        e.set_sweep_mode(3)
+    assert ei.value.code == 1
     # still healthy: a normal prediction + update on a subset of the keypoints
     kps, desc = seq12.frames[0]
     info = e.step(kps[:16], desc[:16])
