@@ -84,6 +84,13 @@ def test_n2000_fp32_two_frames_vs_oracle(eng_mod, oracle_lib):
     print("N=2000 fp32 worst block errors over 2 frames:", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
+def test_n1400_fp32_two_frames_vs_oracle(eng_mod, oracle_lib):
+    """N = 1400 (n_pad = 8448): the smallest kind of map whose Cholesky sweeps run two panels per launch with the 64-column B
+    role from the first launch on (csrc/kernels_update.hip: more 32-column blocks of B than CUs) -- 2 frames vs the oracle."""
+    w = run_pair(eng_mod, oracle_lib, SyntheticSequence(1400, 2, width=1280, height=720), 2)
+    print("N=1400 fp32 worst block errors:", {k: f"{v:.2e}" for k, v in w.items()})
+
+
 def test_n5000_fp32_against_committed_summary(eng_mod):
     """BASELINE configs[4] map size (N = 5000, 1920x1080, fp32) on ONE GPU against the committed oracle summary
     (tests/golden/make_large_fixture.py; the oracle needs ~10 minutes per frame at this size, so it is not run here)."""
