@@ -186,7 +186,8 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     if ((st = hipSetDevice(e->device)) != hipSuccess) return fail(st, "hipSetDevice");
     (void)hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, e->device);
     if (e->n_cus <= 0) e->n_cus = 256;
-    if (const char *cm = std::getenv("EKF_PROBE_CU_MASK")) { // scripts/contention_probe.py only: "first,count" of the CU mask of the main stream
+#ifdef EKF_SWEEP_TRACE // debug builds only (scripts/build_trace_variant.sh), for scripts/contention_probe.py: "first,count" of the CU mask of the main stream
+    if (const char *cm = std::getenv("EKF_PROBE_CU_MASK")) {
         int first = 0, count = 0;
         if (std::sscanf(cm, "%d,%d", &first, &count) == 2 && count > 0) {
             std::vector<uint32_t> mask((e->n_cus + 31) / 32, 0u);
@@ -194,6 +195,7 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
             if ((st = hipExtStreamCreateWithCUMask(&e->stream, (uint32_t)mask.size(), mask.data())) != hipSuccess) return fail(st, "hipExtStreamCreateWithCUMask");
         }
     }
+#endif
     if (!e->stream && (st = hipStreamCreate(&e->stream)) != hipSuccess) return fail(st, "hipStreamCreate");
     if ((st = hipStreamCreate(&e->stream2)) != hipSuccess) return fail(st, "hipStreamCreate");
     if ((st = hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming)) != hipSuccess) return fail(st, "hipEventCreate");

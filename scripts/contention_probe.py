@@ -1,7 +1,9 @@
 """How much slower does the latency-bound Cholesky sweep get while another stream keeps the matrix pipes busy?  (Feasibility of
 overlapping the covariance downdate of finished row blocks of B with the rest of the sweep)  Filter A (N = 1000,
 fp32) steps frames and reports its sweep time per panel; meanwhile filter B (N = 2000, its frame is 60 % downdate at three
-workgroups per CU) steps frames from another host thread on its own stream.  usage: contention_probe.py [frames]"""
+workgroups per CU) steps frames from another host thread on its own stream.  The CU-mask rows need the debug build (the mask hook
+is not in the product library): scripts/build_trace_variant.sh, EKF_ENGINE_LIB=variants/libekf_engine_trace.so.
+usage: contention_probe.py [frames]"""
 import os
 import sys
 import threading

@@ -17,7 +17,7 @@ if [ -f variants/libekf_engine_trace.so ]; then
   EKF_ENGINE_LIB=variants/libekf_engine_trace.so SWEEP_MODE=0 python scripts/sweep_trace.py 1000 15 2>/dev/null | grep -v amdgpu.ids > "$out/sweep_trace_pairs_n1000_f32.txt"
   EKF_ENGINE_LIB=variants/libekf_engine_trace.so SWEEP_MODE=2 python scripts/sweep_trace.py 2000 6 2>/dev/null | grep -v amdgpu.ids > "$out/sweep_trace_n2000_f32.txt"
 fi
-python scripts/contention_probe.py 30 2>/dev/null | grep -v amdgpu.ids > "$out/contention_probe.txt"
+EKF_ENGINE_LIB=variants/libekf_engine_trace.so python scripts/contention_probe.py 30 2>/dev/null | grep -v amdgpu.ids > "$out/contention_probe.txt"
 python scripts/diag_n5000_paths.py 0 1 2>/dev/null | grep -E "^path|^   " > "$out/n5000_three_frames_fp32.txt"
 bash scripts/profile_all.sh "$out/prof"
 for w in n1000_f32 n200_f64 n2000_f32 n5000_f32; do
