@@ -32,8 +32,12 @@ typedef struct EkfEngine EkfEngine;
 
 enum {
     EKF_PRECISION_F64 = 0, /* covariance and work matrices in fp64 (reference arithmetic)                   */
-    EKF_PRECISION_F32 = 1  /* covariance, H*P and the rank-m downdate in fp32 (MFMA f32); S, its Cholesky     */
+    EKF_PRECISION_F32 = 1, /* covariance, H*P and the rank-m downdate in fp32 (MFMA f32); S, its Cholesky     */
                            /* factor, the state and all Jacobians stay fp64                                   */
+    EKF_PRECISION_F32_EXACT = 2 /* fp32 STORAGE of the covariance and of H*P, reference-class arithmetic: B = inv(L) H P in
+                                 * fp64 and the rank-m downdate P - B'B accumulated EXACTLY (int8 digit planes of B on the
+                                 * int8 MFMA, int32 sums), rounded to fp32 once per entry and update.  The reference computes
+                                 * in double throughout (Core/Base.h:67; Update.cpp:105-108, 214-218).  One GPU only. */
 };
 
 typedef struct EkfEngineConfig {

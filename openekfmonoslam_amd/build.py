@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libekf_engine.so")
 SOURCES = ["engine.cpp", "kernels_predict.hip", "kernels_match.hip", "kernels_ransac.hip", "kernels_update.hip",
-           "kernels_pupdate.hip", "kernels_map.hip", "kernels_ncc.hip", "kernels_gemm.hip", "kernels_detect.hip"]
+           "kernels_pupdate.hip", "kernels_pexact.hip", "kernels_map.hip", "kernels_ncc.hip", "kernels_gemm.hip", "kernels_detect.hip"]
 # the decision-making stages (projection, gates, dead-bands) are compiled without FMA contraction so their fp64
 # arithmetic rounds like the reference's scalar C++; the GEMM-shaped kernels keep contraction
 NO_CONTRACT = {"kernels_predict.hip", "kernels_match.hip", "kernels_ransac.hip", "kernels_ncc.hip", "kernels_detect.hip"}

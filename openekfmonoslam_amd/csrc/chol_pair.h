@@ -220,10 +220,10 @@ __device__ __forceinline__ void b_pair_rows_wide(const float *Lt, const float *G
     }
 }
 
-template <typename T>
+template <typename T, typename TG> // T: type of B and of its MFMA; TG: storage type of the gathered rows G (see k_chol_step)
 __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) // fp32: 239 registers, two workgroups per CU (LDS: 70 KB each)
 k_chol_pair(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0, int kbA, int kbB, int k2, double *nu, int n_stiles,
-            double *V, double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc, const T *G, T *Bout, int ld,
+            double *V, double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc, const TG *G, T *Bout, int ld,
             int n_bblocks, int n_rhs, int tiles_first, int spacer, unsigned long long *trace, int b_wide)
 {
 #ifdef EKF_SWEEP_TRACE // debug builds only (scripts/sweep_trace.py): slot 0 first start, 1..4 end of role 0..3, 8.. milestones

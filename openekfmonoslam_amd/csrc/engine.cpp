@@ -119,7 +119,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
                     d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.W, d.Wf, d.G, d.LL, d.LLf, d.Tbuf, d.gates, d.cell_resp, d.cell_xy,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.sq_part, d.diag_save, d.cam_part, d.cam_save, d.HPc, d.Gc, d.Bc, d.zvec, d.yvec,
-                    e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq};
+                    e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq, d.Bq, d.Bexp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &kv : e->pu_tables)
@@ -161,7 +161,16 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     const EkfParams &p = cfg->par;
     e->par = ParD{p.linearAccelSD, p.angularAccelSD, p.matchingCompCoefSecondBestVSFirst,
                   p.ransacThresholdPredictDistance, p.ransacAllInliersProbability, p.ransacChi2Threshold};
-    e->f32 = cfg->precision == EKF_PRECISION_F32;
+    if (cfg->precision != EKF_PRECISION_F64 && cfg->precision != EKF_PRECISION_F32 && cfg->precision != EKF_PRECISION_F32_EXACT) {
+        delete e;
+        return EKF_ERR_INVALID_ARG;
+    }
+    e->exact = cfg->precision == EKF_PRECISION_F32_EXACT;
+    e->f32 = cfg->precision == EKF_PRECISION_F32 || e->exact;
+    if (e->exact && world > 1) { // the exact downdate has no row-sharded form yet
+        delete e;
+        return EKF_ERR_INVALID_ARG;
+    }
     if ((cfg->flags & 0xff) == 1) { // EKF_DESCRIPTOR_F32_L2(cols)
         const int cols = (cfg->flags >> 8) & 0xffff;
         if (cols < 1 || cols > 1024) { delete e; return EKF_ERR_INVALID_ARG; }
@@ -222,8 +231,13 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
         if ((st = dalloc(&raw, (size_t)mcap * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc HP");
         d.HP = raw;
         // + one row: the row operand of a sharded downdate tile may read up to 127 columns past n
-        if ((st = dalloc(&raw, (size_t)(mcap + 1) * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc A");
+        if ((st = dalloc(&raw, (size_t)(mcap + 1) * e->ldP * (e->exact ? 8 : w))) != hipSuccess) return fail(st, "hipMalloc A"); // B = inv(L) G: fp64 beside the exact downdate
         d.A = raw;
+        if (e->exact) { // digit planes of B and their column scales (kernels_pexact.hip)
+            e->bq_rows = round_up((int)mcap, 64) + 64;
+            if ((st = dalloc(&d.Bq, (size_t)PX_S * e->bq_rows * e->ldP)) != hipSuccess) return fail(st, "hipMalloc Bq");
+            if ((st = dalloc(&d.Bexp, (size_t)e->ldP)) != hipSuccess) return fail(st, "hipMalloc Bexp");
+        }
         if ((st = dalloc(&raw, (size_t)(mcap + 1) * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc G");
         d.G = raw;
     }
@@ -264,12 +278,12 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     const size_t mw = (size_t)round_up((int)mcap, 128) + 128;
     ALLOC(d.S, mw * e->ldS);
     ALLOC(d.LL, mw * e->ldS);
-    if (e->f32) ALLOC(d.LLf, mw * e->ldS);
+    if (e->f32 && !e->exact) ALLOC(d.LLf, mw * e->ldS);
     ALLOC(d.nu, mcap);
     ALLOC(d.Dinv, mw * e->ldW);
     ALLOC(d.W, mw * e->ldW);
     ALLOC(d.Tbuf, mw * e->ldW);
-    if (e->f32) ALLOC(d.Wf, mw * e->ldW);
+    if (e->f32 && !e->exact) ALLOC(d.Wf, mw * e->ldW);
     ALLOC(d.mHs, 14 * cap);
     ALLOC(d.mHf, 12 * cap);
     ALLOC(d.mpos, cap);

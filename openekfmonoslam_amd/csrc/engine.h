@@ -16,6 +16,7 @@ constexpr int NB = 32;          // Cholesky panel width
 constexpr int LD_ALIGN = 128;   // leading dimensions are multiples of this many elements
 constexpr int B_SWEEP_MAX = 2048; // rows of S up to which B = inv(L) G is formed inside the sweep's launches
 constexpr int DX_SPLIT = 16;    // k-splits of the dx = B' z reduction
+constexpr int PX_S = 5;         // EKF_PRECISION_F32_EXACT: balanced base-256 digits per element of B (kernels_pexact.hip)
 
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -132,6 +133,8 @@ struct DeviceArrays {
     double *yvec = nullptr;      // [mcap + slack]: y = inv(L)' z = inv(S) nu (fp32 configuration: dx = (H P)' y)
     uint8_t *mask = nullptr;   // generic byte mask output (rescue)
     void *pu_tilemap = nullptr; // int2 (ti, tj) per upper-triangle tile, XCD-friendly order
+    int8_t *Bq = nullptr;       // EKF_PRECISION_F32_EXACT: PX_S digit planes of B, each [bq_rows / 16][ldP][16] bytes (kernels_pexact.hip)
+    int *Bexp = nullptr;        // its column scales (biased exponents), ldP ints
 };
 
 // current frame of the NCC matcher: gray pyramid (level 0 = full resolution) + the raw upload staging buffer
@@ -165,7 +168,8 @@ struct EkfEngine {
     int cap = 0, ncap = 0, mcap = 0, kcap = 0;
     int ldP = 0, ldS = 0, ldW = 0;
     int N = 0, n = 0;
-    bool f32 = false;
+    bool f32 = false;   // P, H P and the gathered rows stored in fp32
+    bool exact = false; // EKF_PRECISION_F32_EXACT: fp32 storage, B in fp64, downdate with exact accumulation (kernels_pexact.hip)
     int desc_bytes = EKF_DESC_BYTES; // bytes per descriptor row
     bool desc_f32 = false;           // CV_32F descriptors / L2 distance (Matching.cpp:60-73) instead of CV_8U / Hamming
     // row sharding: world == 1 means the whole matrix lives here
@@ -194,6 +198,8 @@ struct EkfEngine {
     long long pu_tilemap_nt = -1;
     std::map<long long, std::pair<void *, int>> pu_tables; // built work lists of the downdate: key -> (device list, units per XCD)
     int pu_per_xcd = 0;
+    int bq_rows = 0;          // rows of B a digit plane holds (multiple of 64)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> px_events; // exact downdate: brackets of the column-scale + digit-plane kernels
     int pu_slots = 0;         // resident workgroups of the downdate kernel on this device (0: not asked yet, -1: unknown)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // image-only work of the next frame, overlapped with the update
@@ -237,7 +243,7 @@ struct XtyArgs {
     int n_split;                          // bottom row tiles cut into two half units (tri == 2, batch 1 only)
     double alpha;
 };
-void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32, hipStream_t stream);
+void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32, hipStream_t stream, bool y_f32 = false); // y_f32: fp32 Y beside fp64 arithmetic
 
 // Exclusive prefix sum of one int per thread over a 1024-thread workgroup (and the total): inside a wavefront by shuffles,
 // across the 16 wavefronts through LDS -- one barrier, where a Hillis-Steele scan in LDS needs twenty.  Device code only.
@@ -283,6 +289,7 @@ void launch_slice_bounds(EkfEngine *e, const EkfMatch *list, int h0, int h1);
 void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M = nullptr, int publish_seq = 0);
 void launch_ransac_init(EkfEngine *e, int M);
 void launch_update(EkfEngine *e, int M, bool update_cov);
+void launch_p_update_exact(EkfEngine *e, int m, bool use_bc); // kernels_pexact.hip
 void launch_rescue(EkfEngine *e, int M);
 void launch_state_only_predict(EkfEngine *e, EkfPrediction *d_out); // predictMeasurementState on current state
 void launch_add_features(EkfEngine *e, const double *d_uv, int count, double *d_Jpo, double *d_Jhr);

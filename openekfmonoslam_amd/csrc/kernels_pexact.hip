@@ -1,0 +1,561 @@
+// kernels_pexact.hip -- the covariance downdate  P <- P - B' B  with EXACT accumulation (EKF_PRECISION_F32_EXACT).
+//
+// Replaces covarianceUpdate + symmetrisation (EKF/Update.cpp:214-218, 303) for the "fp32 storage, accurate update"
+// configuration.  The reference does every operation in double (Core/Base.h:67, typedef cv::Mat_<double> Matd); the fp32
+// configuration (kernels_pupdate.hip) rounds B = inv(L) G to fp32 and accumulates B'B in a k-sequential fp32 chain, which
+// costs ~1e-8 absolute on cross-feature entries of ~1e-3 (profiles/r03_parity_attribution.txt).  Here P stays fp32 in HBM,
+// B is formed in fp64 and every entry of B'B is an EXACT integer sum:
+//
+//   * k_col_exp + k_slice_B: column j of B (all m rows) gets one power-of-two scale 2^e_j > max_k |B_kj|; every element is
+//     the 38-bit integer X = rint(B 2^(38 - e_j)), cut into PX_S = 5 balanced base-256 digits d_0 (most significant) ..
+//     d_4 in [-128, 127]: X = sum_s d_s 256^(4 - s).  Digit planes are stored [k / 16][column][k % 16] bytes, so the 16
+//     bytes a lane feeds to v_mfma_i32_32x32x32_i8 are contiguous and a wavefront's piece of a slab is 1 KB of consecutive
+//     bytes in HBM and in LDS (global_load_lds_dwordx4, no staging registers).
+//   * k_p_update_i8: X_i . X_j = sum_L 256^(8 - L) sum_{s + t = L} d_s(i) . d_t(j).  The levels L = 0 .. 4 (15 digit
+//     products per 32 rows of k, each ONE v_mfma_i32_32x32x32_i8 per 32 x 32 block: 32 cycles where the fp32 MFMA needs
+//     1024 for the same 32 rows) are accumulated in int32 -- exact: |d d'| <= 2^14, 5 products, m <= 2^13 rows => < 2^30 --
+//     and combined once in fp64; the dropped levels are below 2^-35 of max_i max_j per term.  P_new = fl32(P_old - v): ONE
+//     rounding per entry and update, i.e. what fp32 storage of an fp64 update costs.
+//   * integer sums are exactly symmetric (level L of (i, j) and of (j, i) are the same multiset of products), so diagonal
+//     tiles are written in place and off-diagonal tiles are mirrored: P stays bitwise symmetric.
+//
+// Work per launch: 15/2 n^2 m int8 MACs on the upper triangle (the ALGORITHMIC count stays n^2 m flop); traffic 2 n^2 w of P
+// + the digit planes (5 bytes per element of B, re-read through L2 once per tile row / column).
+#include "engine.h"
+
+#include <algorithm>
+
+namespace ekf {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------ column scales
+// bexp[j] = max over k of the biased exponent field of B[k][j] (0 for an all-zero column): |B_kj| < 2^(bexp - 1022).
+// Camera columns (j < 13) come from the fp64 side table Bc when given (see k_chol_step: they ride through the sweep as
+// right-hand sides).  Grid (n_pad / 256, PX_KSPLIT); bexp zeroed before the launch.
+constexpr int PX_KSPLIT = 8;
+
+__global__ void __launch_bounds__(256)
+k_col_exp(const double *B, int ld, int m, int n_pad, const double *Bc, int *bexp)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_pad) return;
+    const int per = (m + PX_KSPLIT - 1) / PX_KSPLIT;
+    const int k0 = blockIdx.y * per, k1 = min(m, k0 + per);
+    int hi = 0;
+    const bool cam = Bc && j < 13;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = cam ? Bc[(size_t)(k + u) * 16 + j] : B[(size_t)(k + u) * ld + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) hi = max(hi, __double2hiint(v[u]) & 0x7fffffff);
+    }
+    for (; k < k1; ++k) {
+        const double v = cam ? Bc[(size_t)k * 16 + j] : B[(size_t)k * ld + j];
+        hi = max(hi, __double2hiint(v) & 0x7fffffff);
+    }
+    if (hi >> 20) atomicMax(&bexp[j], hi >> 20);
+}
+
+// ------------------------------------------------------------------------------------------------ digit planes
+// One thread per (16-row group kb, column): reads B[16 kb .. 16 kb + 15][column] (the wavefront reads 512 contiguous bytes
+// per row), writes 16 bytes per plane at Bq[s][kb][column][0..15] (the wavefront writes 1 KB contiguous per plane).
+// Workgroup = 64 columns x 4 row groups; grid (n_pad / 64, m_k / 64).  Rows >= m are zero.
+__global__ void __launch_bounds__(256)
+k_slice_B(const double *B, int ld, int m, int m_k, const double *Bc, const int *bexp, int8_t *Bq, int ldq, size_t plane_stride)
+{
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int kb = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (kb * 16 >= m_k) return;
+    const bool cam = Bc && col < 13;
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = kb * 16 + i;
+        const int kc = min(k, m - 1);
+        const double x = cam ? Bc[(size_t)kc * 16 + col] : B[(size_t)kc * ld + col];
+        v[i] = k < m ? x : 0.0;
+    }
+    // X = rint(B 2^(8 PX_S - 2 - e)), e = bexp - 1022: |X| <= 2^(8 PX_S - 2), so the top digit stays within [-65, 65]
+    const int sh = 8 * PX_S - 2 - (bexp[col] - 1022);
+    unsigned w[PX_S][4];
+#pragma unroll
+    for (int s = 0; s < PX_S; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[s][q] = 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        long long X = __double2ll_rn(ldexp(v[i], sh));
+#pragma unroll
+        for (int s = PX_S - 1; s >= 0; --s) {
+            const int d = (int)((X + 128) & 255) - 128; // balanced digit, [-128, 127]
+            X = (X - d) >> 8;
+            w[s][i >> 2] |= (unsigned)(d & 255) << (8 * (i & 3));
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < PX_S; ++s) {
+        uint4 o = make_uint4(w[s][0], w[s][1], w[s][2], w[s][3]);
+        *(uint4 *)(Bq + (size_t)s * plane_stride + ((size_t)kb * ldq + col) * 16) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the downdate
+// Workgroup = 512 threads = 8 wavefronts (2 x 4), tile 128 x 128 of the upper triangle; wavefront (wr, wc) owns rows
+// 64 wr .. + 63 (two 32 x 32 MFMA blocks) and columns 32 wc .. + 31, five int32 accumulators per block (160 registers).
+// Half units (64 of the tile's 128 rows, see build_units): one block per wavefront.
+// Slab of one step = 32 rows of k: per plane [I side: 2 k-groups x 128 columns x 16 B][J side: the same] = 8 pieces of 1 KB,
+// one per wavefront (global_load_lds_dwordx4), 40 KB per step, two buffers.
+template <bool FULL>
+__device__ __forceinline__ void px_step(const unsigned char *sb, int offA, int offB, v16i (&acc)[2][PX_S])
+{
+    // all five J digits, the I digits one plane ahead of their products (b: 20 registers, a: 8 + 8): with every operand of
+    // the step requested up front the kernel needs 60 operand registers beside its 160 accumulators and spills in the loop
+    v4i b[PX_S];
+#pragma unroll
+    for (int t = 0; t < PX_S; ++t) b[t] = *(const v4i *)(sb + t * 8192 + 4096 + offB);
+    v4i a0 = *(const v4i *)(sb + offA), a1 = a0;
+    if (FULL) a1 = *(const v4i *)(sb + offA + 32 * 16);
+#pragma unroll
+    for (int s = 0; s < PX_S; ++s) {
+        v4i na0 = a0, na1 = a1;
+        if (s + 1 < PX_S) {
+            na0 = *(const v4i *)(sb + (s + 1) * 8192 + offA);
+            if (FULL) na1 = *(const v4i *)(sb + (s + 1) * 8192 + offA + 32 * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < PX_S - s; ++t) {
+            acc[0][s + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b[t], acc[0][s + t], 0, 0, 0);
+            if (FULL) acc[1][s + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b[t], acc[1][s + t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = na0;
+        a1 = na1;
+    }
+}
+
+template <bool AVG>
+__global__ void __launch_bounds__(512, 2)
+k_p_update_i8(float *P, int ldp, int n, const int8_t *Bq, int ldq, size_t plane_stride, int m_k, const int *bexp, int per_xcd,
+              const int4 *units)
+{
+    constexpr int TM = 128, MB = 32;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][PX_S * 8192];
+    const int4 unit = units[(size_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)]; // XCD-aware work order, see k_p_update
+    if (unit.x < 0) return;
+    const int ti = unit.x, tj = unit.y;
+    const bool full = unit.z < 0;
+    const bool diag = ti == tj;
+    const int I0 = ti * TM, J0 = tj * TM;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 2, wc = wv & 3;
+    const int rbase = full ? wr * 2 * MB : unit.z * 2 * MB + wr * MB; // first tile row of the wavefront (64 or 32 rows)
+    const int kg = lane >> 5, idx = lane & 31;
+
+    // this wavefront's piece of every plane: wavefronts 0..3 the I side (k-group, column half), 4..7 the J side
+    const int pside = wv >> 2, pkg = (wv >> 1) & 1, phalf = wv & 1;
+    const bool piece_live = full || pside == 1 || phalf == unit.z; // a half unit reads 64 of the 128 I columns
+    const int8_t *gsrc = Bq + ((size_t)pkg * ldq + (pside ? J0 : I0) + 64 * phalf + lane) * 16;
+    const size_t step_stride = (size_t)2 * ldq * 16;
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const int poff = __builtin_amdgcn_readfirstlane(wv * 1024);
+#define PX_ISSUE(t, buf)                                                                                                      \
+    if (piece_live) {                                                                                                         \
+        _Pragma("unroll") for (int s = 0; s < PX_S; ++s)                                                                      \
+            __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + (size_t)s * plane_stride + (size_t)(t) * step_stride),           \
+                                             (lptr_t)(&smem[buf][s * 8192 + poff]), 16, 0, 0);                                \
+    }
+
+    v16i acc[2][PX_S];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int L = 0; L < PX_S; ++L)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][L][r] = 0;
+
+    const int offA = (kg * TM + rbase + idx) * 16, offB = (kg * TM + wc * MB + idx) * 16;
+    const int nk = m_k / 32;
+    // (one loop per unit kind: with the whole / half test inside the loop the compiler copies the accumulators every step)
+#define PX_LOOP(FULL_)                                                                                                        \
+    PX_ISSUE(0, 0)                                                                                                            \
+    for (int t = 0; t < nk; ++t) {                                                                                            \
+        const int buf = t & 1;                                                                                                \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wavefront's pieces of step t have landed */                  \
+        __syncthreads(); /* everyone's have; everyone has left the other buffer (step t - 1) */                               \
+        if (t + 1 < nk) { PX_ISSUE(t + 1, buf ^ 1) }                                                                          \
+        px_step<FULL_>(smem[buf], offA, offB, acc);                                                                           \
+    }
+    if (full) { PX_LOOP(true) } else { PX_LOOP(false) }
+#undef PX_LOOP
+#undef PX_ISSUE
+    __syncthreads(); // the slabs become the transpose scratch
+
+    // epilogue: v = 2^(e_i + e_j - 12) sum_L acc_L 256^-L (see the header), P <- fl32(P - v); off-diagonal tiles also write
+    // the mirror image through a per-wavefront LDS transpose so that the mirrored stores are row-contiguous
+    float *sT = reinterpret_cast<float *>(&smem[0][0]) + wv * MB * (MB + 1);
+    const int gj = J0 + wc * MB + idx;
+    const int ej = gj < n ? bexp[gj] - 1022 : 0;
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        if (x == 1 && !full) continue;
+        const int bi = I0 + rbase + x * MB;
+        float pv[16];
+        int ei[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gi = bi + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            const bool ok = gi < n && gj < n;
+            ei[r] = gi < n ? bexp[gi] - 1022 : 0;
+            if (AVG) pv[r] = ok ? 0.5f * P[(size_t)gi * ldp + gj] + 0.5f * P[(size_t)gj * ldp + gi] : 0.f;
+            else pv[r] = ok ? P[(size_t)gi * ldp + gj] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int li = (r & 3) + 8 * (r >> 2) + 4 * kg;
+            const int gi = bi + li;
+            double tsum = (double)acc[x][PX_S - 1][r];
+#pragma unroll
+            for (int L = PX_S - 2; L >= 0; --L) tsum = fma(tsum, 1.0 / 256.0, (double)acc[x][L][r]);
+            const double v = ldexp(tsum, ei[r] + ej - 12);
+            const float out = (float)((double)pv[r] - v);
+            // AVG on a diagonal tile: element (i, j) reads P(j, i), which belongs to another wavefront of this tile -- only the
+            // i <= j elements work there and write both places (first update after an arbitrary upload only)
+            const bool st = gi < n && gj < n && (!(AVG && diag) || gi <= gj);
+            if (st) P[(size_t)gi * ldp + gj] = out;
+            if (AVG && diag && st && gi != gj) P[(size_t)gj * ldp + gi] = out;
+            if (!diag) sT[li * (MB + 1) + idx] = out;
+        }
+        if (!diag) {
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < MB / 2; ++it) {
+                const int c = it * 2 + kg; // column of the block = row of the mirror
+                const int mi = bi + idx, mj = J0 + wc * MB + c;
+                const float v = sT[idx * (MB + 1) + c];
+                if (mi < n && mj < n) P[(size_t)mj * ldp + mi] = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// The step of the persistent kernel: the same products as px_step, operands fetched by hand-issued ds_read_b128.  The
+// compiler does not see these reads, so (a) it cannot put "s_waitcnt vmcnt(0)" in front of them -- it does that to any LDS read
+// that MAY alias an LDS-DMA in flight, and with a ring addressed by (step mod 3) every read may: the two slabs that are
+// supposed to travel during the step were drained before its first product -- and (b) their waits are written here: LDS
+// operations complete in order, so "at most k newer reads outstanding" is exact.  The waits name the registers they
+// release ("+v"), which keeps every product behind its wait.
+#ifndef PX_ABL
+#define PX_ABL 0 // timing ablations of scripts/micro/pu_i8_bench.hip only (WRONG results): 1 no epilogue, 2 no slab loads in the loop,
+                 // 4 no barrier, 8 no operand reads
+#endif
+#define PX_DS_READ(dst, addr, off)                                                                                            \
+    do {                                                                                                                      \
+        if (PX_ABL & 8) asm volatile("" : "=v"(dst));                                                                         \
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));                                 \
+    } while (0)
+template <bool FULL>
+__device__ __forceinline__ void px_step_ring(unsigned ldsA, unsigned ldsB, v16i (&acc)[2][PX_S])
+{
+    v4i b0, b1, b2, b3, b4, a[2][2];
+    PX_DS_READ(b0, ldsB, 4096);
+    PX_DS_READ(b1, ldsB, 4096 + 8192);
+    PX_DS_READ(b2, ldsB, 4096 + 2 * 8192);
+    PX_DS_READ(b3, ldsB, 4096 + 3 * 8192);
+    PX_DS_READ(b4, ldsB, 4096 + 4 * 8192);
+    PX_DS_READ(a[0][0], ldsA, 0);
+    if (FULL) PX_DS_READ(a[0][1], ldsA, 512);
+#define PX_GROUP(s_, cur, nxt)                                                                                                \
+    if (s_ + 1 < PX_S) {                                                                                                      \
+        PX_DS_READ(a[nxt][0], ldsA, (s_ + 1) * 8192);                                                                         \
+        if (FULL) PX_DS_READ(a[nxt][1], ldsA, (s_ + 1) * 8192 + 512);                                                         \
+    }                                                                                                                         \
+    if (s_ == 0) {                                                                                                            \
+        if (FULL) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(a[0][0]), "+v"(a[0][1])); \
+        else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(a[0][0]));          \
+    } else if (s_ + 1 < PX_S) {                                                                                               \
+        if (FULL) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a[cur][0]), "+v"(a[cur][1]));                                    \
+        else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a[cur][0]));                                                          \
+    } else {                                                                                                                  \
+        if (FULL) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[cur][0]), "+v"(a[cur][1]));                                    \
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[cur][0]));                                                          \
+    }                                                                                                                         \
+    {                                                                                                                         \
+        const v4i bb[PX_S] = {b0, b1, b2, b3, b4};                                                                            \
+        _Pragma("unroll") for (int t = 0; t < PX_S - s_; ++t) {                                                               \
+            acc[0][s_ + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[cur][0], bb[t], acc[0][s_ + t], 0, 0, 0);                \
+            if (FULL) acc[1][s_ + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[cur][1], bb[t], acc[1][s_ + t], 0, 0, 0);      \
+        }                                                                                                                     \
+    }
+    PX_GROUP(0, 0, 1)
+    PX_GROUP(1, 1, 0)
+    PX_GROUP(2, 0, 1)
+    PX_GROUP(3, 1, 0)
+    PX_GROUP(4, 0, 1)
+#undef PX_GROUP
+}
+
+// ---------------------------------------------------------------------------------- the downdate, persistent form
+// One workgroup per CU walks its share of the unit list (units slot, slot + slots, ... of its XCD's list: what the hardware
+// dispatcher does with one-unit workgroups when every unit takes the same time).  What this buys over k_p_update_i8:
+//   * the slab pipeline never drains: a ring of three 40 KB buffers, two steps of global_load_lds in flight (counted
+//     vmcnt, raw s_barrier -- __syncthreads() would drain the LDS-DMA), and the ring runs on ACROSS units: the first slabs
+//     of the next unit travel during the last steps and the epilogue of this one;
+//   * the epilogue's 64 KB read-modify-write of P hides behind MFMA work instead of ending every launch round in a burst:
+//     the old values are requested when the unit starts (32 registers), the new ones leave as fire-and-forget stores.
+constexpr int PX_RING = 3;
+constexpr int PX_MAXU = 32; // units one workgroup can be dealt (launch_p_update_exact checks)
+
+__global__ void __launch_bounds__(512, 2)
+k_p_update_i8p(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq, int ldq, size_t plane_stride, int m_k,
+               const int *__restrict__ bexp, int per_xcd, const int4 *__restrict__ units, int slots)
+{
+    constexpr int TM = 128, MB = 32, SLAB = PX_S * 8192;
+    constexpr int ST = MB + 4; // row stride of the epilogue's staging image: 16-byte aligned rows
+    __shared__ __attribute__((aligned(16))) unsigned char ring[PX_RING * SLAB];
+    __shared__ __attribute__((aligned(16))) float sTall[8 * MB * ST];
+    __shared__ int sExp[2][2 * TM];
+    __shared__ int4 sUnit[PX_MAXU];
+    __shared__ int sMeta[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wv >> 2, wc = wv & 3;
+    const int kg = lane >> 5, idx = lane & 31;
+    const int nk = m_k / 32;
+    {   // this workgroup's units: slot, slot + slots, ... of its XCD's list (see k_p_update), kept in LDS
+        const int4 *ul = units + (size_t)(blockIdx.x & 7) * per_xcd;
+        const int slot = blockIdx.x >> 3;
+        if (tid < PX_MAXU) {
+            const int u = slot + tid * slots;
+            sUnit[tid] = u < per_xcd ? ul[u] : make_int4(-1, -1, -1, 0);
+        }
+        if (tid == 0) {
+            sMeta[0] = ldp;
+            sMeta[1] = 0;
+        }
+        __syncthreads();
+    }
+    int n_units = 0;
+    while (n_units < PX_MAXU && sUnit[n_units].x >= 0) ++n_units;
+    n_units = __builtin_amdgcn_readfirstlane(n_units);
+    if (n_units == 0) return;
+    const int total = n_units * nk; // steps of the whole pipeline
+
+    // this wavefront's piece of every plane and step: wavefronts 0..3 the I side (k-group, column half), 4..7 the J side
+    // (half units fetch all 128 I columns too: every wavefront then has PX_S loads per step, which keeps the counted wait uniform)
+    const int pside = wv >> 2, pkg = (wv >> 1) & 1, phalf = wv & 1;
+    const size_t step_stride = (size_t)2 * ldq * 16;
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const int poff = wv * 1024;
+    int iu = 0, it = 0, ig = 0;      // issue cursor: unit, step, global step
+    const int8_t *gsrc;
+    {
+        const int4 u0 = sUnit[0];
+        gsrc = Bq + ((size_t)pkg * ldq + (pside ? u0.y : u0.x) * TM + 64 * phalf + lane) * 16;
+    }
+#define PXP_ISSUE()                                                                                                           \
+    if (ig < total) {                                                                                                         \
+        const int rb = (ig % PX_RING) * SLAB + poff;                                                                          \
+        _Pragma("unroll") for (int s = 0; s < PX_S; ++s)                                                                      \
+            __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + (size_t)s * plane_stride + (size_t)it * step_stride),            \
+                                             (lptr_t)(&ring[rb + s * 8192]), 16, 0, 0);                                       \
+        ++ig;                                                                                                                 \
+        if (++it == nk) {                                                                                                     \
+            it = 0;                                                                                                           \
+            ++iu;                                                                                                             \
+            if (iu < n_units) {                                                                                               \
+                const int4 un = sUnit[iu];                                                                                    \
+                gsrc = Bq + ((size_t)pkg * ldq + (pside ? un.y : un.x) * TM + 64 * phalf + lane) * 16;                        \
+            }                                                                                                                 \
+        }                                                                                                                     \
+    }
+    PXP_ISSUE()
+    PXP_ISSUE()
+    int g = 0; // global step being multiplied
+    const unsigned ring_lds = (unsigned)(size_t)(lptr_t)&ring[0]; // LDS byte address of the ring
+    float *sT = sTall + wv * MB * ST;
+    const bool late = wv >= 4; // see the k-loop
+    for (int ui = 0; ui < n_units; ++ui) {
+        const int4 unit = sUnit[ui];
+        const int ti = __builtin_amdgcn_readfirstlane(unit.x), tj = __builtin_amdgcn_readfirstlane(unit.y);
+        const int uz = __builtin_amdgcn_readfirstlane(unit.z);
+        const bool full = uz < 0;
+        const bool diag = ti == tj;
+        const int I0 = ti * TM, J0 = tj * TM;
+        const int rbase = full ? wr * 2 * MB : uz * 2 * MB + wr * MB; // first tile row of the wavefront (64 or 32 rows)
+        const int offA = (kg * TM + rbase + idx) * 16, offB = (kg * TM + wc * MB + idx) * 16;
+        if (tid < 2 * TM) { // the tile's row and column scales, for the epilogue
+            const int c = (tid < TM ? I0 : J0 - TM) + tid;
+            sExp[ui & 1][tid] = c < n ? bexp[c] - 1022 : 0;
+        }
+        v16i acc[2][PX_S];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int L = 0; L < PX_S; ++L)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][L][r] = 0;
+#define PXP_LOOP(FULL_)                                                                                                       \
+    for (int t = 0; t < nk; ++t, ++g) {                                                                                       \
+        /* step g has landed (this wavefront's pieces): everything but the PX_S loads of step g + 1 is complete */            \
+        if (g + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PX_S) : "memory");                                        \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                 \
+        if (!(PX_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); /* everyone's have; everyone has left buffer g - 1 */  \
+        /* wavefronts w and w + 4 share a SIMD: one of them requests its pieces of step g + 2 before its products, the   */    \
+        /* other after them, so that one multiplies while the other issues (an LDS-DMA costs 60-180 issue cycles)      */    \
+        if (!late && !(PX_ABL & 2)) { PXP_ISSUE() }                                                                           \
+        px_step_ring<FULL_>(ring_lds + (g % PX_RING) * SLAB + offA, ring_lds + (g % PX_RING) * SLAB + offB, acc);             \
+        if (late && !(PX_ABL & 2)) { PXP_ISSUE() }                                                                            \
+    }
+        if (full) { PXP_LOOP(true) } else { PXP_LOOP(false) }
+#undef PXP_LOOP
+        if (PX_ABL & 1) {
+            int h = 0;
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int L = 0; L < PX_S; ++L)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) h ^= acc[x][L][r];
+            if (h == 0x12345677) P[0] = 0.f;
+            continue;
+        }
+        // epilogue: v = 2^(e_i + e_j - 12) sum_L acc_L 256^-L, P <- fl32(P - v); off-diagonal tiles also write the mirror image
+        // (the epilogue's addresses are formed from a copy of ldp the compiler cannot see through -- read back from LDS --:
+        // otherwise it computes all 64 store addresses BEFORE the k-loop and spills them, 190 registers, around it)
+        float *Pe = P;
+        const int lde = __builtin_amdgcn_readfirstlane(sMeta[0]); // = ldp, read back from LDS after the loop
+        float *sTe = sT + __builtin_amdgcn_readfirstlane(sMeta[1]); // + 0
+        const int *se = sExp[ui & 1];
+        const int ej = se[TM + wc * MB + idx];
+        float *pe = Pe + (size_t)(I0 + rbase) * lde + J0 + wc * MB;
+        const int le = 4 * kg * lde + idx;
+        // P is addressed as (wavefront-uniform origin) + (lane offset) + (uniform row step).  Rows / columns up to the tile
+        // grid's edge exist (the engine allocates P to a multiple of 128 rows), so the loads need no guards; the stores are
+        // guarded.  The old values are requested here, not before the k-loop: 16 or 32 more live registers beside the 160
+        // accumulators spill inside the loop.  The stores are fire-and-forget: they drain under the next unit's k-loop.
+        float pv0[16], pv1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pv0[r] = (pe + ((r & 3) + 8 * (r >> 2)) * lde)[le];
+        if (full) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pv1[r] = (pe + (MB + (r & 3) + 8 * (r >> 2)) * lde)[le];
+        }
+        float *pm = Pe + (size_t)(J0 + wc * MB) * lde + I0 + rbase; // mirror image of block (0, .)
+        // Both images of a block leave through the wavefront's staging area as 16-byte stores (a store instruction costs the
+        // same issue time whatever its width: 64 four-byte stores per lane and unit were most of a unit's fixed cost):
+        //   direct image  [row][column], rows of ST floats: lane (q8, q4) reads columns 4 q4 .. + 3 of rows 8 it + q8;
+        //   mirror image  [column][row]: the same read pattern gives rows 4 q4 .. + 3 of the mirror's row 8 it + q8.
+        const int q8 = lane >> 3, q4 = lane & 7;
+        float *sTd = sTe + 4 * kg * ST + idx;  // + (row of the register) x ST: an immediate offset
+        float *sTt = sTe + idx * ST + 4 * kg;  // + (row of the register)
+        const float4 *sTq = reinterpret_cast<const float4 *>(sTe + q8 * ST + 4 * q4);
+        const int lq = q8 * lde + 4 * q4;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            if (x == 1 && !full) continue;
+            const int bi = I0 + rbase + x * MB;
+            float out[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int li = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                double tsum = (double)acc[x][PX_S - 1][r];
+#pragma unroll
+                for (int L = PX_S - 2; L >= 0; --L) tsum = fma(tsum, 1.0 / 256.0, (double)acc[x][L][r]);
+                const double v = ldexp(tsum, se[rbase + x * MB + li] + ej - 12);
+                out[r] = (float)((double)(x == 0 ? pv0[r] : pv1[r]) - v);
+                sTd[((r & 3) + 8 * (r >> 2)) * ST] = out[r];
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const float4 v = sTq[i4 * 8 * ST / 4];
+                const int gi = bi + 8 * i4 + q8, gj0 = J0 + wc * MB + 4 * q4;
+                float *dst = (pe + (x * MB + 8 * i4) * lde) + lq;
+                if (gi < n) {
+                    if (gj0 + 3 < n) *reinterpret_cast<float4 *>(dst) = v;
+                    else { // the ragged last column tile (n is not a multiple of 4): the padding stays untouched
+                        if (gj0 < n) dst[0] = v.x;
+                        if (gj0 + 1 < n) dst[1] = v.y;
+                        if (gj0 + 2 < n) dst[2] = v.z;
+                    }
+                }
+            }
+            if (!diag) { // rows of an off-diagonal tile are all < n (its row range ends before its column range starts)
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sTt[(r & 3) + 8 * (r >> 2)] = out[r];
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const float4 v = sTq[i4 * 8 * ST / 4];
+                    const int mj = J0 + wc * MB + 8 * i4 + q8; // row of the mirror = column of the block
+                    if (mj < n) *reinterpret_cast<float4 *>((pm + x * MB + 8 * i4 * lde) + lq) = v;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+#undef PXP_ISSUE
+}
+
+// ------------------------------------------------------------------------------------------------ launcher
+void build_units(EkfEngine *e, int nt, int nrt, bool rect, int order); // kernels_pupdate.hip
+
+int g_px_variant = 0; // scripts/micro/pu_i8_bench.hip only: 1 = one workgroup per unit (k_p_update_i8)
+
+// B (fp64, k-major, ld = e->ldP) sits in e->d.A; camera columns from e->d.Bc when use_bc
+void launch_p_update_exact(EkfEngine *e, int m, bool use_bc)
+{
+    hipStream_t s = e->stream;
+    const int n = e->n, ld = e->ldP;
+    const int n_pad = round_up(n, LD_ALIGN);
+    const int m_k = round_up(m, 32);
+    const double *B = (const double *)e->d.A;
+    const double *Bc = use_bc ? e->d.Bc : nullptr;
+    const size_t plane_stride = (size_t)e->bq_rows * ld; // bytes per digit plane
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (e->timing) {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventCreate(&e2);
+        (void)hipEventRecord(e2, s);
+    }
+    (void)hipMemsetAsync(e->d.Bexp, 0, sizeof(int) * (size_t)ld, s);
+    k_col_exp<<<dim3((n_pad + 255) / 256, PX_KSPLIT), 256, 0, s>>>(B, ld, m, n_pad, Bc, e->d.Bexp);
+    k_slice_B<<<dim3(n_pad / 64, (m_k + 63) / 64), 256, 0, s>>>(B, ld, m, m_k, Bc, e->d.Bexp, e->d.Bq, ld, plane_stride);
+    const int nt = (n + 127) / 128;
+    const int slots_saved = e->pu_slots;
+    e->pu_slots = e->n_cus; // one 512-thread workgroup per CU is resident (160 accumulator registers per lane)
+    build_units(e, nt, 0, false, 0);
+    e->pu_slots = slots_saved;
+    const int grid = e->pu_per_xcd * 8;
+    const int4 *tm = (const int4 *)e->d.pu_tilemap;
+    if (e->timing) (void)hipEventRecord(e0, s);
+    if (!e->p_exact_sym) k_p_update_i8<true><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
+    else if (g_px_variant == 1) k_p_update_i8<false><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
+    else k_p_update_i8p<<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8);
+    if (e->timing) {
+        (void)hipEventRecord(e1, s);
+        e->pu_events.emplace_back(e0, e1);
+        e->pu_work.push_back((double)n * (double)n * (double)m);
+        e->pu_m.push_back(m);
+        e->px_events.emplace_back(e2, e0); // the two slicing kernels
+    }
+    e->p_exact_sym = true;
+}
+
+} // namespace ekf

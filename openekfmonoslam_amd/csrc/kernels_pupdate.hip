@@ -504,7 +504,7 @@ k_p_update_f32(float *P, int ldp, int n, const float *B, int ldb, int m_k, int p
 int g_pu_order_override = -1; // scripts/micro/pu_bench.hip only
 
 // order: 0 half units last, 1 half units first, 2 mixed first round (see below)
-static void build_units(EkfEngine *e, int nt, int nrt, bool rect, int order)
+void build_units(EkfEngine *e, int nt, int nrt, bool rect, int order)
 {
     if (g_pu_order_override >= 0) order = g_pu_order_override;
     const long long key = ((long long)(rect ? -(nt * 4096 + nrt) : nt) * 4 + order) * 4096 + e->pu_slots;

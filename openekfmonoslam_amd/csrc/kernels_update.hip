@@ -185,10 +185,10 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 //   S itself is only read in column k, B only in rows above k, nu / Gc only in rows k: nothing races inside a launch.
 // Above B_SWEEP_MAX rows B = inv(L) G is not part of the sweep: the factor is inverted explicitly (k_inv_diag,
 // k_triinv_level) and B is one GEMM against it (k_xty, kernels_gemm.hip).
-template <typename T>
+template <typename T, typename TG> // T: type of B and of its MFMA; TG: storage type of the gathered rows G (EKF_PRECISION_F32_EXACT: double / float)
 __global__ void __launch_bounds__(256)
 k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0, int kb, double *nu, int n_stiles, double *V,
-            double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc, const T *G, T *Bout, int ld,
+            double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc, const TG *G, T *Bout, int ld,
             int n_bblocks, int n_rhs, int tiles_first, int spacer, unsigned long long *trace, int abl)
 {
 #ifdef EKF_SWEEP_TRACE // debug builds only (scripts/sweep_trace.py): per-role time stamps and role ablations
@@ -276,7 +276,7 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         const T *Lt = sizeof(T) == 4 ? (const T *)LLf : (const T *)LL; // L' above the diagonal blocks, in T
         // this thread's four elements of G_k, requested first: they are cold and only needed at the end
         const int r = tid >> 3, cg = (tid & 7) * 4;
-        T g4[4];
+        TG g4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) g4[e] = G[(size_t)(k0 + r) * ld + c0 + cg + e];
         typename M::acc_t acc[NBLK][NBLK];
@@ -864,10 +864,10 @@ __global__ void __launch_bounds__(256) k_yvec(const double *W, int ldw, int m, c
     if (lane == 0) y[i] = s;
 }
 
-template <typename T, bool USE_G>
+template <typename T, bool USE_G, typename TG = T> // T: type of B; TG: storage type of P and G
 __global__ void __launch_bounds__(256)
 k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, int ldpart, double *sq_part, double *cam_part,
-             const double *Bc, const T *P, RowMap rm, double *dsave, double *csave, int avg, const T *G, const double *y)
+             const double *Bc, const TG *P, RowMap rm, double *dsave, double *csave, int avg, const TG *G, const double *y)
 {
     __shared__ double sc[64][13]; // fp64 camera columns of a chunk of rows of B
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -876,11 +876,11 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
         // phase 0 of the fp64 fix (k_fix_normalize): keep the diagonal and the camera rows of P as they are before the downdate
         // (avg: the first downdate after an arbitrary upload works on 0.5 (P(a,j) + P(j,a)))
         const bool mine = owns_row(rm, j);
-        const T *prow = P + (size_t)local_row(rm, j) * ld;
+        const TG *prow = P + (size_t)local_row(rm, j) * ld;
         if (mine) dsave[j] = (double)prow[j];
 #pragma unroll
         for (int a = 0; a < 13; ++a)
-            csave[(size_t)a * ldpart + j] = avg ? (double)((T)0.5 * P[(size_t)a * ld + j] + (T)0.5 * prow[a]) : (double)P[(size_t)a * ld + j];
+            csave[(size_t)a * ldpart + j] = avg ? (double)((TG)0.5 * P[(size_t)a * ld + j] + (TG)0.5 * prow[a]) : (double)P[(size_t)a * ld + j];
     }
     const int per = (m + DX_SPLIT - 1) / DX_SPLIT;
     const int kb = ks * per, ke = min(m, kb + per);
@@ -898,12 +898,13 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
         if (j < n) {
             // the whole chunk's rows are requested before the first is used: a split is one round trip to memory, not
             // one per few rows (the loop was latency-bound: 30 us for 23 MB)
-            T bv[64], gv[USE_G ? 64 : 1];
+            T bv[64];
+            TG gv[USE_G ? 64 : 1];
 #pragma unroll
             for (int u = 0; u < 64; ++u) {
                 const int k = min(u, cnt - 1);
                 bv[u] = B[(size_t)(k0 + k) * ld + j];
-                if (USE_G) gv[u] = j >= 13 ? G[(size_t)(k0 + k) * ld + j] : (T)0;
+                if (USE_G) gv[u] = j >= 13 ? G[(size_t)(k0 + k) * ld + j] : (TG)0;
             }
 #pragma unroll
             for (int u = 0; u < 64; ++u) {
@@ -1145,22 +1146,25 @@ k_fix_normalize(T *P, int ld, int n, RowMap rm, const double *dsave, const doubl
 // P-update launcher lives in kernels_pupdate.hip
 void launch_p_update(EkfEngine *e, int m_pad, int m);
 
-template <typename T>
+// T: storage type of P, H P and the gathered rows G; TB: type of B = inv(L) G and of the arithmetic that forms it
+// (TB = T except EKF_PRECISION_F32_EXACT: T = float, TB = double, the downdate by kernels_pexact.hip)
+template <typename T, typename TB>
 static void update_impl(EkfEngine *e, int M, bool update_cov)
 {
+    constexpr bool EXACT = sizeof(T) != sizeof(TB);
     hipStream_t s = e->stream;
     const int m = 2 * M, n = e->n, ld = e->ldP, ldS = e->ldS, ldw = e->ldW;
     const int m_pad = round_up(m, NB);
     const int n_pad = round_up(n, LD_ALIGN);
     T *G = (T *)e->d.G; // gathered rows of H P
-    T *A = (T *)e->d.A; // B = inv(L) G
+    TB *A = (TB *)e->d.A; // B = inv(L) G
     // B = inv(L) G: up to B_SWEEP_MAX rows, row block k is formed inside the launch of panel k (forward substitution
     // beside the look-ahead factorisation: no explicit inverse, no GEMM launch); above it the per-launch row block becomes
     // longer than the factorisation it hides behind, and the explicit inverse + one big-tile GEMM is the better use of
     // the MFMA pipe.  e->b_path (ekf_set_update_path): 0 by size, 1 always in the sweep, 2 always by GEMM.
     const bool b_in_sweep = e->b_path == 1 || (e->b_path == 0 && m_pad <= B_SWEEP_MAX);
     double *V = e->d.Dinv, *W = b_in_sweep ? nullptr : e->d.W; // W = inv(L)' (and L row-major in LL): the GEMM path's
-    float *Wf = e->f32 && !b_in_sweep ? e->d.Wf : nullptr;
+    float *Wf = sizeof(TB) == 4 && !b_in_sweep ? e->d.Wf : nullptr;
     {
         dim3 grid((n_pad / (int)(16 / sizeof(T)) + 255) / 256, m_pad);
         k_gather<T><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const T *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
@@ -1210,7 +1214,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const int n_stiles = nrb == 0 ? 0 : 1 + (nrb >= 2 ? nsr * (nsr + 1) / 2 : 0); // look-ahead tile + groups
         const int n_rhs_blocks = max(1, (m - k2 + 63) / 64); // right-hand-side blocks, 64 rows each
         // pair launches of a large fp32 map: 64 columns of B per workgroup (chol_pair.h, b_pair_rows_wide)
-        const bool b_wide = pair_launch && kbB > 0 && sizeof(T) == 4 && n_bblocks > e->n_cus;
+        const bool b_wide = pair_launch && kbB > 0 && sizeof(TB) == 4 && n_bblocks > e->n_cus;
         const int n_bw = b_wide ? n_pad / (2 * NB) : n_bblocks;
         const int n_wgs = n_stiles + n_rhs_blocks + n_bw;
         const int spacer = n_wgs > e->n_cus ? e->n_cus : 0; // see k_chol_step: empty blocks where the look-ahead workgroup's CU comes round again
@@ -1227,13 +1231,13 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         }
 #endif
         if (pair_launch) {
-            k_chol_pair<T><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(T) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, kbB, k2,
+            k_chol_pair<TB, T><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(TB) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, kbB, k2,
                                                              e->d.nu, n_stiles, V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
                                                              e->d.zvec, e->d.Bc, G, A, ld, n_bw, n_rhs_blocks, n_wgs > e->n_cus ? 1 : 0, spacer, tr, b_wide ? 1 : 0);
             k0 += have_pair ? 2 * NB : NB;
             have_pair = true;
         } else {
-            k_chol_step<T><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(T) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, e->d.nu, n_stiles,
+            k_chol_step<TB, T><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(TB) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, e->d.nu, n_stiles,
                                                              V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
                                                              e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks,
                                                              n_wgs > e->n_cus ? 1 : 0, spacer, tr, tr_abl);
@@ -1261,20 +1265,20 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         }
     }
     if (!b_in_sweep) {   // B = inv(L) G = W' G : one GEMM, k <= row (W upper triangular)
-        const int TM = sizeof(T) == 4 ? 128 : 64;
+        const int TM = sizeof(TB) == 4 ? 128 : 64;
         XtyArgs g{};
-        g.X = e->f32 ? (const void *)Wf : (const void *)W; g.ldx = ldw;
+        g.X = sizeof(TB) == 4 ? (const void *)Wf : (const void *)W; g.ldx = ldw;
         g.Y = G; g.ldy = ld;
         g.C = A; g.ldc = ld;
         g.M = m_pad; g.N = n_pad; g.K = m_pad;
         g.row0_first = 0; g.row0_stride = 0; g.m_lim = m_pad;
         g.tri = 2; g.tiles_i = (m_pad + TM - 1) / TM; g.tiles_j = (n_pad + TM - 1) / TM; g.alpha = 1.0;
         g.n_split = g.tiles_i / 2; // k-depth of row tile i is ~(i+1) TM: halve the units of the longer half
-        launch_xty(e, g, 1, e->f32, s);
+        launch_xty(e, g, 1, sizeof(TB) == 4, s, EXACT);
     }
     {
         dim3 grid((n + 255) / 256, DX_SPLIT);
-        const bool fix = update_cov && sizeof(T) == 4;
+        const bool fix = update_cov && sizeof(T) == 4 && !EXACT; // (the exact downdate needs no fp64 repair of the diagonal / camera rows)
         const int avg = e->p_exact_sym ? 0 : 1; // an AVG downdate only exists on an unsharded engine: every row is local
         const double *Bc = nullptr;
         const T *Gy = nullptr;
@@ -1285,7 +1289,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             Gy = need_inverse ? G : nullptr;
             if (Gy) k_yvec<<<(m + 3) / 4, 256, 0, s>>>(W, ldw, m, e->d.zvec, e->d.yvec);
         }
-#define DX_LAUNCH(USEG) k_dx_partial<T, USEG><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, \
+#define DX_LAUNCH(USEG) k_dx_partial<TB, USEG, T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, \
                                              fix ? e->d.sq_part : nullptr, fix ? e->d.cam_part : nullptr, Bc, (const T *)e->d.P, \
                                              e->rm, e->d.diag_save, fix ? e->d.cam_save : nullptr, avg, Gy, e->d.yvec);
         if (Gy) { DX_LAUNCH(true) } else { DX_LAUNCH(false) }
@@ -1296,8 +1300,9 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
                                                        e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
     }
     if (!update_cov) return;
-    const bool fix_diag = sizeof(T) == 4;
-    launch_p_update(e, m_pad, m);
+    const bool fix_diag = sizeof(T) == 4 && !EXACT;
+    if (EXACT) launch_p_update_exact(e, m, true);
+    else launch_p_update(e, m_pad, m);
     if (fix_diag) {
         k_fix_normalize<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save,
                                                            e->d.cam_part, ld, e->d.state);
@@ -1310,8 +1315,9 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
 void launch_update(EkfEngine *e, int M, bool update_cov)
 {
     if (M <= 0) return;
-    if (e->f32) update_impl<float>(e, M, update_cov);
-    else update_impl<double>(e, M, update_cov);
+    if (e->exact) update_impl<float, double>(e, M, update_cov);
+    else if (e->f32) update_impl<float, float>(e, M, update_cov);
+    else update_impl<double, double>(e, M, update_cov);
 }
 
 } // namespace ekf

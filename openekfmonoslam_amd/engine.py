@@ -16,7 +16,7 @@ from .ekftypes import (DESC_BYTES, KEYPOINT_DTYPE, MATCH_DTYPE, PREDICTION_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libekf_engine.so")
-PRECISION_F64, PRECISION_F32 = 0, 1
+PRECISION_F64, PRECISION_F32, PRECISION_F32_EXACT = 0, 1, 2
 
 
 class EkfEngineConfig(C.Structure):

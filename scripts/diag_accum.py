@@ -5,6 +5,8 @@ S = G H' + R, L = chol(S), B = inv(L) G) and evaluates (B'B)[i][j] on sampled co
   E_bcomp   B from an fp32 blocked forward substitution (fp32 L, fp32 partial sums like the sweep's B role), sums in fp64
   E_seq     B rounded to fp32, k-sequential fp32 fmaf chain (what v_mfma_f32_32x32x2 does)
   E_chunk16 / E_chunk32   the same chain restarted every 16 / 32 rows, chunks added in fp64
+  E_i8xS    fp64 B cut per COLUMN into S balanced int8 digits (scale = power of two >= the column's max |B|), digit
+            products of level s + t < S only, integer sums exact (what v_mfma_i32_32x32x32_i8 does), levels combined in fp64
 Errors are absolute, against the fp64 value; also shown relative to rms|(B'B)[i][j]| of the sampled pairs."""
 import ctypes as C
 import os
@@ -120,6 +122,37 @@ res = {
     "E_chunk16": dots(B32, 16),
     "E_engine~ (B by fp32 subst. + fp32 fmaf chain)": dots(Bc, 0),
 }
+
+
+def slices(Bm, S):
+    """balanced base-256 digits of every column of Bm relative to a power-of-two column scale: Bm ~ scale * sum_s d_s 256^-(s+1)"""
+    cmax = np.abs(Bm).max(axis=0)
+    scale = np.where(cmax > 0, 2.0 ** np.ceil(np.log2(np.where(cmax > 0, cmax, 1.0)) + 1e-12), 1.0)  # |Bm / scale| <= 1
+    # integer image of the column first, digits from the least significant end: every digit in [-128, 127], no digit overflow
+    X = np.rint(Bm / scale * 0.5 * 256.0 ** S).astype(np.int64)
+    X = np.clip(X, -(2 ** (8 * S - 1)) + 1, 2 ** (8 * S - 1) - 1 - 128 * sum(256 ** i for i in range(S - 1)) if S > 1 else 127)
+    digs = [None] * S
+    for s_ in range(S - 1, -1, -1):
+        d = ((X + 128) % 256) - 128
+        X = (X - d) // 256
+        digs[s_] = d
+    assert np.all(X == 0) and all(np.abs(d).max() <= 128 and d.max() <= 127 for d in digs)
+    return scale * 2.0, digs                             # value = scale2 * sum_s d_s 256^-(s+1)
+
+
+def dots_i8(Bm, S):
+    scale, digs = slices(Bm, S)
+    out = np.zeros(len(pi))
+    for lvl in range(S):
+        acc = np.zeros(len(pi), dtype=np.int64)
+        for s_ in range(lvl + 1):
+            acc += np.einsum("kp,kp->p", digs[s_][:, pi], digs[lvl - s_][:, pj])
+        out += acc.astype(np.float64) * 256.0 ** -(lvl + 2)
+    return out * scale[pi] * scale[pj]
+
+
+for S_ in (3, 4, 5):
+    res[f"E_i8x{S_}    (fp64 B in {S_} int8 digits per column, levels < {S_}, exact sums)"] = dots_i8(B, S_)
 rms = np.sqrt((exact ** 2).mean())
 sm = pj == col
 print(f"sampled cross-feature pairs: {len(pi)}; rms|(B'B)_ij| {rms:.2e}; pairs with the smallest-|rho| feature's rho column ({fsm}, rho={fp[fsm, 5]:.2e}): {sm.sum()}")
