@@ -259,6 +259,9 @@ int ekf_timing_p_update_launches(EkfEngine *e, int capacity, int32_t *m_rows, fl
  * flops of the factorisation (m^3 / 3 each) and the flops of B = inv(L) (H P) formed in the same launches (m^2 n each;
  * 0 for updates that went through the explicit inverse + GEMM).  Any output pointer may be null. */
 int ekf_timing_sweep(EkfEngine *e, double *kernel_ms, int64_t *panels, int64_t *updates, double *flops_fp64, double *flops_b);
+/* ... and the number of kernel launches behind those panels (a launch of the two-panels-per-launch scheme covers two), plus,
+ * EKF_PRECISION_F32_EXACT only, the HIP-event time of the column-scale + digit-plane kernels that precede each exact downdate. */
+int ekf_timing_sweep_launches(EkfEngine *e, int64_t *launches, double *slice_ms);
 
 /* -- row-sharded filter (multi-GPU) ----------------------------------------------------------
  * One engine per GPU / rank.  Rank g stores the 13 camera rows of P (replicated, updated identically everywhere)

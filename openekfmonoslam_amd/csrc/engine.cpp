@@ -126,6 +126,7 @@ void ekf_engine_destroy(EkfEngine *e)
         if (kv.second.first) (void)hipFree(kv.second.first);
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto &pr : e->px_events) (void)hipEventDestroy(pr.first);
     for (auto &pr : e->pu_events) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
@@ -228,17 +229,18 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
                                    : SHARD_BASE + round_up(6 * ((e->cap + world - 1) / world), LD_ALIGN) + LD_ALIGN;
         if ((st = dalloc(&raw, (size_t)e->p_rows_cap * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc P");
         d.P = raw;
-        if ((st = dalloc(&raw, (size_t)mcap * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc HP");
+        const size_t wb = e->exact ? 8 : w; // element size of H P, its gathered rows and B = inv(L) G
+        if ((st = dalloc(&raw, (size_t)mcap * e->ldP * wb)) != hipSuccess) return fail(st, "hipMalloc HP");
         d.HP = raw;
         // + one row: the row operand of a sharded downdate tile may read up to 127 columns past n
-        if ((st = dalloc(&raw, (size_t)(mcap + 1) * e->ldP * (e->exact ? 8 : w))) != hipSuccess) return fail(st, "hipMalloc A"); // B = inv(L) G: fp64 beside the exact downdate
+        if ((st = dalloc(&raw, (size_t)(mcap + 1) * e->ldP * wb)) != hipSuccess) return fail(st, "hipMalloc A");
         d.A = raw;
         if (e->exact) { // digit planes of B and their column scales (kernels_pexact.hip)
             e->bq_rows = round_up((int)mcap, 64) + 64;
             if ((st = dalloc(&d.Bq, (size_t)PX_S * e->bq_rows * e->ldP)) != hipSuccess) return fail(st, "hipMalloc Bq");
             if ((st = dalloc(&d.Bexp, (size_t)e->ldP)) != hipSuccess) return fail(st, "hipMalloc Bexp");
         }
-        if ((st = dalloc(&raw, (size_t)(mcap + 1) * e->ldP * w)) != hipSuccess) return fail(st, "hipMalloc G");
+        if ((st = dalloc(&raw, (size_t)(mcap + 1) * e->ldP * wb)) != hipSuccess) return fail(st, "hipMalloc G");
         d.G = raw;
     }
     ALLOC(d.mm_scratch, (size_t)60 * cap + 4 * (size_t)e->ldP + 64);
@@ -1219,6 +1221,12 @@ int ekf_rescue(EkfEngine *e, const EkfMatch *outliers, int M, uint8_t *rescued_m
 // ------------------------------------------------------------------------------------------------------ step
 static void harvest_pu_events(EkfEngine *e)
 {
+    for (auto &pr : e->px_events) { // exact downdate: the column-scale + digit-plane kernels (their end event is the downdate's start event, destroyed below)
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) e->slice_ms += ms;
+        (void)hipEventDestroy(pr.first);
+    }
+    e->px_events.clear();
     for (size_t i = 0; i < e->pu_events.size(); ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e->pu_events[i].first, e->pu_events[i].second) == hipSuccess) {
@@ -1240,6 +1248,7 @@ static void harvest_pu_events(EkfEngine *e)
             const double m = std::abs(e->sw_m[i]);
             e->sweep_ms += ms;
             e->sweep_panels += ((long long)m + NB - 1) / NB;
+            e->sweep_launches += i < e->sw_launch.size() ? e->sw_launch[i] : 0;
             e->sweep_updates += 1;
             e->sweep_flops_f64 += m * m * m / 3.0;                        // Cholesky of S
             if (e->sw_m[i] > 0) e->sweep_flops_b += m * m * (double)e->n;  // B = inv(L) (H P): forward substitution, m^2 n
@@ -1248,6 +1257,7 @@ static void harvest_pu_events(EkfEngine *e)
         (void)hipEventDestroy(e->sw_events[i].second);
     }
     e->sw_events.clear();
+    e->sw_launch.clear();
     e->sw_m.clear();
 }
 
@@ -1820,7 +1830,8 @@ int ekf_timing_reset(EkfEngine *e)
     e->pu_log.clear();
     std::memset(&e->times, 0, sizeof(e->times));
     e->sweep_ms = e->sweep_flops_f64 = e->sweep_flops_b = 0.0;
-    e->sweep_panels = e->sweep_updates = 0;
+    e->sweep_panels = e->sweep_updates = e->sweep_launches = 0;
+    e->slice_ms = 0.0;
     return EKF_OK;
 }
 
@@ -1843,6 +1854,16 @@ int ekf_timing_sweep(EkfEngine *e, double *kernel_ms, int64_t *panels, int64_t *
     if (updates) *updates = e->sweep_updates;
     if (flops_fp64) *flops_fp64 = e->sweep_flops_f64;
     if (flops_b) *flops_b = e->sweep_flops_b;
+    return EKF_OK;
+}
+
+int ekf_timing_sweep_launches(EkfEngine *e, int64_t *launches, double *slice_ms)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    (void)hipStreamSynchronize(e->stream);
+    harvest_pu_events(e);
+    if (launches) *launches = e->sweep_launches;
+    if (slice_ms) *slice_ms = e->slice_ms;
     return EKF_OK;
 }
 

@@ -77,7 +77,7 @@ struct DeviceArrays {
     double *pred_S = nullptr;  // 4 per feature
     double *Hs = nullptr;      // 2x7 per feature
     double *Hf = nullptr;      // 2x6 per feature
-    void *HP = nullptr;        // T [2*cap x ldP]: rows 2f, 2f+1 = H_f P
+    void *HP = nullptr;        // T [2*cap x ldP]: rows 2f, 2f+1 = H_f P   (fp64 in EKF_PRECISION_F32_EXACT)
     // work lists
     int *work_idx = nullptr;   // input feature indices of a subset prediction
     int *work_flag = nullptr;  // per work item: predicted?
@@ -168,8 +168,8 @@ struct EkfEngine {
     int cap = 0, ncap = 0, mcap = 0, kcap = 0;
     int ldP = 0, ldS = 0, ldW = 0;
     int N = 0, n = 0;
-    bool f32 = false;   // P, H P and the gathered rows stored in fp32
-    bool exact = false; // EKF_PRECISION_F32_EXACT: fp32 storage, B in fp64, downdate with exact accumulation (kernels_pexact.hip)
+    bool f32 = false;   // P stored in fp32 (and, unless `exact`, H P, its gathered rows and B)
+    bool exact = false; // EKF_PRECISION_F32_EXACT: P in fp32; H P, G and B in fp64; downdate with exact accumulation (kernels_pexact.hip)
     int desc_bytes = EKF_DESC_BYTES; // bytes per descriptor row
     bool desc_f32 = false;           // CV_32F descriptors / L2 distance (Matching.cpp:60-73) instead of CV_8U / Hamming
     // row sharding: world == 1 means the whole matrix lives here
@@ -218,8 +218,10 @@ struct EkfEngine {
     std::vector<std::pair<int, float>> pu_log;                 // harvested (m, ms) per launch
     std::vector<std::pair<hipEvent_t, hipEvent_t>> sw_events;  // brackets of the Cholesky sweep's launches of one update
     std::vector<int> sw_m;                                     // m of each bracket
+    std::vector<int> sw_launch;                                // launches of each bracket (pair launches cover two panels)
     double sweep_ms = 0.0, sweep_flops_f64 = 0.0, sweep_flops_b = 0.0; // harvested totals (ekf_timing_sweep)
-    long long sweep_panels = 0, sweep_updates = 0;
+    long long sweep_panels = 0, sweep_updates = 0, sweep_launches = 0;
+    double slice_ms = 0.0;                                     // exact downdate: column scales + digit planes (harvested)
     // host scratch
     std::vector<int> h_counts;
     int *h_mirror = nullptr, *d_mirror = nullptr; // GPU-writable host page: counters + sequence number (read_counts)
@@ -243,7 +245,7 @@ struct XtyArgs {
     int n_split;                          // bottom row tiles cut into two half units (tri == 2, batch 1 only)
     double alpha;
 };
-void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32, hipStream_t stream, bool y_f32 = false); // y_f32: fp32 Y beside fp64 arithmetic
+void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32, hipStream_t stream);
 
 // Exclusive prefix sum of one int per thread over a 1024-thread workgroup (and the total): inside a wavefront by shuffles,
 // across the 16 wavefronts through LDS -- one barrier, where a Hillis-Steele scan in LDS needs twenty.  Device code only.

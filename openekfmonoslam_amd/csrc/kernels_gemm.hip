@@ -9,19 +9,13 @@
 #include "engine.h"
 #include "mma_tile.h"
 
-#include <type_traits>
-
 namespace ekf {
 
 // BK: k-slab depth.  The fp64 instances are small, latency-bound GEMMs (a 64x64 tile's MFMAs of one 16-deep slab take
 // 0.2 us, a global load round trip over 1 us), so they run with 32-deep slabs: half as many round trips.
-// YF32 (T = double only, EKF_PRECISION_F32_EXACT): Y is stored in fp32 (the gathered rows of the fp32 H P) and widened
-// on its way into the staging registers; X, the arithmetic and C are fp64.
-template <typename T, int BK, bool YF32 = false>
+template <typename T, int BK>
 __global__ void __launch_bounds__(256, BK * sizeof(T) >= 128 ? 2 : 3) k_xty(XtyArgs a)
 {
-    static_assert(!YF32 || sizeof(T) == 8, "a narrower Y only beside fp64 arithmetic");
-    typedef typename std::conditional<YF32, float, T>::type TY;
     using M = Mma<T>;
     constexpr int MB = M::MB, TM = 4 * MB, VEC = M::VEC;
     constexpr int LOADS = BK * TM / (256 * VEC);
@@ -50,7 +44,7 @@ __global__ void __launch_bounds__(256, BK * sizeof(T) >= 128 ? 2 : 3) k_xty(XtyA
     const int Mb = min(a.M, a.m_lim - (a.row0_first + b * a.row0_stride));
     if (I0 >= Mb) return;
     const T *X = (const T *)a.X + (size_t)b * a.xb;
-    const TY *Y = (const TY *)a.Y + (size_t)b * a.yb;
+    const T *Y = (const T *)a.Y + (size_t)b * a.yb;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv >> 1, wc = wv & 1;
@@ -66,31 +60,20 @@ __global__ void __launch_bounds__(256, BK * sizeof(T) >= 128 ? 2 : 3) k_xty(XtyA
     const int k_hi = a.tri == 2 ? min(a.K, I0 + TM) : a.K;
     const int nk = (k_hi - k_lo) / BK; // K, the tile edges and BK are multiples of 32 (16 for fp32): whole slabs
     using V = typename M::vec_t;
-    auto ldy = [](const TY *p) -> V {
-        if constexpr (YF32) {
-            const float2 f = *(const float2 *)p;
-            V o;
-            o.x = (double)f.x;
-            o.y = (double)f.y;
-            return o;
-        } else {
-            return *(const V *)p;
-        }
-    };
     const size_t xslab = (size_t)BK * a.ldx, yslab = (size_t)BK * a.ldy;
 #define XT_PIECE(q)                                                                                              \
     const int lk##q = ((tid + q * 256) * VEC) / TM, lc##q = ((tid + q * 256) * VEC) % TM;                         \
     const T *gI##q = X + (size_t)(k_lo + lk##q) * a.ldx + I0 + lc##q;                                            \
-    const TY *gJ##q = Y + (size_t)(k_lo + lk##q) * a.ldy + J0 + lc##q;                                           \
+    const T *gJ##q = Y + (size_t)(k_lo + lk##q) * a.ldy + J0 + lc##q;                                            \
     V rI##q = V(), rJ##q = V();                                                                                  \
-    if (q < LOADS) { rI##q = *(const V *)gI##q; rJ##q = ldy(gJ##q); }
+    if (q < LOADS) { rI##q = *(const V *)gI##q; rJ##q = *(const V *)gJ##q; }
     XT_PIECE(0)
     XT_PIECE(1)
     XT_PIECE(2)
     XT_PIECE(3)
 #undef XT_PIECE
 #define XT_STORE(q, bf) *(V *)(&sI[bf][lk##q][lc##q]) = rI##q; *(V *)(&sJ[bf][lk##q][lc##q]) = rJ##q;
-#define XT_LOAD(q, kt) rI##q = *(const V *)(gI##q + (kt) * xslab); rJ##q = ldy(gJ##q + (kt) * yslab);
+#define XT_LOAD(q, kt) rI##q = *(const V *)(gI##q + (kt) * xslab); rJ##q = *(const V *)(gJ##q + (kt) * yslab);
     XT_STORE(0, 0)
     XT_STORE(1, 0)
     if (LOADS == 4) {
@@ -148,13 +131,12 @@ __global__ void __launch_bounds__(256, BK * sizeof(T) >= 128 ? 2 : 3) k_xty(XtyA
         }
 }
 
-void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32, hipStream_t stream, bool y_f32)
+void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32, hipStream_t stream)
 {
     (void)e;
     const int grid = batch * (a.tiles_i + a.n_split) * a.tiles_j;
     if (grid <= 0) return;
     if (f32) k_xty<float, 16><<<grid, 256, 0, stream>>>(a);
-    else if (y_f32) k_xty<double, 32, true><<<grid, 256, 0, stream>>>(a);
     else k_xty<double, 32><<<grid, 256, 0, stream>>>(a);
 }
 

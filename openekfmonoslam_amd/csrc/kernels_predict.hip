@@ -240,10 +240,14 @@ void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool sta
 // One workgroup per predicted feature: the 2 x n row pair  H_f P = Hf P[pos:pos+d,:] + Hs P[0:7,:]  (:644, columns
 // 7..12 of Hs are structurally zero), streamed with coalesced reads of 7+d rows of P, and the 2x2 innovation
 // covariance S_f = (H_f P) H_f' + I (:651-653) from the fp64 values of the 13 columns H_f touches.
-template <typename T>
+// TO: storage type of the row pairs (= T, except EKF_PRECISION_F32_EXACT: P in fp32, H P in fp64 -- an H P rounded to fp32
+// independently of P makes S = (H P) H' + R and B = inv(L) (H P) inconsistent with the P they downdate, and that
+// inconsistency, unlike the rounding of P itself, is amplified by the conditioning of S: measured at N = 2000, 1.2e-5
+// component-wise with an fp32 H P against 2.5e-7 for fp32 storage of P alone)
+template <typename T, typename TO>
 __global__ void __launch_bounds__(256)
 k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, const int *feat_covpos,
-          const double *Hs_tab, const double *Hf_tab, T *HP, double *S_tab, RowMap rm, double *HPc, unsigned *times_predicted,
+          const double *Hs_tab, const double *Hf_tab, TO *HP, double *S_tab, RowMap rm, double *HPc, unsigned *times_predicted,
           const int *d_count)
 {
     // the grid is an upper bound when the length of the list is only known on the device (step path: no read-back)
@@ -293,8 +297,8 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
         sHP[0][tid - 64] = a0 + b0;
         sHP[1][tid - 64] = a1 + b1;
     }
-    T *o0 = HP + (size_t)(2 * fi) * ld;
-    T *o1 = o0 + ld;
+    TO *o0 = HP + (size_t)(2 * fi) * ld;
+    TO *o1 = o0 + ld;
     // 16 bytes per lane and row: a wavefront reads 1 KB (fp32) / 1 KB (fp64, two columns) of CONTIGUOUS row per load
     // instead of 256 B, which the HBM-bound pass over P needs (rows are ld elements apart; ld is a multiple of 128, so
     // reading up to the padded row end is in bounds; columns >= n are never stored)
@@ -308,7 +312,8 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
             if (a < d) pf[a] = *(const vec_t *)(Pf + (size_t)a * ld + jb);
 #pragma unroll
         for (int a = 0; a < 7; ++a) pc[a] = *(const vec_t *)(P + (size_t)a * ld + jb);
-        vec_t r0, r1;
+        typedef TO ovec_t __attribute__((ext_vector_type(VW)));
+        ovec_t r0, r1;
 #pragma unroll
         for (int v = 0; v < VW; ++v) {
             const int j = jb + v;
@@ -329,16 +334,16 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
             }
             a0 += b0;
             a1 += b1;
-            r0[v] = (T)a0;
-            r1[v] = (T)a1;
+            r0[v] = (TO)a0;
+            r1[v] = (TO)a1;
             if (j < 13) { // fp64 copy of the camera columns: the camera part of B = inv(L) (H P) is solved in fp64
                 HPc[(size_t)(2 * fi) * 16 + j] = a0;
                 HPc[(size_t)(2 * fi + 1) * 16 + j] = a1;
             }
         }
         if (jb + VW <= n) {
-            *(vec_t *)(o0 + jb) = r0;
-            *(vec_t *)(o1 + jb) = r1;
+            *(ovec_t *)(o0 + jb) = r0;
+            *(ovec_t *)(o1 + jb) = r1;
         } else {
 #pragma unroll
             for (int v = 0; v < VW; ++v)
@@ -361,12 +366,16 @@ void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_pred
     unsigned *tp = count_predicted ? e->d.feat_times_predicted : nullptr;
     if (n_list <= 0) return;
     const int chunks_f = (e->n + 256 * 4 - 1) / (256 * 4), chunks_d = (e->n + 256 * 2 - 1) / (256 * 2);
-    if (e->f32)
-        k_hp_rows<float><<<dim3(n_list, chunks_f), 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
+    if (e->exact)
+        k_hp_rows<float, double><<<dim3(n_list, chunks_f), 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
+                                                        e->d.feat_covpos, e->d.Hs, e->d.Hf, (double *)e->d.HP,
+                                                        e->d.pred_S, e->rm, e->d.HPc, tp, d_count);
+    else if (e->f32)
+        k_hp_rows<float, float><<<dim3(n_list, chunks_f), 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
                                                         e->d.feat_covpos, e->d.Hs, e->d.Hf, (float *)e->d.HP,
                                                         e->d.pred_S, e->rm, e->d.HPc, tp, d_count);
     else
-        k_hp_rows<double><<<dim3(n_list, chunks_d), 256, 0, e->stream>>>((const double *)e->d.P, e->ldP, e->n, d_list,
+        k_hp_rows<double, double><<<dim3(n_list, chunks_d), 256, 0, e->stream>>>((const double *)e->d.P, e->ldP, e->n, d_list,
                                                          e->d.feat_type, e->d.feat_covpos, e->d.Hs, e->d.Hf,
                                                          (double *)e->d.HP, e->d.pred_S, e->rm, e->d.HPc, tp, d_count);
 }

@@ -160,7 +160,7 @@ void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M,
 {
     const int nb = batch; // hyp_flags rows are zeroed by their workgroups, hyp_count[b] is only read for launched hypotheses
     const double thr = e->cfg.par.ransacThresholdPredictDistance;
-    if (e->f32)
+    if (e->f32 && !e->exact) // (EKF_PRECISION_F32_EXACT keeps H P in fp64)
         k_ransac_hyp<float><<<nb, e->N > 256 ? HYP_THREADS : 256, 0, e->stream>>>(e->d.state, e->cam, thr, e->d.feat_pos, e->d.feat_type,
                                                        e->d.feat_covpos, e->N, (const float *)e->d.HP, e->ldP,
                                                        e->d.pred_uv, e->d.pred_S, e->d.matches, M,

@@ -864,10 +864,10 @@ __global__ void __launch_bounds__(256) k_yvec(const double *W, int ldw, int m, c
     if (lane == 0) y[i] = s;
 }
 
-template <typename T, bool USE_G, typename TG = T> // T: type of B; TG: storage type of P and G
+template <typename T, bool USE_G, typename TG = T> // T: type of B and of the gathered rows G; TG: storage type of P
 __global__ void __launch_bounds__(256)
 k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, int ldpart, double *sq_part, double *cam_part,
-             const double *Bc, const TG *P, RowMap rm, double *dsave, double *csave, int avg, const TG *G, const double *y)
+             const double *Bc, const TG *P, RowMap rm, double *dsave, double *csave, int avg, const T *G, const double *y)
 {
     __shared__ double sc[64][13]; // fp64 camera columns of a chunk of rows of B
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -898,13 +898,12 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
         if (j < n) {
             // the whole chunk's rows are requested before the first is used: a split is one round trip to memory, not
             // one per few rows (the loop was latency-bound: 30 us for 23 MB)
-            T bv[64];
-            TG gv[USE_G ? 64 : 1];
+            T bv[64], gv[USE_G ? 64 : 1];
 #pragma unroll
             for (int u = 0; u < 64; ++u) {
                 const int k = min(u, cnt - 1);
                 bv[u] = B[(size_t)(k0 + k) * ld + j];
-                if (USE_G) gv[u] = j >= 13 ? G[(size_t)(k0 + k) * ld + j] : (TG)0;
+                if (USE_G) gv[u] = j >= 13 ? G[(size_t)(k0 + k) * ld + j] : (T)0;
             }
 #pragma unroll
             for (int u = 0; u < 64; ++u) {
@@ -1146,7 +1145,7 @@ k_fix_normalize(T *P, int ld, int n, RowMap rm, const double *dsave, const doubl
 // P-update launcher lives in kernels_pupdate.hip
 void launch_p_update(EkfEngine *e, int m_pad, int m);
 
-// T: storage type of P, H P and the gathered rows G; TB: type of B = inv(L) G and of the arithmetic that forms it
+// T: storage type of P; TB: type of H P, of its gathered rows G, of B = inv(L) G and of the arithmetic that forms it
 // (TB = T except EKF_PRECISION_F32_EXACT: T = float, TB = double, the downdate by kernels_pexact.hip)
 template <typename T, typename TB>
 static void update_impl(EkfEngine *e, int M, bool update_cov)
@@ -1156,7 +1155,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     const int m = 2 * M, n = e->n, ld = e->ldP, ldS = e->ldS, ldw = e->ldW;
     const int m_pad = round_up(m, NB);
     const int n_pad = round_up(n, LD_ALIGN);
-    T *G = (T *)e->d.G; // gathered rows of H P
+    TB *G = (TB *)e->d.G; // gathered rows of H P
     TB *A = (TB *)e->d.A; // B = inv(L) G
     // B = inv(L) G: up to B_SWEEP_MAX rows, row block k is formed inside the launch of panel k (forward substitution
     // beside the look-ahead factorisation: no explicit inverse, no GEMM launch); above it the per-launch row block becomes
@@ -1166,8 +1165,8 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     double *V = e->d.Dinv, *W = b_in_sweep ? nullptr : e->d.W; // W = inv(L)' (and L row-major in LL): the GEMM path's
     float *Wf = sizeof(TB) == 4 && !b_in_sweep ? e->d.Wf : nullptr;
     {
-        dim3 grid((n_pad / (int)(16 / sizeof(T)) + 255) / 256, m_pad);
-        k_gather<T><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const T *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
+        dim3 grid((n_pad / (int)(16 / sizeof(TB)) + 255) / 256, m_pad);
+        k_gather<TB><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const TB *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
                                          e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc);
     }
@@ -1176,7 +1175,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     if (e->hook_rc) return;
     {
         dim3 grid((M + 15) / 16, (M + 15) / 16);
-        k_assemble_S<T><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
+        k_assemble_S<TB><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts);
     }
     const int n_bblocks = b_in_sweep ? n_pad / NB : 0; // row block k of B = inv(L) G rides in the launch of panel k
@@ -1199,7 +1198,9 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     const long long PAIR_FROM = n_bblocks > e->n_cus ? 0 : 195000;
     constexpr int PAIR_ROWS = 3072; // rows of the trailing matrix from which a sweep without the B role starts in pairs
     bool have_pair = false;
+    int n_sweep_launches = 0;
     for (int k0 = 0; k0 < m;) {
+        ++n_sweep_launches;
         // (without the rows of B -- inverse + GEMM path -- a big sweep is bound by streaming the fp64 trailing matrix once per
         // launch: 2 x 8 m^2 bytes; pairs stream it once per two panels: N = 5000, m = 3000-4500: 16.6 -> 15.4 us per panel)
         const bool want_pairs = e->sweep_mode == EKF_SWEEP_PAIRS ||
@@ -1231,14 +1232,14 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         }
 #endif
         if (pair_launch) {
-            k_chol_pair<TB, T><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(TB) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, kbB, k2,
-                                                             e->d.nu, n_stiles, V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
+            k_chol_pair<TB, TB><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(TB) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, kbB, k2,
+                                                             e->d.nu, n_stiles, V, W, Wf, ldw, e->d.counts, sizeof(TB) == 4 ? e->d.Gc : nullptr,
                                                              e->d.zvec, e->d.Bc, G, A, ld, n_bw, n_rhs_blocks, n_wgs > e->n_cus ? 1 : 0, spacer, tr, b_wide ? 1 : 0);
             k0 += have_pair ? 2 * NB : NB;
             have_pair = true;
         } else {
-            k_chol_step<TB, T><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(TB) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, e->d.nu, n_stiles,
-                                                             V, W, Wf, ldw, e->d.counts, sizeof(T) == 4 ? e->d.Gc : nullptr,
+            k_chol_step<TB, TB><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(TB) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, e->d.nu, n_stiles,
+                                                             V, W, Wf, ldw, e->d.counts, sizeof(TB) == 4 ? e->d.Gc : nullptr,
                                                              e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks,
                                                              n_wgs > e->n_cus ? 1 : 0, spacer, tr, tr_abl);
             k0 += NB;
@@ -1248,6 +1249,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         (void)hipEventRecord(sw1, s);
         e->sw_events.emplace_back(sw0, sw1);
         e->sw_m.push_back(b_in_sweep ? m : -m); // negative: the rows of B were not formed in these launches
+        e->sw_launch.push_back(n_sweep_launches);
     }
     // inv(L): the 128 x 128 diagonal chunks in one launch, then by doubling 128 -> 256 -> ... until one block covers all rows
     const bool need_inverse = !b_in_sweep;
@@ -1274,15 +1276,15 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         g.row0_first = 0; g.row0_stride = 0; g.m_lim = m_pad;
         g.tri = 2; g.tiles_i = (m_pad + TM - 1) / TM; g.tiles_j = (n_pad + TM - 1) / TM; g.alpha = 1.0;
         g.n_split = g.tiles_i / 2; // k-depth of row tile i is ~(i+1) TM: halve the units of the longer half
-        launch_xty(e, g, 1, sizeof(TB) == 4, s, EXACT);
+        launch_xty(e, g, 1, sizeof(TB) == 4, s);
     }
     {
         dim3 grid((n + 255) / 256, DX_SPLIT);
         const bool fix = update_cov && sizeof(T) == 4 && !EXACT; // (the exact downdate needs no fp64 repair of the diagonal / camera rows)
         const int avg = e->p_exact_sym ? 0 : 1; // an AVG downdate only exists on an unsharded engine: every row is local
         const double *Bc = nullptr;
-        const T *Gy = nullptr;
-        if (sizeof(T) == 4) {
+        const TB *Gy = nullptr;
+        if (sizeof(TB) == 4) { // (with B in fp64 its camera columns and B'z need no fp64 side channel)
             Bc = e->d.Bc; // inv(L) Gc, produced by the right-hand-side blocks of k_chol_step
             // feature columns of dx: with the explicit inverse at hand, (H P)' y with y = inv(L)' z in fp64 (k_yvec);
             // on the sweep path B' z (fp32 B): the same to 1e-6 of the largest component of a block, see DESIGN.md section 6
@@ -1301,7 +1303,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     }
     if (!update_cov) return;
     const bool fix_diag = sizeof(T) == 4 && !EXACT;
-    if (EXACT) launch_p_update_exact(e, m, true);
+    if (EXACT) launch_p_update_exact(e, m, false);
     else launch_p_update(e, m_pad, m);
     if (fix_diag) {
         k_fix_normalize<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save,

