@@ -37,7 +37,7 @@ enum {
     EKF_PRECISION_F32_EXACT = 2 /* fp32 STORAGE of the covariance and of H*P, reference-class arithmetic: B = inv(L) H P in
                                  * fp64 and the rank-m downdate P - B'B accumulated EXACTLY (int8 digit planes of B on the
                                  * int8 MFMA, int32 sums), rounded to fp32 once per entry and update.  The reference computes
-                                 * in double throughout (Core/Base.h:67; Update.cpp:105-108, 214-218).  One GPU only. */
+                                 * in double throughout (Core/Base.h:67; Update.cpp:105-108, 214-218). */
 };
 
 typedef struct EkfEngineConfig {
@@ -262,6 +262,12 @@ int ekf_timing_sweep(EkfEngine *e, double *kernel_ms, int64_t *panels, int64_t *
 /* ... and the number of kernel launches behind those panels (a launch of the two-panels-per-launch scheme covers two), plus,
  * EKF_PRECISION_F32_EXACT only, the HIP-event time of the column-scale + digit-plane kernels that precede each exact downdate. */
 int ekf_timing_sweep_launches(EkfEngine *e, int64_t *launches, double *slice_ms);
+/* Measurement aid, EKF_PRECISION_F64 engines only: replaces every entry of the device-resident covariance by its nearest fp32
+ * value, in place (asynchronous, on the engine's stream).  Called between the stage functions at the points where an
+ * fp32-storage configuration rounds P (after ekf_set_state, ekf_predict and each ekf_update) it yields the filter "fp32 storage,
+ * fp64 arithmetic": the accuracy floor of EKF_PRECISION_F32 / _F32_EXACT on a sequence (scripts/storage_floor_gpu.py).  The
+ * reference keeps everything in double (Core/Base.h:67). */
+int ekf_round_covariance_to_f32(EkfEngine *e);
 
 /* -- row-sharded filter (multi-GPU) ----------------------------------------------------------
  * One engine per GPU / rank.  Rank g stores the 13 camera rows of P (replicated, updated identically everywhere)

@@ -83,6 +83,9 @@ static hipError_t dalloc(T **p, size_t count, bool zero = true)
     return st;
 }
 
+// element size of H P and of its gathered rows (fp64 beside the exact downdate, else the covariance's)
+static inline size_t hp_elem_bytes(const EkfEngine *e) { return e->exact ? 8 : (e->f32 ? 4 : 8); }
+
 extern "C" {
 
 int ekf_abi_version(void) { return 1; }
@@ -168,10 +171,6 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     }
     e->exact = cfg->precision == EKF_PRECISION_F32_EXACT;
     e->f32 = cfg->precision == EKF_PRECISION_F32 || e->exact;
-    if (e->exact && world > 1) { // the exact downdate has no row-sharded form yet
-        delete e;
-        return EKF_ERR_INVALID_ARG;
-    }
     if ((cfg->flags & 0xff) == 1) { // EKF_DESCRIPTOR_F32_L2(cols)
         const int cols = (cfg->flags >> 8) & 0xffff;
         if (cols < 1 || cols > 1024) { delete e; return EKF_ERR_INVALID_ARG; }
@@ -913,8 +912,8 @@ static int complete_hp_table(EkfEngine *e)
     int rc;
     std::vector<int32_t> rb(e->shard_world + 1);
     for (int r = 0; r <= e->shard_world; ++r) rb[r] = 2 * e->shard_feat_begin[r];
-    if ((rc = exchange_rows(e, EKF_XCHG_HP, e->d.HP, (size_t)e->ldP * (e->f32 ? 4 : 8), rb, "the H.P row blocks"))) return rc;
-    if (e->f32 && (rc = exchange_rows(e, EKF_XCHG_HPC, e->d.HPc, 16 * sizeof(double), rb, "the fp64 camera columns of H.P"))) return rc;
+    if ((rc = exchange_rows(e, EKF_XCHG_HP, e->d.HP, (size_t)e->ldP * hp_elem_bytes(e), rb, "the H.P row blocks"))) return rc;
+    if (e->f32 && !e->exact && (rc = exchange_rows(e, EKF_XCHG_HPC, e->d.HPc, 16 * sizeof(double), rb, "the fp64 camera columns of H.P"))) return rc;
     e->hp_complete = true;
     return EKF_OK;
 }
@@ -1080,8 +1079,8 @@ static int ransac_dev(EkfEngine *e, int M, bool lean = false)
             }
             std::vector<int32_t> rb(e->shard_world + 1);
             for (int r = 0; r <= e->shard_world; ++r) rb[r] = 2 * std::min(std::max(e->shard_feat_begin[r], f_lo), f_hi + 1);
-            if ((rc = exchange_rows(e, EKF_XCHG_HP, e->d.HP, (size_t)e->ldP * (e->f32 ? 4 : 8), rb, "the H.P rows of a RANSAC batch"))) return rc;
-            if (e->f32 && (rc = exchange_rows(e, EKF_XCHG_HPC, e->d.HPc, 16 * sizeof(double), rb, "their fp64 camera columns"))) return rc;
+            if ((rc = exchange_rows(e, EKF_XCHG_HP, e->d.HP, (size_t)e->ldP * hp_elem_bytes(e), rb, "the H.P rows of a RANSAC batch"))) return rc;
+            if (e->f32 && !e->exact && (rc = exchange_rows(e, EKF_XCHG_HPC, e->d.HPc, 16 * sizeof(double), rb, "their fp64 camera columns"))) return rc;
         }
         launch_ransac_batch(e, M, h0, batch);
         int rc = read_counts(e);
@@ -1129,8 +1128,8 @@ static int lean_gather_exchange(EkfEngine *e, int M)
 {
     (void)M;
     int rc;
-    if ((rc = exchange_rows(e, EKF_XCHG_HP, e->d.G, (size_t)e->ldP * (e->f32 ? 4 : 8), e->shard_rb, "the gathered H.P rows"))) return rc;
-    if (e->f32 && (rc = exchange_rows(e, EKF_XCHG_HPC, e->d.Gc, 16 * sizeof(double), e->shard_rb, "their fp64 camera columns"))) return rc;
+    if ((rc = exchange_rows(e, EKF_XCHG_HP, e->d.G, (size_t)e->ldP * hp_elem_bytes(e), e->shard_rb, "the gathered H.P rows"))) return rc;
+    if (e->f32 && !e->exact && (rc = exchange_rows(e, EKF_XCHG_HPC, e->d.Gc, 16 * sizeof(double), e->shard_rb, "their fp64 camera columns"))) return rc;
     return EKF_OK;
 }
 
@@ -1854,6 +1853,15 @@ int ekf_timing_sweep(EkfEngine *e, double *kernel_ms, int64_t *panels, int64_t *
     if (updates) *updates = e->sweep_updates;
     if (flops_fp64) *flops_fp64 = e->sweep_flops_f64;
     if (flops_b) *flops_b = e->sweep_flops_b;
+    return EKF_OK;
+}
+
+int ekf_round_covariance_to_f32(EkfEngine *e)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    if (e->f32) return EKF_ERR_INVALID_ARG; // an fp64 engine only: the fp32 configurations store fp32 already
+    HIPCHK(hipSetDevice(e->device));
+    launch_round_P_f32(e);
     return EKF_OK;
 }
 

@@ -292,6 +292,7 @@ void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M 
 void launch_ransac_init(EkfEngine *e, int M);
 void launch_update(EkfEngine *e, int M, bool update_cov);
 void launch_p_update_exact(EkfEngine *e, int m, bool use_bc); // kernels_pexact.hip
+void launch_round_P_f32(EkfEngine *e);                        // kernels_map.hip
 void launch_rescue(EkfEngine *e, int M);
 void launch_state_only_predict(EkfEngine *e, EkfPrediction *d_out); // predictMeasurementState on current state
 void launch_add_features(EkfEngine *e, const double *d_uv, int count, double *d_Jpo, double *d_Jhr);

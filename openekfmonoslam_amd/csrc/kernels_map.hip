@@ -295,4 +295,17 @@ void launch_convert(EkfEngine *e, int fi, int pos, double *d_J, double *d_T3)
     }
 }
 
+// Measurement aid (ekf_round_covariance_to_f32): every stored entry of an fp64 covariance replaced by its nearest fp32 value.
+__global__ void __launch_bounds__(256) k_round_P_f32(double *P, int ld, int n, int rows)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (i < rows && j < n) P[(size_t)i * ld + j] = (double)(float)P[(size_t)i * ld + j];
+}
+
+void launch_round_P_f32(EkfEngine *e)
+{
+    const int rows = e->shard_world > 1 ? local_row(e->rm, e->rm.r1 - 1) + 1 : e->n;
+    k_round_P_f32<<<dim3((e->n + 255) / 256, rows), 256, 0, e->stream>>>((double *)e->d.P, e->ldP, e->n, rows);
+}
+
 } // namespace ekf

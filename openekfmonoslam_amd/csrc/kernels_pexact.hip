@@ -24,6 +24,8 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <string>
 
 namespace ekf {
 
@@ -312,41 +314,47 @@ __device__ __forceinline__ void px_step_ring(unsigned ldsA, unsigned ldsB, v16i 
 //   * the epilogue's 64 KB read-modify-write of P hides behind MFMA work instead of ending every launch round in a burst:
 //     the old values are requested when the unit starts (32 registers), the new ones leave as fire-and-forget stores.
 constexpr int PX_RING = 3;
-constexpr int PX_MAXU = 32; // units one workgroup can be dealt (launch_p_update_exact checks)
 
+// RECT (row-sharded storage; see k_p_update): the rank owns row tiles, not a triangle -- tile row 0 is the replicated
+// camera block (13 live rows), tile row t >= 1 holds the owned global rows rm.r0 + (t - 1) TM ..., stored from local row
+// rm.base on; every (row tile, column tile) pair is computed and written in place, nothing is mirrored.  The integer sums of
+// (i, j) and (j, i) are the same number, so P[i][j] here is bit for bit P[j][i] on the rank that owns row j.
+template <bool RECT>
 __global__ void __launch_bounds__(512, 2)
 k_p_update_i8p(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq, int ldq, size_t plane_stride, int m_k,
-               const int *__restrict__ bexp, int per_xcd, const int4 *__restrict__ units, int slots)
+               const int *__restrict__ bexp, int per_xcd, const int4 *__restrict__ units, int slots, RowMap rm)
 {
     constexpr int TM = 128, MB = 32, SLAB = PX_S * 8192;
     constexpr int ST = MB + 4; // row stride of the epilogue's staging image: 16-byte aligned rows
     __shared__ __attribute__((aligned(16))) unsigned char ring[PX_RING * SLAB];
     __shared__ __attribute__((aligned(16))) float sTall[8 * MB * ST];
     __shared__ int sExp[2][2 * TM];
-    __shared__ int4 sUnit[PX_MAXU];
     __shared__ int sMeta[2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv >> 2, wc = wv & 3;
     const int kg = lane >> 5, idx = lane & 31;
     const int nk = m_k / 32;
-    {   // this workgroup's units: slot, slot + slots, ... of its XCD's list (see k_p_update), kept in LDS
-        const int4 *ul = units + (size_t)(blockIdx.x & 7) * per_xcd;
-        const int slot = blockIdx.x >> 3;
-        if (tid < PX_MAXU) {
-            const int u = slot + tid * slots;
-            sUnit[tid] = u < per_xcd ? ul[u] : make_int4(-1, -1, -1, 0);
-        }
-        if (tid == 0) {
-            sMeta[0] = ldp;
-            sMeta[1] = 0;
-        }
-        __syncthreads();
-    }
+    // this workgroup's units: slot, slot + slots, ... of its XCD's list (see k_p_update).  A descriptor is fetched by a SCALAR
+    // load (uniform address, lgkm counter): a vector load would sit on the same counter as the LDS-DMA ring and drain it.
+    const int4 *ul = units + (size_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    auto unit_at = [&](int k) -> int4 {
+        v4i u;
+        const int4 *p = ul + (size_t)k * slots;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(u) : "s"(p) : "memory");
+        return make_int4(u[0], u[1], u[2], u[3]);
+    };
     int n_units = 0;
-    while (n_units < PX_MAXU && sUnit[n_units].x >= 0) ++n_units;
-    n_units = __builtin_amdgcn_readfirstlane(n_units);
+    for (int u = blockIdx.x >> 3; u < per_xcd; u += slots) {
+        if (unit_at(n_units).x < 0) break;
+        ++n_units;
+    }
     if (n_units == 0) return;
+    if (tid == 0) {
+        sMeta[0] = ldp;
+        sMeta[1] = 0;
+    }
+    __syncthreads();
     const int total = n_units * nk; // steps of the whole pipeline
 
     // this wavefront's piece of every plane and step: wavefronts 0..3 the I side (k-group, column half), 4..7 the J side
@@ -358,9 +366,11 @@ k_p_update_i8p(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__
     const int poff = wv * 1024;
     int iu = 0, it = 0, ig = 0;      // issue cursor: unit, step, global step
     const int8_t *gsrc;
+    // first global row (= column of B) of row tile t
+    auto row0 = [&](int t) { return RECT ? (t == 0 ? 0 : rm.r0 + (t - 1) * TM) : t * TM; };
     {
-        const int4 u0 = sUnit[0];
-        gsrc = Bq + ((size_t)pkg * ldq + (pside ? u0.y : u0.x) * TM + 64 * phalf + lane) * 16;
+        const int4 u0 = unit_at(0);
+        gsrc = Bq + ((size_t)pkg * ldq + (pside ? u0.y * TM : row0(u0.x)) + 64 * phalf + lane) * 16;
     }
 #define PXP_ISSUE()                                                                                                           \
     if (ig < total) {                                                                                                         \
@@ -373,8 +383,8 @@ k_p_update_i8p(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__
             it = 0;                                                                                                           \
             ++iu;                                                                                                             \
             if (iu < n_units) {                                                                                               \
-                const int4 un = sUnit[iu];                                                                                    \
-                gsrc = Bq + ((size_t)pkg * ldq + (pside ? un.y : un.x) * TM + 64 * phalf + lane) * 16;                        \
+                const int4 un = unit_at(iu);                                                                                    \
+                gsrc = Bq + ((size_t)pkg * ldq + (pside ? un.y * TM : row0(un.x)) + 64 * phalf + lane) * 16;                  \
             }                                                                                                                 \
         }                                                                                                                     \
     }
@@ -385,12 +395,14 @@ k_p_update_i8p(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__
     float *sT = sTall + wv * MB * ST;
     const bool late = wv >= 4; // see the k-loop
     for (int ui = 0; ui < n_units; ++ui) {
-        const int4 unit = sUnit[ui];
+        const int4 unit = unit_at(ui);
         const int ti = __builtin_amdgcn_readfirstlane(unit.x), tj = __builtin_amdgcn_readfirstlane(unit.y);
         const int uz = __builtin_amdgcn_readfirstlane(unit.z);
         const bool full = uz < 0;
-        const bool diag = ti == tj;
-        const int I0 = ti * TM, J0 = tj * TM;
+        const bool diag = RECT || ti == tj;
+        const int I0 = row0(ti), J0 = tj * TM;
+        const int p_off = RECT ? (ti == 0 ? 0 : rm.base - rm.r0) : 0; // local minus global row
+        const int ilim = RECT ? (ti == 0 ? 13 : rm.r1) : n;
         const int rbase = full ? wr * 2 * MB : uz * 2 * MB + wr * MB; // first tile row of the wavefront (64 or 32 rows)
         const int offA = (kg * TM + rbase + idx) * 16, offB = (kg * TM + wc * MB + idx) * 16;
         if (tid < 2 * TM) { // the tile's row and column scales, for the epilogue
@@ -437,7 +449,7 @@ k_p_update_i8p(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__
         float *sTe = sT + __builtin_amdgcn_readfirstlane(sMeta[1]); // + 0
         const int *se = sExp[ui & 1];
         const int ej = se[TM + wc * MB + idx];
-        float *pe = Pe + (size_t)(I0 + rbase) * lde + J0 + wc * MB;
+        float *pe = Pe + (size_t)(I0 + p_off + rbase) * lde + J0 + wc * MB;
         const int le = 4 * kg * lde + idx;
         // P is addressed as (wavefront-uniform origin) + (lane offset) + (uniform row step).  Rows / columns up to the tile
         // grid's edge exist (the engine allocates P to a multiple of 128 rows), so the loads need no guards; the stores are
@@ -450,7 +462,7 @@ k_p_update_i8p(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) pv1[r] = (pe + (MB + (r & 3) + 8 * (r >> 2)) * lde)[le];
         }
-        float *pm = Pe + (size_t)(J0 + wc * MB) * lde + I0 + rbase; // mirror image of block (0, .)
+        float *pm = Pe + (size_t)(J0 + wc * MB) * lde + I0 + rbase; // mirror image of block (0, .) (never used when RECT)
         // Both images of a block leave through the wavefront's staging area as 16-byte stores (a store instruction costs the
         // same issue time whatever its width: 64 four-byte stores per lane and unit were most of a unit's fixed cost):
         //   direct image  [row][column], rows of ST floats: lane (q8, q4) reads columns 4 q4 .. + 3 of rows 8 it + q8;
@@ -482,7 +494,7 @@ k_p_update_i8p(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__
                 const float4 v = sTq[i4 * 8 * ST / 4];
                 const int gi = bi + 8 * i4 + q8, gj0 = J0 + wc * MB + 4 * q4;
                 float *dst = (pe + (x * MB + 8 * i4) * lde) + lq;
-                if (gi < n) {
+                if (gi < ilim) {
                     if (gj0 + 3 < n) *reinterpret_cast<float4 *>(dst) = v;
                     else { // the ragged last column tile (n is not a multiple of 4): the padding stays untouched
                         if (gj0 < n) dst[0] = v.x;
@@ -538,20 +550,32 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc)
     k_col_exp<<<dim3((n_pad + 255) / 256, PX_KSPLIT), 256, 0, s>>>(B, ld, m, n_pad, Bc, e->d.Bexp);
     k_slice_B<<<dim3(n_pad / 64, (m_k + 63) / 64), 256, 0, s>>>(B, ld, m, m_k, Bc, e->d.Bexp, e->d.Bq, ld, plane_stride);
     const int nt = (n + 127) / 128;
+    const bool rect = e->shard_world > 1;
+    const int owned = e->rm.r1 - e->rm.r0;
+    const int nrt = 1 + (owned + 127) / 128; // camera tile + owned row tiles
     const int slots_saved = e->pu_slots;
     e->pu_slots = e->n_cus; // one 512-thread workgroup per CU is resident (160 accumulator registers per lane)
-    build_units(e, nt, 0, false, 0);
+    build_units(e, nt, nrt, rect, 0);
     e->pu_slots = slots_saved;
     const int grid = e->pu_per_xcd * 8;
     const int4 *tm = (const int4 *)e->d.pu_tilemap;
     if (e->timing) (void)hipEventRecord(e0, s);
-    if (!e->p_exact_sym) k_p_update_i8<true><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
+    if (!e->p_exact_sym && !rect) k_p_update_i8<true><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
     else if (g_px_variant == 1) k_p_update_i8<false><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
-    else k_p_update_i8p<<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8);
+    else if (rect) k_p_update_i8p<true><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
+    else k_p_update_i8p<false><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
+    {   // a launch that the runtime refuses (resources) would leave P silently un-downdated
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            e->err = std::string("exact downdate launch: ") + hipGetErrorString(le);
+            std::fprintf(stderr, "ekf: %s\n", e->err.c_str());
+            e->hook_rc = EKF_ERR_HIP;
+        }
+    }
     if (e->timing) {
         (void)hipEventRecord(e1, s);
         e->pu_events.emplace_back(e0, e1);
-        e->pu_work.push_back((double)n * (double)n * (double)m);
+        e->pu_work.push_back(rect ? (double)(owned + 13) * (double)n * (double)m * 2.0 : (double)n * (double)n * (double)m);
         e->pu_m.push_back(m);
         e->px_events.emplace_back(e2, e0); // the two slicing kernels
     }

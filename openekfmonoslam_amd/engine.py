@@ -103,6 +103,7 @@ ABI = {
     "ekf_timing_sweep": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                               C.POINTER(C.c_double)]),
     "ekf_timing_sweep_launches": (_i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "ekf_round_covariance_to_f32": (_i, [_vp]),
     "ekf_shard_rows": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "ekf_engine_create_sharded": (_i, [C.POINTER(EkfEngineConfig), _i, _i, C.POINTER(_vp)]),
     "ekf_set_exchange": (_i, [_vp, _vp, _vp]),
@@ -513,6 +514,10 @@ class EkfEngine:
         self._chk(self.L.ekf_timing_sweep_launches(self.h, C.byref(launches), C.byref(slice_ms)))
         return {"ms": ms.value, "panels": panels.value, "updates": updates.value, "flops_fp64": fl64.value, "flops_b": flb.value,
                 "launches": launches.value, "slice_ms": slice_ms.value}
+
+    def round_covariance_to_f32(self):
+        """fp64 engines: every entry of P to its nearest fp32 value, in place (storage-floor measurements)."""
+        self._chk(self.L.ekf_round_covariance_to_f32(self.h))
 
     def synchronize(self):
         self._chk(self.L.ekf_synchronize(self.h))

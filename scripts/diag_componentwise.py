@@ -23,6 +23,8 @@ scenes = [("scene25", dict(horizon=25)), ("scene70", dict(horizon=70)), ("scene1
           ("seedB", dict(seed=20260102))]
 if N != 1000:
     scenes = [("default", dict(width=1280, height=720) if N == 2000 else dict())]
+if os.environ.get("EKF_DIAG_KW"):  # e.g. "dict(width=1280, height=720)"
+    scenes = [("custom", eval(os.environ["EKF_DIAG_KW"]))]
 for name, kw in scenes:
     seq = SyntheticSequence(N, F, **kw)
     o = ol.Oracle(seq.cam, seq.par, N + 8)

@@ -38,6 +38,8 @@ int main(int argc, char **argv)
         free(dup);
     }
     const int rounds = argc > 3 ? atoi(argv[3]) : 7;
+    const int variant = argc > 4 ? atoi(argv[4]) : 0; // 0 persistent kernel; 1 one workgroup per unit; 2 the AVG instance (first update after an upload)
+    g_px_variant = variant == 1 ? 1 : 0;
     const int n = 13 + 6 * N, ld = round_up(n, LD_ALIGN);
     int m_max = 0;
     for (int m : ms) m_max = std::max(m_max, m);
@@ -94,7 +96,7 @@ int main(int argc, char **argv)
 
         // ---- correctness of the exact path
         hipMemcpy(dP, dP0, hP.size() * 4, hipMemcpyDeviceToDevice);
-        e.p_exact_sym = true;
+        e.p_exact_sym = variant != 2; // (the input is symmetric: the averaging instance must give the same bits)
         e.d.A = dB;
         launch_p_update_exact(&e, m, false);
         hipStreamSynchronize(e.stream);
