@@ -16,7 +16,10 @@ constexpr int NB = 32;          // Cholesky panel width
 constexpr int LD_ALIGN = 128;   // leading dimensions are multiples of this many elements
 constexpr int B_SWEEP_MAX = 2048; // rows of S up to which B = inv(L) G is formed inside the sweep's launches
 constexpr int DX_SPLIT = 16;    // k-splits of the dx = B' z reduction
-constexpr int PX_S = 5;         // EKF_PRECISION_F32_EXACT: balanced base-256 digits per element of B (kernels_pexact.hip)
+#ifndef PX_S_VALUE
+#define PX_S_VALUE 5
+#endif
+constexpr int PX_S = PX_S_VALUE; // EKF_PRECISION_F32_EXACT: balanced base-256 digits per element of B (kernels_pexact.hip)
 
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 

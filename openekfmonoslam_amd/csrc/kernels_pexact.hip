@@ -249,6 +249,7 @@ k_p_update_i8(float *P, int ldp, int n, const int8_t *Bq, int ldq, size_t plane_
     }
 }
 
+#if PX_S_VALUE == 5 // (the persistent kernel is written out for five digit planes; other counts run k_p_update_i8 -- accuracy experiments)
 // The step of the persistent kernel: the same products as px_step, operands fetched by hand-issued ds_read_b128.  The
 // compiler does not see these reads, so (a) it cannot put "s_waitcnt vmcnt(0)" in front of them -- it does that to any LDS read
 // that MAY alias an LDS-DMA in flight, and with a ring addressed by (step mod 3) every read may: the two slabs that are
@@ -524,6 +525,8 @@ k_p_update_i8p(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__
 #undef PXP_ISSUE
 }
 
+#endif
+
 // ------------------------------------------------------------------------------------------------ launcher
 void build_units(EkfEngine *e, int nt, int nrt, bool rect, int order); // kernels_pupdate.hip
 
@@ -561,9 +564,11 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc)
     const int4 *tm = (const int4 *)e->d.pu_tilemap;
     if (e->timing) (void)hipEventRecord(e0, s);
     if (!e->p_exact_sym && !rect) k_p_update_i8<true><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
-    else if (g_px_variant == 1) k_p_update_i8<false><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
+    else if (g_px_variant == 1 || PX_S != 5) k_p_update_i8<false><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
+#if PX_S_VALUE == 5
     else if (rect) k_p_update_i8p<true><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
     else k_p_update_i8p<false><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
+#endif
     {   // a launch that the runtime refuses (resources) would leave P silently un-downdated
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) {

@@ -157,8 +157,6 @@ for S_ in (3, 4, 5):
 # a-priori column scale: sum_k B_kj^2 = P_jj - P_jj(new) <= P_jj, so |B_kj| <= sqrt(P_jj) is known BEFORE B exists
 Pdiag = np.diag(o.P()).copy()
 apri = np.sqrt(Pdiag) * (1.0 + 1e-6)
-print(f"a-priori bound sqrt(P_jj) over the true column max of |B|: median {np.median(apri[13:] / np.maximum(np.abs(B).max(axis=0)[13:], 1e-300)):.1f}, "
-      f"90th percentile {np.percentile(apri[13:] / np.maximum(np.abs(B).max(axis=0)[13:], 1e-300), 90):.1f}, max {np.max(apri[13:] / np.maximum(np.abs(B).max(axis=0)[13:], 1e-300)):.1f}")
 for S_ in (5, 6):
     res[f"E_i8x{S_}ap  ({S_} digits, column scale from sqrt(P_jj) instead of the column's max)"] = dots_i8(B, S_, apri)
 rms = np.sqrt((exact ** 2).mean())

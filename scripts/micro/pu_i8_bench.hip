@@ -133,7 +133,7 @@ int main(int argc, char **argv)
         }
         for (auto &sp : samples) {
             const int i = sp.first, j = sp.second;
-            long long lv[PX_S] = {0, 0, 0, 0, 0};
+            long long lv[PX_S] = {};
             double exact = 0.0;
             for (int k = 0; k < m; ++k) {
                 int di[PX_S], dj[PX_S];
