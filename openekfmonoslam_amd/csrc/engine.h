@@ -294,7 +294,7 @@ void launch_slice_bounds(EkfEngine *e, const EkfMatch *list, int h0, int h1);
 void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M = nullptr, int publish_seq = 0);
 void launch_ransac_init(EkfEngine *e, int M);
 void launch_update(EkfEngine *e, int M, bool update_cov);
-void launch_p_update_exact(EkfEngine *e, int m, bool use_bc); // kernels_pexact.hip
+void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready = false); // kernels_pexact.hip
 void launch_round_P_f32(EkfEngine *e);                        // kernels_map.hip
 void launch_rescue(EkfEngine *e, int M);
 void launch_state_only_predict(EkfEngine *e, EkfPrediction *d_out); // predictMeasurementState on current state

@@ -533,7 +533,9 @@ void build_units(EkfEngine *e, int nt, int nrt, bool rect, int order); // kernel
 int g_px_variant = 0; // scripts/micro/pu_i8_bench.hip only: 1 = one workgroup per unit (k_p_update_i8)
 
 // B (fp64, k-major, ld = e->ldP) sits in e->d.A; camera columns from e->d.Bc when use_bc
-void launch_p_update_exact(EkfEngine *e, int m, bool use_bc)
+// exps_ready: e->d.Bexp already holds the column scales of columns 0 .. n - 1 (the engine collects them in the pass that forms
+// dx = B'z); otherwise k_col_exp computes them here (scripts/micro/pu_i8_bench.hip)
+void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready)
 {
     hipStream_t s = e->stream;
     const int n = e->n, ld = e->ldP;
@@ -549,8 +551,10 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc)
         (void)hipEventCreate(&e2);
         (void)hipEventRecord(e2, s);
     }
-    (void)hipMemsetAsync(e->d.Bexp, 0, sizeof(int) * (size_t)ld, s);
-    k_col_exp<<<dim3((n_pad + 255) / 256, PX_KSPLIT), 256, 0, s>>>(B, ld, m, n_pad, Bc, e->d.Bexp);
+    if (!exps_ready) {
+        (void)hipMemsetAsync(e->d.Bexp, 0, sizeof(int) * (size_t)ld, s);
+        k_col_exp<<<dim3((n_pad + 255) / 256, PX_KSPLIT), 256, 0, s>>>(B, ld, m, n_pad, Bc, e->d.Bexp);
+    }
     k_slice_B<<<dim3(n_pad / 64, (m_k + 63) / 64), 256, 0, s>>>(B, ld, m, m_k, Bc, e->d.Bexp, e->d.Bq, ld, plane_stride);
     const int nt = (n + 127) / 128;
     const bool rect = e->shard_world > 1;

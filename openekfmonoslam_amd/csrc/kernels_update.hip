@@ -29,9 +29,16 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
          const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
-         double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc)
+         double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, int *bexp)
 {
     const int row = blockIdx.y;
+    if (bexp && row == 0) { // exact downdate: the column scales of B are collected by k_dx_partial (atomicMax): start from zero
+        constexpr int VWz = 16 / sizeof(T);
+        const int jz = (blockIdx.x * 256 + threadIdx.x) * VWz;
+#pragma unroll
+        for (int v = 0; v < VWz; ++v)
+            if (jz + v < n_pad) bexp[jz + v] = 0;
+    }
     // 16 bytes per thread: the copy is pure HBM traffic (n_pad and ld are multiples of 128 elements)
     constexpr int VW = 16 / sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(VW)));
@@ -867,7 +874,7 @@ __global__ void __launch_bounds__(256) k_yvec(const double *W, int ldw, int m, c
 template <typename T, bool USE_G, typename TG = T> // T: type of B and of the gathered rows G; TG: storage type of P
 __global__ void __launch_bounds__(256)
 k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, int ldpart, double *sq_part, double *cam_part,
-             const double *Bc, const TG *P, RowMap rm, double *dsave, double *csave, int avg, const T *G, const double *y)
+             const double *Bc, const TG *P, RowMap rm, double *dsave, double *csave, int avg, const T *G, const double *y, int *bexp)
 {
     __shared__ double sc[64][13]; // fp64 camera columns of a chunk of rows of B
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -885,6 +892,7 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
     const int per = (m + DX_SPLIT - 1) / DX_SPLIT;
     const int kb = ks * per, ke = min(m, kb + per);
     double s = 0.0, q = 0.0;
+    int hi = 0; // exact downdate: largest biased exponent of this column's entries of B (the column scale of its digit planes)
     double c[13];
 #pragma unroll
     for (int a = 0; a < 13; ++a) c[a] = 0.0;
@@ -913,6 +921,7 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
                     if (USE_G && j >= 13) s += (double)gv[u] * y[k0 + u];
                     else s += b * z[k0 + u];
                     q += b * b; // (B'B)_jj in fp64, same pass over B: see k_fix_normalize
+                    if (sizeof(T) == 8 && bexp) hi = max(hi, __double2hiint(b) & 0x7fffffff);
                     if (cam_part) {
 #pragma unroll
                         for (int a = 0; a < 13; ++a) c[a] += sc[u][a] * b; // (B'B)_aj, camera rows
@@ -922,6 +931,7 @@ k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, in
         }
     }
     if (j >= n) return;
+    if (bexp && (hi >> 20)) atomicMax(&bexp[j], hi >> 20);
     part[(size_t)ks * ldpart + j] = s;
     if (sq_part) sq_part[(size_t)ks * ldpart + j] = q;
     if (cam_part) {
@@ -1168,7 +1178,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         dim3 grid((n_pad / (int)(16 / sizeof(TB)) + 255) / 256, m_pad);
         k_gather<TB><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const TB *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
-                                         e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc);
+                                         e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc, EXACT ? e->d.Bexp : nullptr);
     }
     // sharded step: every rank gathered the rows of the matches it owns; the others arrive here (engine.cpp)
     e->hook_rc = e->after_gather ? e->after_gather(e, M) : 0;
@@ -1293,7 +1303,8 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         }
 #define DX_LAUNCH(USEG) k_dx_partial<TB, USEG, T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, \
                                              fix ? e->d.sq_part : nullptr, fix ? e->d.cam_part : nullptr, Bc, (const T *)e->d.P, \
-                                             e->rm, e->d.diag_save, fix ? e->d.cam_save : nullptr, avg, Gy, e->d.yvec);
+                                             e->rm, e->d.diag_save, fix ? e->d.cam_save : nullptr, avg, Gy, e->d.yvec, \
+                                             (EXACT && update_cov) ? e->d.Bexp : nullptr);
         if (Gy) { DX_LAUNCH(true) } else { DX_LAUNCH(false) }
 #undef DX_LAUNCH
 
@@ -1303,7 +1314,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     }
     if (!update_cov) return;
     const bool fix_diag = sizeof(T) == 4 && !EXACT;
-    if (EXACT) launch_p_update_exact(e, m, false);
+    if (EXACT) launch_p_update_exact(e, m, false, true); // (column scales: zeroed by k_gather, collected by k_dx_partial)
     else launch_p_update(e, m_pad, m);
     if (fix_diag) {
         k_fix_normalize<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save,
