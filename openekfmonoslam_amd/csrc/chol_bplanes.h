@@ -1,0 +1,180 @@
+// chol_bplanes.h -- the rows of B = inv(L) G of the Cholesky sweep on the int8 MFMA (EKF_PRECISION_F32_EXACT, one GPU).
+// Included by kernels_update.hip inside namespace ekf, before k_chol_step.
+//
+// In fp64 the row block of a late panel is bound by the fp64 matrix pipe of ONE CU: a workgroup owns 32 columns and multiplies
+// every finished 32-row block of B by the panel's block of L' -- 32 v_mfma_f64_16x16x4 (64 cycles each) per finished block
+// and wavefront, 6.6 us at the last panel of an m = 1014 update, where the look-ahead workgroup the launch waits for needs
+// 7.5: the sweep ran 11.7 us per panel against 9.1 with the fp32 rows of B.  The exact downdate (kernels_pexact.hip) wants B
+// as int8 digit planes anyway, so the rows of B are formed FROM those planes:
+//
+//   * column scales of B are known before B exists: sum_k B_kj^2 = P_jj - P_jj(new) <= P_jj, so |B_kj| <= sqrt(P_jj)
+//     (k_gather stores the exponent of sqrt(P_jj) per column); a finished row block is cut into PX_S digit planes by the
+//     workgroup that computed it, in the layout the downdate reads ([k / 16][column][k % 16]);
+//   * row scales of L likewise: sum_k L_rk^2 = S_rr, so |L_rk| <= sqrt(S_rr) (k_assemble_S stores the exponent per row); the
+//     workgroups that store a block of L also store its digit planes, one contiguous KB per (plane, block, k-half);
+//   * the left-looking sum  sum_{j<k} L_kj B_j  is then 15 v_mfma_i32_32x32x32_i8 (32 cycles each) per finished block, exact
+//     in int32, the five levels combined in fp64 once per launch: matrix time vanishes and the role streams 5 instead of 8
+//     bytes per element of B;
+//   * the rest of the role is unchanged and fp64: R = G_k - sum, B_k = inv(L_kk) R on the fp64 MFMA, stored in fp64 (for
+//     dx = B'z) and as digit planes (for the later panels and for the downdate).
+//
+// Accuracy of the a-priori scales against the column's true maximum (which is only known when B is complete): 5 digits with
+// the bound sqrt(P_jj) leave the cross-feature entries of B'B with 7e-13 rms absolute error against 1.2e-13 with the true
+// maximum (N = 1000, scripts/diag_accum.py, profiles/r04_accumulation_schemes.txt) -- the fp32 rounding of the result is 3e-11.
+#pragma once
+// (digit_planes.h is included by kernels_update.hip before this file)
+
+typedef int bp_v4i __attribute__((ext_vector_type(4)));
+typedef int bp_v16i __attribute__((ext_vector_type(16)));
+
+struct BPlanes {
+    int8_t *Bq = nullptr;     // digit planes of B: [PX_S][rows / 16][ldq][16]
+    size_t b_stride = 0;      // bytes per plane of B
+    int ldq = 0;              // columns per plane row
+    const int *bexp = nullptr; // biased exponent of the column scale (|B_kj| < 2^(bexp - 1022))
+    int8_t *Lq = nullptr;     // digit planes of L: [PX_S][row block][column block][k half][row][16]
+    size_t l_stride = 0;      // bytes per plane of L
+    int nbk = 0;              // blocks per side of the L planes
+    const int *lexp = nullptr; // biased exponent of the row scale of L
+};
+
+// Digit planes of TWO 32 x 32 blocks of L (rows i0a.. and i0b.., columns k0 .. k0 + kb - 1, in LDS; n_blk = 1: the first
+// only), by all 256 threads: thread (block, k half, 8-byte half, row) cuts eight values and stores eight bytes per plane.
+// (As sixty-four threads cutting sixteen values each with a carry chain this took the tile groups, which the launch waits for
+// on the early panels, from ~6 to 10.4 us.)
+__device__ __forceinline__ void store_l_planes(const BPlanes &bp, int m, int n_blk, int i0a, const double (*sLa)[NB + 1], int i0b,
+                                               const double (*sLb)[NB + 1], int k0, int kb)
+{
+    if (!bp.Lq) return;
+    const int tid = threadIdx.x;
+    const int blk = tid >> 7, r = tid & 31, kg = (tid >> 5) & 1, hf = (tid >> 6) & 1;
+    if (blk >= n_blk) return;
+    const int i0 = blk ? i0b : i0a;
+    const double(*sL)[NB + 1] = blk ? sLb : sLa;
+    const int er = i0 + r < m ? bp.lexp[i0 + r] - 1022 : 0;
+    const int sh = 8 * PX_S - 2 - er;
+    unsigned w[PX_S][2];
+#pragma unroll
+    for (int s = 0; s < PX_S; ++s) w[s][0] = w[s][1] = 0u;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int col = 16 * kg + 8 * hf + c;
+        const double v = (i0 + r < m && col < kb) ? sL[r][col] : 0.0;
+        const unsigned long long dw = px_digit_word(v, sh);
+#pragma unroll
+        for (int s = 0; s < PX_S; ++s) w[s][c >> 2] |= px_digit_byte(dw, s) << (8 * (c & 3));
+    }
+    const size_t off = ((size_t)(i0 / NB) * bp.nbk + k0 / NB) * 1024 + kg * 512 + r * 16 + hf * 8;
+#pragma unroll
+    for (int s = 0; s < PX_S; ++s) *(uint2 *)(bp.Lq + (size_t)s * bp.l_stride + off) = make_uint2(w[s][0], w[s][1]);
+}
+
+// Row block k of B, columns 32 bcol ..: B_k = inv(L_kk) (G_k - sum_{j<k} L_kj B_j), the sum from the digit planes.
+// pool: the launch's LDS blocks (k_chol_step): [0], [1] partial sums, [2] right-hand side, [3] the finished block; sLi = inv(L_kk)
+__device__ __forceinline__ void b_rows_planes(const BPlanes &bp, const double *G, double *Bout, int ld, int m, int k0, int bcol,
+                                              double (*pool)[NB][NB + 1], double (*sLi)[NB + 1], const double (&gv)[4])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int kg = lane >> 5, idx = lane & 31;
+    const int c0 = bcol * NB, kp = k0 / NB;
+    double(*red)[NB][NB + 1] = pool; // [0], [1]
+    double(*sR)[NB + 1] = pool[2];
+    double(*sO)[NB + 1] = pool[3];
+    // this thread's four elements of G_k, requested first: they are cold and only needed at the end
+    const int r4 = tid >> 3, cg = (tid & 7) * 4;
+    double g4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g4[e] = G[(size_t)(k0 + r4) * ld + c0 + cg + e];
+    bp_v16i acc[PX_S];
+#pragma unroll
+    for (int L = 0; L < PX_S; ++L)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[L][r] = 0;
+    // the wavefront's finished blocks j = wv, wv + 4, ...: the operands of the next block are in flight while one is multiplied
+    const int8_t *pl = bp.Lq + ((size_t)kp * bp.nbk * 2 + kg) * 512 + idx * 16;            // + j * 1024 + s * l_stride
+    const int8_t *pb = bp.Bq + ((size_t)kg * bp.ldq + c0 + idx) * 16;                       // + 2 j * ldq * 16 + s * b_stride
+    const size_t bstep = (size_t)2 * bp.ldq * 16;
+    bp_v4i la[3][PX_S], lb[3][PX_S]; // the operands of the next TWO blocks are in flight while one is multiplied (a round trip to
+                                     // L2 under load is over 1 us, a block's fifteen products 0.2 us)
+#define BP_LOAD(S_, J_)                                                                                           \
+    _Pragma("unroll") for (int s = 0; s < PX_S; ++s) {                                                            \
+        la[S_][s] = *(const bp_v4i *)(pl + (size_t)(J_) * 1024 + (size_t)s * bp.l_stride);                        \
+        lb[S_][s] = *(const bp_v4i *)(pb + (size_t)(J_) * bstep + (size_t)s * bp.b_stride);                       \
+    }
+#define BP_MMA(S_)                                                                                                \
+    _Pragma("unroll") for (int s = 0; s < PX_S; ++s)                                                              \
+        _Pragma("unroll") for (int t = 0; t < PX_S - s; ++t)                                                      \
+            acc[s + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(la[S_][s], lb[S_][t], acc[s + t], 0, 0, 0);
+    const int cnt = kp > wv ? (kp - wv + 3) / 4 : 0;
+    if (cnt > 0) { BP_LOAD(0, wv) }
+    if (cnt > 1) { BP_LOAD(1, wv + 4) }
+    for (int i = 0; i < cnt; i += 3) {
+        if (i + 2 < cnt) { BP_LOAD(2, wv + 4 * (i + 2)) }
+        BP_MMA(0)
+        if (i + 1 < cnt) {
+            if (i + 3 < cnt) { BP_LOAD(0, wv + 4 * (i + 3)) }
+            BP_MMA(1)
+        }
+        if (i + 2 < cnt) {
+            if (i + 4 < cnt) { BP_LOAD(1, wv + 4 * (i + 4)) }
+            BP_MMA(2)
+        }
+    }
+#undef BP_LOAD
+#undef BP_MMA
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sLi[(tid + q * 256) / NB][(tid + q * 256) % NB] = gv[q];
+    // levels -> fp64 (value = 2^(e_row + e_col - 12) sum_L acc_L 256^-L, see kernels_pexact.hip), partial sums of the four
+    // wavefronts through LDS: 2, 3 store, 0, 1 add
+    const int ec = bp.bexp[c0 + idx] - 1022;
+    double part[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
+        double tsum = (double)acc[PX_S - 1][r];
+#pragma unroll
+        for (int L = PX_S - 2; L >= 0; --L) tsum = fma(tsum, 1.0 / 256.0, (double)acc[L][r]);
+        const int er = k0 + row < m ? bp.lexp[k0 + row] - 1022 : 0;
+        part[r] = cnt > 0 ? ldexp(tsum, er + ec - 12) : 0.0;
+    }
+    if (wv >= 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wv - 2][(r & 3) + 8 * (r >> 2) + 4 * kg][idx] = part[r];
+    }
+    __syncthreads();
+    if (wv < 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wv][(r & 3) + 8 * (r >> 2) + 4 * kg][idx] += part[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sR[r4][cg + e] = g4[e] - (red[0][r4][cg + e] + red[1][r4][cg + e]);
+    __syncthreads();
+    {   // B_k = Linv_k R on the fp64 MFMA, one 16 x 16 quadrant per wavefront
+        const int bi = wv >> 1, bj = wv & 1, lr = lane & 15, lk = lane >> 4;
+        const acc4_t o = quad_prod<false>(acc4_t{0, 0, 0, 0}, sLi, sR, bi, bj, lr, lk);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            Bout[(size_t)(k0 + 16 * bi + lk + 4 * q) * ld + c0 + 16 * bj + lr] = o[q];
+            sO[16 * bi + lk + 4 * q][16 * bj + lr] = o[q];
+        }
+    }
+    __syncthreads();
+    {   // the block's digit planes: thread (k half, 4-row quarter, column) cuts four rows of its column: four bytes per plane
+        const int col = tid & 31, qr = (tid >> 5) & 3, kh = tid >> 7;
+        const int sh = 8 * PX_S - 2 - (bp.bexp[c0 + col] - 1022);
+        unsigned w[PX_S];
+#pragma unroll
+        for (int s = 0; s < PX_S; ++s) w[s] = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 16 * kh + 4 * qr + i;
+            const unsigned long long dw = px_digit_word(k0 + row < m ? sO[row][col] : 0.0, sh);
+#pragma unroll
+            for (int s = 0; s < PX_S; ++s) w[s] |= px_digit_byte(dw, s) << (8 * i);
+        }
+        int8_t *dst = bp.Bq + ((size_t)(2 * kp + kh) * bp.ldq + c0 + col) * 16 + 4 * qr;
+#pragma unroll
+        for (int s = 0; s < PX_S; ++s) *(unsigned *)(dst + (size_t)s * bp.b_stride) = w[s];
+    }
+}

@@ -138,6 +138,8 @@ struct DeviceArrays {
     void *pu_tilemap = nullptr; // int2 (ti, tj) per upper-triangle tile, XCD-friendly order
     int8_t *Bq = nullptr;       // EKF_PRECISION_F32_EXACT: PX_S digit planes of B, each [bq_rows / 16][ldP][16] bytes (kernels_pexact.hip)
     int *Bexp = nullptr;        // its column scales (biased exponents), ldP ints
+    int8_t *Lq = nullptr;       // digit planes of L for the rows of B formed from planes (chol_bplanes.h): PX_S x lq_nbk^2 KB
+    int *Lexp = nullptr;        // row scales of L (biased exponents)
 };
 
 // current frame of the NCC matcher: gray pyramid (level 0 = full resolution) + the raw upload staging buffer
@@ -202,6 +204,7 @@ struct EkfEngine {
     std::map<long long, std::pair<void *, int>> pu_tables; // built work lists of the downdate: key -> (device list, units per XCD)
     int pu_per_xcd = 0;
     int bq_rows = 0;          // rows of B a digit plane holds (multiple of 64)
+    int lq_nbk = 0;           // 32-row blocks per side of the digit planes of L
     std::vector<std::pair<hipEvent_t, hipEvent_t>> px_events; // exact downdate: brackets of the column-scale + digit-plane kernels
     int pu_slots = 0;         // resident workgroups of the downdate kernel on this device (0: not asked yet, -1: unknown)
     hipStream_t stream = nullptr;
@@ -294,7 +297,7 @@ void launch_slice_bounds(EkfEngine *e, const EkfMatch *list, int h0, int h1);
 void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M = nullptr, int publish_seq = 0);
 void launch_ransac_init(EkfEngine *e, int M);
 void launch_update(EkfEngine *e, int M, bool update_cov);
-void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready = false); // kernels_pexact.hip
+void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready = false, bool planes_ready = false); // kernels_pexact.hip
 void launch_round_P_f32(EkfEngine *e);                        // kernels_map.hip
 void launch_rescue(EkfEngine *e, int M);
 void launch_state_only_predict(EkfEngine *e, EkfPrediction *d_out); // predictMeasurementState on current state

@@ -22,6 +22,7 @@
 // Work per launch: 15/2 n^2 m int8 MACs on the upper triangle (the ALGORITHMIC count stays n^2 m flop); traffic 2 n^2 w of P
 // + the digit planes (5 bytes per element of B, re-read through L2 once per tile row / column).
 #include "engine.h"
+#include "digit_planes.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -90,13 +91,9 @@ k_slice_B(const double *B, int ld, int m, int m_k, const double *Bc, const int *
         for (int q = 0; q < 4; ++q) w[s][q] = 0u;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        long long X = __double2ll_rn(ldexp(v[i], sh));
+        const unsigned long long dw = px_digit_word(v[i], sh); // balanced digits without a carry chain, see digit_planes.h
 #pragma unroll
-        for (int s = PX_S - 1; s >= 0; --s) {
-            const int d = (int)((X + 128) & 255) - 128; // balanced digit, [-128, 127]
-            X = (X - d) >> 8;
-            w[s][i >> 2] |= (unsigned)(d & 255) << (8 * (i & 3));
-        }
+        for (int s = 0; s < PX_S; ++s) w[s][i >> 2] |= px_digit_byte(dw, s) << (8 * (i & 3));
     }
 #pragma unroll
     for (int s = 0; s < PX_S; ++s) {
@@ -535,7 +532,8 @@ int g_px_variant = 0; // scripts/micro/pu_i8_bench.hip only: 1 = one workgroup p
 // B (fp64, k-major, ld = e->ldP) sits in e->d.A; camera columns from e->d.Bc when use_bc
 // exps_ready: e->d.Bexp already holds the column scales of columns 0 .. n - 1 (the engine collects them in the pass that forms
 // dx = B'z); otherwise k_col_exp computes them here (scripts/micro/pu_i8_bench.hip)
-void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready)
+// planes_ready: the digit planes of rows 0 .. m - 1 are in e->d.Bq already (the sweep formed B from them, chol_bplanes.h)
+void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bool planes_ready)
 {
     hipStream_t s = e->stream;
     const int n = e->n, ld = e->ldP;
@@ -555,7 +553,7 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready)
         (void)hipMemsetAsync(e->d.Bexp, 0, sizeof(int) * (size_t)ld, s);
         k_col_exp<<<dim3((n_pad + 255) / 256, PX_KSPLIT), 256, 0, s>>>(B, ld, m, n_pad, Bc, e->d.Bexp);
     }
-    k_slice_B<<<dim3(n_pad / 64, (m_k + 63) / 64), 256, 0, s>>>(B, ld, m, m_k, Bc, e->d.Bexp, e->d.Bq, ld, plane_stride);
+    if (!planes_ready) k_slice_B<<<dim3(n_pad / 64, (m_k + 63) / 64), 256, 0, s>>>(B, ld, m, m_k, Bc, e->d.Bexp, e->d.Bq, ld, plane_stride);
     const int nt = (n + 127) / 128;
     const bool rect = e->shard_world > 1;
     const int owned = e->rm.r1 - e->rm.r0;

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include "chol32.h"
 #include "mma_tile.h"
+#include "digit_planes.h"
 
 namespace ekf {
 
@@ -29,15 +30,26 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
          const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
-         double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, int *bexp)
+         double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, int *bexp, const float *Pdiag, int ldpd,
+         int n)
 {
     const int row = blockIdx.y;
-    if (bexp && row == 0) { // exact downdate: the column scales of B are collected by k_dx_partial (atomicMax): start from zero
+    if (bexp && row == 0) {
+        // exact downdate, column scales of B.  Pdiag == nullptr: collected by k_dx_partial (atomicMax of the entries' exponents),
+        // start from zero.  Otherwise (rows of B from digit planes, chol_bplanes.h) a-priori: |B_kj| <= sqrt(P_jj)
         constexpr int VWz = 16 / sizeof(T);
         const int jz = (blockIdx.x * 256 + threadIdx.x) * VWz;
 #pragma unroll
-        for (int v = 0; v < VWz; ++v)
-            if (jz + v < n_pad) bexp[jz + v] = 0;
+        for (int v = 0; v < VWz; ++v) {
+            const int j = jz + v;
+            if (j >= n_pad) continue;
+            int be = 0;
+            if (Pdiag) {
+                const float pjj = j < n ? Pdiag[(size_t)j * ldpd + j] : 0.f;
+                be = pjj > 0.f ? ilogb(sqrt((double)pjj) * 1.001) + 1 + 1022 : 1022;
+            }
+            bexp[j] = be;
+        }
     }
     // 16 bytes per thread: the copy is pure HBM traffic (n_pad and ld are multiples of 128 elements)
     constexpr int VW = 16 / sizeof(T);
@@ -122,7 +134,7 @@ __device__ __forceinline__ void store_linv(double *V, double *W, float *Wf, int 
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, const int *mpos, const int *mdim,
-             double pixel_err, double *S, int ldS, double *V, double *W, float *Wf, int ldw, int *counts)
+             double pixel_err, double *S, int ldS, double *V, double *W, float *Wf, int ldw, int *counts, int *lexp)
 {
     const int b = blockIdx.x * 16 + (threadIdx.x & 15);
     const int a = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -151,6 +163,8 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
             }
             S[(size_t)(2 * a + r) * ldS + 2 * b] = s0;
             S[(size_t)(2 * a + r) * ldS + 2 * b + 1] = s1;
+            // row scale of L for its digit planes (chol_bplanes.h): sum_k L_rk^2 = S_rr, so |L_rk| <= sqrt(S_rr)
+            if (lexp && a == b) lexp[2 * a + r] = ilogb(sqrt(r == 0 ? s0 : s1) * 1.001) + 1 + 1022;
         }
     }
     if (blockIdx.x != 0 || blockIdx.y != 0) return;
@@ -170,6 +184,7 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 }
 
 #include "chol_pair.h" // the two-panels-per-launch variant of the sweep below, and the 32^3 product helpers both use
+#include "chol_bplanes.h" // EKF_PRECISION_F32_EXACT: the rows of B from int8 digit planes
 
 // -------------------------------------------------------------------------------------- blocked Cholesky sweep
 // Right-looking sweep over [ S | nu ], panel width NB = 32, ONE launch per panel (k_chol_step).  The only serial
@@ -196,7 +211,7 @@ template <typename T, typename TG> // T: type of B and of its MFMA; TG: storage 
 __global__ void __launch_bounds__(256)
 k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0, int kb, double *nu, int n_stiles, double *V,
             double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc, const TG *G, T *Bout, int ld,
-            int n_bblocks, int n_rhs, int tiles_first, int spacer, unsigned long long *trace, int abl)
+            int n_bblocks, int n_rhs, int tiles_first, int spacer, unsigned long long *trace, int abl, BPlanes bp)
 {
 #ifdef EKF_SWEEP_TRACE // debug builds only (scripts/sweep_trace.py): per-role time stamps and role ablations
     const unsigned long long t_in = trace ? wall_clock64() : 0ull;
@@ -265,6 +280,13 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         gv[q] = V[(size_t)(k0 + i / NB) * ldw + k0 + i % NB];
     }
     // (gv lands in sLi inside each role, after the role's own loads have been requested: one round trip, not two)
+    if constexpr (sizeof(T) == 8 && sizeof(TG) == 8) {
+        if (bcol >= 0 && bp.Bq) { // EKF_PRECISION_F32_EXACT: the same role from int8 digit planes (chol_bplanes.h)
+            b_rows_planes(bp, (const double *)G, (double *)Bout, ld, m, k0, bcol, pool, sLi, gv);
+            SWEEP_TRACE(1)
+            return;
+        }
+    }
     if (bcol >= 0) {
         // Row block k of B = inv(L) G, columns 32 bcol ..: B_k = inv(L_kk) (G_k - sum_{j<k} L_kj B_j) -- every operand
         // is final when this launch starts (L_kj: stored by the panels before, B_j: by their launches), so the forward
@@ -465,6 +487,7 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         if (TJ == 0) {
             store_l_block(LL, LLf, W != nullptr, ldS, m_pad, k1 + 2 * TI * NB, k0, kb, sP[0]);
             store_l_block(LL, LLf, W != nullptr, ldS, m_pad, k1 + (2 * TI + 1) * NB, k0, kb, sP[1]);
+            store_l_planes(bp, m, 2, k1 + 2 * TI * NB, sP[0], k1 + (2 * TI + 1) * NB, sP[1], k0, kb);
         }
         SWEEP_TRACE(2)
         return;
@@ -553,7 +576,10 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         // the rows of B -- in fp32 when the covariance is --, and with W set (inverse + GEMM path) also row-major and in
         // fp64 for the inverse's levels.  The look-ahead workgroup's own block is stored by the first group of tiles, which
         // holds the same block, when there is one: the look-ahead workgroup is the one the launch waits for.
-        if (n_stiles == 1) store_l_block(LL, LLf, W != nullptr, ldS, m_pad, i0, k0, kb, sLI);
+        if (n_stiles == 1) {
+            store_l_block(LL, LLf, W != nullptr, ldS, m_pad, i0, k0, kb, sLI);
+            store_l_planes(bp, m, 1, i0, sLI, i0, sLI, k0, kb);
+        }
         SWEEP_TRACE(2)
         return;
     }
@@ -1172,13 +1198,22 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     // longer than the factorisation it hides behind, and the explicit inverse + one big-tile GEMM is the better use of
     // the MFMA pipe.  e->b_path (ekf_set_update_path): 0 by size, 1 always in the sweep, 2 always by GEMM.
     const bool b_in_sweep = e->b_path == 1 || (e->b_path == 0 && m_pad <= B_SWEEP_MAX);
+    // exact configuration on one GPU, B in the sweep: its rows are formed from int8 digit planes (chol_bplanes.h), in single-panel
+    // launches (the planes of L cover B_SWEEP_MAX rows; a sharded rank does not know the diagonal of the rows it does not own)
+    const bool planes_b = EXACT && b_in_sweep && m_pad <= B_SWEEP_MAX && e->shard_world == 1 && e->d.Lq != nullptr && update_cov;
+    BPlanes bp{};
+    if (planes_b) {
+        bp.Bq = e->d.Bq; bp.b_stride = (size_t)e->bq_rows * ld; bp.ldq = ld; bp.bexp = e->d.Bexp;
+        bp.Lq = e->d.Lq; bp.nbk = e->lq_nbk; bp.l_stride = (size_t)e->lq_nbk * e->lq_nbk * 1024; bp.lexp = e->d.Lexp;
+    }
     double *V = e->d.Dinv, *W = b_in_sweep ? nullptr : e->d.W; // W = inv(L)' (and L row-major in LL): the GEMM path's
     float *Wf = sizeof(TB) == 4 && !b_in_sweep ? e->d.Wf : nullptr;
     {
         dim3 grid((n_pad / (int)(16 / sizeof(TB)) + 255) / 256, m_pad);
         k_gather<TB><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const TB *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
-                                         e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc, EXACT ? e->d.Bexp : nullptr);
+                                         e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc, EXACT ? e->d.Bexp : nullptr,
+                                         planes_b ? (const float *)e->d.P : nullptr, ld, n);
     }
     // sharded step: every rank gathered the rows of the matches it owns; the others arrive here (engine.cpp)
     e->hook_rc = e->after_gather ? e->after_gather(e, M) : 0;
@@ -1186,7 +1221,8 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     {
         dim3 grid((M + 15) / 16, (M + 15) / 16);
         k_assemble_S<TB><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
-                                             e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts);
+                                             e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts,
+                                             planes_b ? e->d.Lexp : nullptr);
     }
     const int n_bblocks = b_in_sweep ? n_pad / NB : 0; // row block k of B = inv(L) G rides in the launch of panel k
     hipEvent_t sw0 = nullptr, sw1 = nullptr;
@@ -1216,7 +1252,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const bool want_pairs = e->sweep_mode == EKF_SWEEP_PAIRS ||
                                 (e->sweep_mode == EKF_SWEEP_AUTO &&
                                  (b_in_sweep ? (long long)(k0 / NB) * n_pad >= PAIR_FROM : m - k0 >= PAIR_ROWS));
-        const bool pair_launch = have_pair || want_pairs;
+        const bool pair_launch = !planes_b && (have_pair || want_pairs);
         const int kbA = min(NB, m - k0);
         const int kbB = have_pair ? max(0, min(NB, m - k0 - NB)) : 0;
         const int k2 = k0 + kbA + (pair_launch ? kbB : 0); // first row of the trailing matrix (= m: nothing below)
@@ -1251,7 +1287,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             k_chol_step<TB, TB><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(TB) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, e->d.nu, n_stiles,
                                                              V, W, Wf, ldw, e->d.counts, sizeof(TB) == 4 ? e->d.Gc : nullptr,
                                                              e->d.zvec, e->d.Bc, G, A, ld, n_bblocks, n_rhs_blocks,
-                                                             n_wgs > e->n_cus ? 1 : 0, spacer, tr, tr_abl);
+                                                             n_wgs > e->n_cus ? 1 : 0, spacer, tr, tr_abl, bp);
             k0 += NB;
         }
     }
@@ -1304,7 +1340,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
 #define DX_LAUNCH(USEG) k_dx_partial<TB, USEG, T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, \
                                              fix ? e->d.sq_part : nullptr, fix ? e->d.cam_part : nullptr, Bc, (const T *)e->d.P, \
                                              e->rm, e->d.diag_save, fix ? e->d.cam_save : nullptr, avg, Gy, e->d.yvec, \
-                                             (EXACT && update_cov) ? e->d.Bexp : nullptr);
+                                             (EXACT && update_cov && !planes_b) ? e->d.Bexp : nullptr);
         if (Gy) { DX_LAUNCH(true) } else { DX_LAUNCH(false) }
 #undef DX_LAUNCH
 
@@ -1314,7 +1350,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     }
     if (!update_cov) return;
     const bool fix_diag = sizeof(T) == 4 && !EXACT;
-    if (EXACT) launch_p_update_exact(e, m, false, true); // (column scales: zeroed by k_gather, collected by k_dx_partial)
+    if (EXACT) launch_p_update_exact(e, m, false, true, planes_b); // (column scales: k_gather + k_dx_partial, or a-priori; planes: the sweep's)
     else launch_p_update(e, m_pad, m);
     if (fix_diag) {
         k_fix_normalize<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save,

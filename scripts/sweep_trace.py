@@ -17,7 +17,7 @@ from openekfmonoslam_amd.synth import SyntheticSequence  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 15
 seq = SyntheticSequence(N, F + 1)
-e = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=1 if N >= 1000 else 0)
+e = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=int(os.environ.get('PRECISION', '1' if N >= 1000 else '0')))
 e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
 e.set_update_path(int(os.environ.get('UPDATE_PATH', '0')))
 e.set_sweep_mode(int(os.environ.get('SWEEP_MODE', '2')))
