@@ -94,8 +94,10 @@ __device__ __forceinline__ void b_rows_planes(const BPlanes &bp, const double *G
     const int8_t *pl = bp.Lq + ((size_t)kp * bp.nbk * 2 + kg) * 512 + idx * 16;            // + j * 1024 + s * l_stride
     const int8_t *pb = bp.Bq + ((size_t)kg * bp.ldq + c0 + idx) * 16;                       // + 2 j * ldq * 16 + s * b_stride
     const size_t bstep = (size_t)2 * bp.ldq * 16;
-    bp_v4i la[3][PX_S], lb[3][PX_S]; // the operands of the next TWO blocks are in flight while one is multiplied (a round trip to
-                                     // L2 under load is over 1 us, a block's fifteen products 0.2 us)
+#ifndef BP_STAGES
+#define BP_STAGES 2 // operand blocks in flight besides the one being multiplied + 1 (3 needs 13 spilled registers at two workgroups per CU)
+#endif
+    bp_v4i la[BP_STAGES][PX_S], lb[BP_STAGES][PX_S];
 #define BP_LOAD(S_, J_)                                                                                           \
     _Pragma("unroll") for (int s = 0; s < PX_S; ++s) {                                                            \
         la[S_][s] = *(const bp_v4i *)(pl + (size_t)(J_) * 1024 + (size_t)s * bp.l_stride);                        \
@@ -106,6 +108,7 @@ __device__ __forceinline__ void b_rows_planes(const BPlanes &bp, const double *G
         _Pragma("unroll") for (int t = 0; t < PX_S - s; ++t)                                                      \
             acc[s + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(la[S_][s], lb[S_][t], acc[s + t], 0, 0, 0);
     const int cnt = kp > wv ? (kp - wv + 3) / 4 : 0;
+#if BP_STAGES == 3
     if (cnt > 0) { BP_LOAD(0, wv) }
     if (cnt > 1) { BP_LOAD(1, wv + 4) }
     for (int i = 0; i < cnt; i += 3) {
@@ -120,6 +123,17 @@ __device__ __forceinline__ void b_rows_planes(const BPlanes &bp, const double *G
             BP_MMA(2)
         }
     }
+#else
+    if (cnt > 0) { BP_LOAD(0, wv) }
+    for (int i = 0; i < cnt; i += 2) {
+        if (i + 1 < cnt) { BP_LOAD(1, wv + 4 * (i + 1)) }
+        BP_MMA(0)
+        if (i + 1 < cnt) {
+            if (i + 2 < cnt) { BP_LOAD(0, wv + 4 * (i + 2)) }
+            BP_MMA(1)
+        }
+    }
+#endif
 #undef BP_LOAD
 #undef BP_MMA
 #pragma unroll

@@ -207,8 +207,10 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 //   S itself is only read in column k, B only in rows above k, nu / Gc only in rows k: nothing races inside a launch.
 // Above B_SWEEP_MAX rows B = inv(L) G is not part of the sweep: the factor is inverted explicitly (k_inv_diag,
 // k_triinv_level) and B is one GEMM against it (k_xty, kernels_gemm.hip).
-template <typename T, typename TG> // T: type of B and of its MFMA; TG: storage type of the gathered rows G (EKF_PRECISION_F32_EXACT: double / float)
-__global__ void __launch_bounds__(256)
+// (two workgroups per CU: the early panels of a sweep have more workgroups than the chip has CUs -- tile groups + rows of B --
+// and the second round must not wait for the first: 14 against 8 us per launch on the first eight panels of an m = 920 sweep)
+template <typename T, typename TG> // T: type of B and of its MFMA; TG: storage type of the gathered rows G
+__global__ void __launch_bounds__(256, 2)
 k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0, int kb, double *nu, int n_stiles, double *V,
             double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc, const TG *G, T *Bout, int ld,
             int n_bblocks, int n_rhs, int tiles_first, int spacer, unsigned long long *trace, int abl, BPlanes bp)
