@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -851,19 +852,25 @@ int ekf_convert_inverse_depth_to_depth(EkfEngine *e, int *converted_index)
 // a one-wavefront kernel copies the 16 ints and then a sequence number, the host polls the sequence number.  The
 // per-frame control flow needs ~6 of these round trips (how many predictions / matches / inliers / rescued decide the
 // next launches); a memcpy + stream synchronise costs ~20 us each, the poll a few.
+constexpr int POLL_SECONDS = 20; // bound of a host poll in wall time (not in iterations: their rate depends on the host); then the plain path
+
 static int read_counts(EkfEngine *e)
 {
     if (e->h_mirror) {
         const int seq = ++e->mirror_seq;
         launch_publish_counts(e, e->d_mirror, seq);
         volatile int *m = e->h_mirror;
-        for (long spin = 0; spin < 400000000L; ++spin) {
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(POLL_SECONDS);
+        for (long spin = 0;; ++spin) {
             if (m[CNT_COUNT] == seq) {
                 std::atomic_thread_fence(std::memory_order_acquire);
                 for (int i = 0; i < CNT_COUNT; ++i) e->h_counts[i] = m[i];
                 return EKF_OK;
             }
-            if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(e->stream) == hipSuccess && m[CNT_COUNT] != seq) break; // stream drained without the write: fall back
+            if ((spin & 0xfffff) == 0xfffff) { // every ~1e6 polls: the stream drained without the write, or the time bound: fall back
+                if (hipStreamQuery(e->stream) == hipSuccess && m[CNT_COUNT] != seq) break;
+                if (std::chrono::steady_clock::now() > t_end) break;
+            }
         }
     }
     HIPCHK(hipMemcpyAsync(e->h_counts.data(), e->d.counts, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, e->stream));
@@ -879,13 +886,15 @@ static int wait_counts(EkfEngine *e, int seq)
 {
     if (seq <= 0) return read_counts(e);
     volatile int *m = e->h_mirror;
-    for (long spin = 0; spin < 400000000L; ++spin) {
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(POLL_SECONDS);
+    for (long spin = 0;; ++spin) {
         if (m[CNT_COUNT] == seq) {
             std::atomic_thread_fence(std::memory_order_acquire);
             for (int i = 0; i < CNT_COUNT; ++i) e->h_counts[i] = m[i];
             return EKF_OK;
         }
-        if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(e->stream) == hipSuccess && m[CNT_COUNT] != seq) break;
+        if ((spin & 0xfffff) == 0xfffff &&
+            ((hipStreamQuery(e->stream) == hipSuccess && m[CNT_COUNT] != seq) || std::chrono::steady_clock::now() > t_end)) break;
 #if defined(__x86_64__)
         __builtin_ia32_pause(); // the caller's thread polls one cache line; leave the core's other thread its issue slots
 #endif

@@ -293,15 +293,24 @@ void launch_partition(EkfEngine *e, const EkfMatch *src, int M, const uint8_t *f
 __global__ void k_shard_bounds(const EkfMatch *list, int count, const int *feat_begin, int world, int *counts)
 {
     const int r = threadIdx.x;
-    if (r > world) return;
-    const int f = feat_begin[r];
-    int lo = 0, hi = count;
+    const int f = r <= world ? feat_begin[r] : 0;
+    int lo = 0, hi = r <= world ? count : 0;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (list[mid].featureIndex < f) lo = mid + 1;
         else hi = mid;
     }
-    counts[CNT_SHARD0 + r] = lo;
+    if (r <= world) counts[CNT_SHARD0 + r] = lo;
+    // the boundaries mean "rank r's rows are ONE run" only for a list in strictly increasing feature order: verify it (one pass,
+    // all 64 threads) and poison the last boundary otherwise -- the host then refuses the update instead of exchanging rows
+    // that were never written
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i + 1 < count; i += blockDim.x)
+        if (list[i].featureIndex >= list[i + 1].featureIndex) bad = 1;
+    __syncthreads();
+    if (bad && r == world) counts[CNT_SHARD0 + r] = -1;
 }
 
 void launch_shard_bounds(EkfEngine *e, const EkfMatch *list, int count)
@@ -311,7 +320,10 @@ void launch_shard_bounds(EkfEngine *e, const EkfMatch *list, int count)
 
 __global__ void k_slice_bounds(const EkfMatch *list, int h0, int h1, int *counts)
 {
-    counts[CNT_AUX0] = list[h0].featureIndex;
+    int lo = list[h0].featureIndex;
+    for (int i = h0; i + 1 < h1; ++i) // (a batch is 32 hypotheses) the slice between the two ends is only the batch's rows for a sorted list
+        if (list[i].featureIndex >= list[i + 1].featureIndex) lo = -1;
+    counts[CNT_AUX0] = lo;
     counts[CNT_AUX1] = list[h1 - 1].featureIndex;
 }
 

@@ -527,7 +527,11 @@ k_p_update_i8p(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__
 // ------------------------------------------------------------------------------------------------ launcher
 void build_units(EkfEngine *e, int nt, int nrt, bool rect, int order); // kernels_pupdate.hip
 
-int g_px_variant = 0; // scripts/micro/pu_i8_bench.hip only: 1 = one workgroup per unit (k_p_update_i8)
+#ifdef PX_BENCH // scripts/micro/pu_i8_bench.hip only: 1 = one workgroup per unit (k_p_update_i8)
+int g_px_variant = 0;
+#else
+constexpr int g_px_variant = 0;
+#endif
 
 // B (fp64, k-major, ld = e->ldP) sits in e->d.A; camera columns from e->d.Bc when use_bc
 // exps_ready: e->d.Bexp already holds the column scales of columns 0 .. n - 1 (the engine collects them in the pass that forms
@@ -564,6 +568,7 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bo
     e->pu_slots = slots_saved;
     const int grid = e->pu_per_xcd * 8;
     const int4 *tm = (const int4 *)e->d.pu_tilemap;
+    if (grid == 0 || !tm) return; // build_units failed (e->hook_rc is set)
     if (e->timing) (void)hipEventRecord(e0, s);
     if (!e->p_exact_sym && !rect) k_p_update_i8<true><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
     else if (g_px_variant == 1 || PX_S != 5) k_p_update_i8<false><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);

@@ -501,7 +501,11 @@ k_p_update_f32(float *P, int ldp, int n, const float *B, int ldb, int m_k, int p
 // host-built work list.  Tiles: super-tiles of 8 x 8 tiles, row-major inside; upper triangle only (whole matrix on
 // one GPU) or all nrt x nt tiles of the owned row tiles (RECT).  The tail (ntiles mod #CUs tiles, i.e. what would
 // occupy only part of the chip for a whole tile time) is split into half units.
-int g_pu_order_override = -1; // scripts/micro/pu_bench.hip only
+#ifdef PU_BENCH // tuning overrides of scripts/micro/pu_bench.hip: not in the product library (process-global, not thread-safe)
+int g_pu_order_override = -1;
+#else
+constexpr int g_pu_order_override = -1;
+#endif
 
 // order: 0 half units last, 1 half units first, 2 mixed first round (see below)
 void build_units(EkfEngine *e, int nt, int nrt, bool rect, int order)
@@ -585,16 +589,29 @@ void build_units(EkfEngine *e, int nt, int nrt, bool rect, int order)
         for (size_t k = 0; k < out.size(); ++k) table[(size_t)x * per + k] = out[k];
     }
     e->d.pu_tilemap = nullptr;
-    (void)hipMalloc((void **)&e->d.pu_tilemap, table.size() * sizeof(int4));
-    (void)hipMemcpyAsync(e->d.pu_tilemap, table.data(), table.size() * sizeof(int4), hipMemcpyHostToDevice, e->stream);
-    (void)hipStreamSynchronize(e->stream);
+    if (hipMalloc((void **)&e->d.pu_tilemap, table.size() * sizeof(int4)) != hipSuccess ||
+        hipMemcpyAsync(e->d.pu_tilemap, table.data(), table.size() * sizeof(int4), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess) {
+        // no work list: the caller's launch is skipped (grid 0) and the update reports the failure instead of downdating garbage
+        if (e->d.pu_tilemap) (void)hipFree(e->d.pu_tilemap);
+        e->d.pu_tilemap = nullptr;
+        e->pu_per_xcd = 0;
+        e->pu_tilemap_nt = -1;
+        e->err = "work list of the covariance downdate: allocation or upload failed";
+        e->hook_rc = EKF_ERR_HIP;
+        return;
+    }
     e->pu_tilemap_nt = key;
     e->pu_per_xcd = per;
     e->pu_tables[key] = std::make_pair(e->d.pu_tilemap, per);
 }
 
-int g_pu_stagger_override = -1; // scripts/micro/pu_bench.hip only
-int g_pu_force_slots = 0;       // scripts/micro/pu_bench.hip only: the slot count the unit list is balanced against
+#ifdef PU_BENCH
+int g_pu_stagger_override = -1;
+int g_pu_force_slots = 0;       // the slot count the unit list is balanced against
+#else
+constexpr int g_pu_stagger_override = -1, g_pu_force_slots = 0;
+#endif
 
 template <typename T>
 static void launch_p_update_t(EkfEngine *e, int m_pad, int grid, const int4 *tm, bool avg, bool rect)
@@ -647,6 +664,7 @@ void launch_p_update(EkfEngine *e, int m_pad, int m)
     e->pu_slots = slots_saved;
     const int grid = e->pu_per_xcd * 8;
     const int4 *tm = (const int4 *)e->d.pu_tilemap;
+    if (grid == 0 || !tm) return; // build_units failed (e->hook_rc is set)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (e->timing) {
         (void)hipEventCreate(&e0);

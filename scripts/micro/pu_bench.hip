@@ -3,6 +3,7 @@
 // result), then timed with HIP events, interleaved rounds, median and min per variant (guide rule 24).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I openekfmonoslam_amd/csrc scripts/micro/pu_bench.hip -o scripts/micro/pu_bench
 //   scripts/micro/pu_bench [N=1000] [m list, e.g. 298,1014,2000]
+#define PU_BENCH
 #include "../../openekfmonoslam_amd/csrc/kernels_pupdate.hip"
 #ifdef PU_BENCH_ABLATIONS
 #include "pu_v3.h"

@@ -6,6 +6,8 @@
 //   * timing: HIP events per kernel, interleaved rounds, median and min.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I openekfmonoslam_amd/csrc scripts/micro/pu_i8_bench.hip -o scripts/micro/pu_i8_bench
 //   scripts/micro/pu_i8_bench [N=1000] [m list, e.g. 298,1014,2000] [rounds]
+#define PX_BENCH
+#define PU_BENCH
 #include "../../openekfmonoslam_amd/csrc/kernels_pupdate.hip"
 #include "../../openekfmonoslam_amd/csrc/kernels_pexact.hip"
 

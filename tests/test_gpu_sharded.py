@@ -48,7 +48,10 @@ def test_sharded_steps_match_unsharded(eng_mod, oracle_lib, nfeat, world, precis
     x, fp, P = grp.get_state()
     xr, fpr, Pr = ref.get_state()
     assert not np.isnan(P).any(), "some rows of P were returned by no rank"
-    tol = 1e-12 if precision == 0 else 1e-6
+    # precision 2: the unsharded engine forms the rows of B from int8 digit planes with a-priori column scales (chol_bplanes.h), a
+    # rank of the sharded one in fp64 with the columns' true maxima -- two roundings of the same fp32-stored filter, 1.3e-6 apart
+    # component-wise after three frames (measured); held to the north-star 1e-5
+    tol = 1e-12 if precision == 0 else (1e-6 if precision == 1 else 1e-5)
     assert state_err(x, fp, xr, fpr) <= tol
     assert rel_max(P, Pr) <= tol
     # replicated pieces are bitwise identical on every rank
