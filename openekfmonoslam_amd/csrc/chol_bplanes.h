@@ -36,6 +36,7 @@ struct BPlanes {
     size_t l_stride = 0;      // bytes per plane of L
     int nbk = 0;              // blocks per side of the L planes
     const int *lexp = nullptr; // biased exponent of the row scale of L
+    const int *grow = nullptr; // row of the H P table behind every row of G (-1: a zero row), see k_gather
 };
 
 // Digit planes of TWO 32 x 32 blocks of L (rows i0a.. and i0b.., columns k0 .. k0 + kb - 1, in LDS; n_blk = 1: the first
@@ -83,8 +84,11 @@ __device__ __forceinline__ void b_rows_planes(const BPlanes &bp, const double *G
     // this thread's four elements of G_k, requested first: they are cold and only needed at the end
     const int r4 = tid >> 3, cg = (tid & 7) * 4;
     double g4[4];
+    {
+        const int gr = bp.grow[k0 + r4]; // (G is the H P table; rows m .. m_pad are zero)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) g4[e] = G[(size_t)(k0 + r4) * ld + c0 + cg + e];
+        for (int e = 0; e < 4; ++e) g4[e] = gr >= 0 ? G[(size_t)gr * ld + c0 + cg + e] : 0.0;
+    }
     bp_v16i acc[PX_S];
 #pragma unroll
     for (int L = 0; L < PX_S; ++L)

@@ -140,6 +140,7 @@ struct DeviceArrays {
     int *Bexp = nullptr;        // its column scales (biased exponents), ldP ints
     int8_t *Lq = nullptr;       // digit planes of L for the rows of B formed from planes (chol_bplanes.h): PX_S x lq_nbk^2 KB
     int *Lexp = nullptr;        // row scales of L (biased exponents)
+    int *Grow = nullptr;        // row of the H P table behind every gathered row (k_gather without the copy)
 };
 
 // current frame of the NCC matcher: gray pyramid (level 0 = full resolution) + the raw upload staging buffer

@@ -31,25 +31,29 @@ __global__ void __launch_bounds__(256)
 k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
          const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
          double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, int *bexp, const float *Pdiag, int ldpd,
-         int n)
+         int n, int *grow)
 {
+    // grow != nullptr (exact configuration, rows of B from digit planes): the rows are NOT copied -- their consumers (k_assemble_S,
+    // b_rows_planes) read H P through the row map grow[row] = row of H P, -1 for the zero rows m .. m_pad; the launch then has
+    // one workgroup column (grid.x = 1 covers the per-match bookkeeping; the column scales are written by grid.y = 0's columns)
     const int row = blockIdx.y;
-    if (bexp && row == 0) {
-        // exact downdate, column scales of B.  Pdiag == nullptr: collected by k_dx_partial (atomicMax of the entries' exponents),
-        // start from zero.  Otherwise (rows of B from digit planes, chol_bplanes.h) a-priori: |B_kj| <= sqrt(P_jj)
+    if (bexp && grow) {
+        // rows of B from digit planes (chol_bplanes.h): the column scales are known before B exists, |B_kj| <= sqrt(P_jj); the
+        // m_pad workgroups of this launch (one per row, no copy) share the columns
+        if (blockIdx.x == 0) {
+            const int per = (n_pad + m_pad - 1) / m_pad;
+            for (int j = row * per + threadIdx.x; j < min((row + 1) * per, n_pad); j += 256) {
+                const float pjj = j < n ? Pdiag[(size_t)j * ldpd + j] : 0.f;
+                bexp[j] = pjj > 0.f ? ilogb(sqrt((double)pjj) * 1.001) + 1 + 1022 : 1022;
+            }
+        }
+    } else if (bexp && row == 0) {
+        // exact downdate, column scales of B collected by k_dx_partial (atomicMax of the entries' exponents): start from zero
         constexpr int VWz = 16 / sizeof(T);
         const int jz = (blockIdx.x * 256 + threadIdx.x) * VWz;
 #pragma unroll
-        for (int v = 0; v < VWz; ++v) {
-            const int j = jz + v;
-            if (j >= n_pad) continue;
-            int be = 0;
-            if (Pdiag) {
-                const float pjj = j < n ? Pdiag[(size_t)j * ldpd + j] : 0.f;
-                be = pjj > 0.f ? ilogb(sqrt((double)pjj) * 1.001) + 1 + 1022 : 1022;
-            }
-            bexp[j] = be;
-        }
+        for (int v = 0; v < VWz; ++v)
+            if (jz + v < n_pad) bexp[jz + v] = 0;
     }
     // 16 bytes per thread: the copy is pure HBM traffic (n_pad and ld are multiples of 128 elements)
     constexpr int VW = 16 / sizeof(T);
@@ -59,7 +63,9 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
     if (row < m) {
         const int i = row >> 1, r = row & 1;
         const int fi = matches[i].featureIndex;
-        if (j < n_pad) *(vec_t *)(A + (size_t)row * ld + j) = *(const vec_t *)(HP + (size_t)(2 * fi + r) * ld + j);
+        if (grow) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) grow[row] = 2 * fi + r;
+        } else if (j < n_pad) *(vec_t *)(A + (size_t)row * ld + j) = *(const vec_t *)(HP + (size_t)(2 * fi + r) * ld + j);
         if (blockIdx.x == 0 && threadIdx.x < 16) Gc[(size_t)row * 16 + threadIdx.x] = threadIdx.x < 13 ? HPc[(size_t)(2 * fi + r) * 16 + threadIdx.x] : 0.0;
         if (blockIdx.x == 0 && r == 0) {
             const int t = threadIdx.x;
@@ -74,7 +80,9 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
             }
         }
     } else if (row < m_pad) {
-        if (j < n_pad) {
+        if (grow) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) grow[row] = -1;
+        } else if (j < n_pad) {
             vec_t zero;
 #pragma unroll
             for (int v = 0; v < VW; ++v) zero[v] = (T)0;
@@ -134,7 +142,7 @@ __device__ __forceinline__ void store_linv(double *V, double *W, float *Wf, int 
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, const int *mpos, const int *mdim,
-             double pixel_err, double *S, int ldS, double *V, double *W, float *Wf, int ldw, int *counts, int *lexp)
+             double pixel_err, double *S, int ldS, double *V, double *W, float *Wf, int ldw, int *counts, int *lexp, const int *grow)
 {
     const int b = blockIdx.x * 16 + (threadIdx.x & 15);
     const int a = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -143,7 +151,7 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
         const double *hs = mHs + 14 * b, *hf = mHf + 12 * b;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const T *ar = A + (size_t)(2 * a + r) * ld;
+            const T *ar = A + (size_t)(grow ? grow[2 * a + r] : 2 * a + r) * ld; // (grow: A is the H P table itself)
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
@@ -1193,7 +1201,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     const int m = 2 * M, n = e->n, ld = e->ldP, ldS = e->ldS, ldw = e->ldW;
     const int m_pad = round_up(m, NB);
     const int n_pad = round_up(n, LD_ALIGN);
-    TB *G = (TB *)e->d.G; // gathered rows of H P
+    TB *G = (TB *)e->d.G; // gathered rows of H P (or the H P table itself, see planes_b)
     TB *A = (TB *)e->d.A; // B = inv(L) G
     // B = inv(L) G: up to B_SWEEP_MAX rows, row block k is formed inside the launch of panel k (forward substitution
     // beside the look-ahead factorisation: no explicit inverse, no GEMM launch); above it the per-launch row block becomes
@@ -1207,15 +1215,18 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     if (planes_b) {
         bp.Bq = e->d.Bq; bp.b_stride = (size_t)e->bq_rows * ld; bp.ldq = ld; bp.bexp = e->d.Bexp;
         bp.Lq = e->d.Lq; bp.nbk = e->lq_nbk; bp.l_stride = (size_t)e->lq_nbk * e->lq_nbk * 1024; bp.lexp = e->d.Lexp;
+        bp.grow = e->d.Grow;
     }
     double *V = e->d.Dinv, *W = b_in_sweep ? nullptr : e->d.W; // W = inv(L)' (and L row-major in LL): the GEMM path's
     float *Wf = sizeof(TB) == 4 && !b_in_sweep ? e->d.Wf : nullptr;
     {
         dim3 grid((n_pad / (int)(16 / sizeof(TB)) + 255) / 256, m_pad);
+        if (planes_b) grid.x = 1; // no copy: one workgroup per row (bookkeeping, row map, its share of the column scales)
         k_gather<TB><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const TB *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
                                          e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc, EXACT ? e->d.Bexp : nullptr,
-                                         planes_b ? (const float *)e->d.P : nullptr, ld, n);
+                                         planes_b ? (const float *)e->d.P : nullptr, ld, n, planes_b ? e->d.Grow : nullptr);
+        if (planes_b) G = (TB *)e->d.HP; // the consumers read H P through the row map
     }
     // sharded step: every rank gathered the rows of the matches it owns; the others arrive here (engine.cpp)
     e->hook_rc = e->after_gather ? e->after_gather(e, M) : 0;
@@ -1224,7 +1235,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         dim3 grid((M + 15) / 16, (M + 15) / 16);
         k_assemble_S<TB><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts,
-                                             planes_b ? e->d.Lexp : nullptr);
+                                             planes_b ? e->d.Lexp : nullptr, planes_b ? e->d.Grow : nullptr);
     }
     const int n_bblocks = b_in_sweep ? n_pad / NB : 0; // row block k of B = inv(L) G rides in the launch of panel k
     hipEvent_t sw0 = nullptr, sw1 = nullptr;
