@@ -278,7 +278,7 @@ int ekf_round_covariance_to_f32(EkfEngine *e);
  * several ranks share a GPU (tests).  Map management is not available on a sharded engine. */
 typedef int (*EkfExchangeFn)(void *user, int what, void *device_base, size_t row_bytes, const int32_t *row_begin,
                              int world, int rank);
-enum { EKF_XCHG_HP = 0, EKF_XCHG_PRED_S = 1, EKF_XCHG_HPC = 2 };
+enum { EKF_XCHG_HP = 0, EKF_XCHG_PRED_S = 1, EKF_XCHG_HPC = 2, EKF_XCHG_PDIAG = 3, EKF_XCHG_BPLANES = 4 };
 /* what: which replicated table is being completed; device_base: its first row on this rank's GPU; rank r owns rows
  * [row_begin[r], row_begin[r+1]) of row_bytes each and has just written them.  The callback returns when this
  * rank's table holds every rank's rows (0 = ok).  It is called with the engine's stream idle. */
@@ -298,6 +298,10 @@ int ekf_comm_init(EkfEngine *e, const uint8_t id[EKF_COMM_ID_BYTES]);
  * which every rank also keeps).  On a sharded engine ekf_set_state takes the full n x n matrix and keeps its rows;
  * ekf_get_state fills only those rows of the caller's n x n buffer (camera rows + owned rows). */
 int ekf_shard_info(const EkfEngine *e, int *rank, int *world, int *row_begin, int *row_end);
+/* EKF_PRECISION_F32_EXACT on a sharded engine: a rank forms the rows of B = inv(L) H P for its own column blocks only and receives
+ * the others' int8 digit planes (5 bytes per element of B).  plane_bytes_received: total since creation; [own_columns_begin,
+ * own_columns_end): the columns (multiples of 32) whose rows of B this rank forms.  Tests compare both with the cost model. */
+int ekf_shard_counters(EkfEngine *e, int64_t *plane_bytes_received, int32_t *own_columns_begin, int32_t *own_columns_end);
 /* device-to-device copy on the engine's device, synchronous: the exchange primitive when ranks share a GPU */
 int ekf_device_copy(EkfEngine *e, void *dst, const void *src, size_t bytes);
 

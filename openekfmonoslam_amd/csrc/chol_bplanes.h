@@ -36,7 +36,8 @@ struct BPlanes {
     size_t l_stride = 0;      // bytes per plane of L
     int nbk = 0;              // blocks per side of the L planes
     const int *lexp = nullptr; // biased exponent of the row scale of L
-    const int *grow = nullptr; // row of the H P table behind every row of G (-1: a zero row), see k_gather
+    const int *grow = nullptr; // row of the H P table behind every row of G (-1: a zero row), see k_gather; null: G is a copy
+    int bcol0 = 0;             // first column block of this rank (row-sharded engines form their own blocks only)
 };
 
 // Digit planes of TWO 32 x 32 blocks of L (rows i0a.. and i0b.., columns k0 .. k0 + kb - 1, in LDS; n_blk = 1: the first
@@ -85,7 +86,7 @@ __device__ __forceinline__ void b_rows_planes(const BPlanes &bp, const double *G
     const int r4 = tid >> 3, cg = (tid & 7) * 4;
     double g4[4];
     {
-        const int gr = bp.grow[k0 + r4]; // (G is the H P table; rows m .. m_pad are zero)
+        const int gr = bp.grow ? bp.grow[k0 + r4] : k0 + r4; // (grow: G is the H P table; rows m .. m_pad are zero)
 #pragma unroll
         for (int e = 0; e < 4; ++e) g4[e] = gr >= 0 ? G[(size_t)gr * ld + c0 + cg + e] : 0.0;
     }

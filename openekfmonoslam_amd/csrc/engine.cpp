@@ -84,6 +84,8 @@ static hipError_t dalloc(T **p, size_t count, bool zero = true)
     return st;
 }
 
+static int exchange_rows(EkfEngine *e, int what, void *base, size_t row_bytes, const std::vector<int32_t> &rb, const char *name);
+
 // element size of H P and of its gathered rows (fp64 beside the exact downdate, else the covariance's)
 static inline size_t hp_elem_bytes(const EkfEngine *e) { return e->exact ? 8 : (e->f32 ? 4 : 8); }
 
@@ -123,7 +125,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
                     d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.W, d.Wf, d.G, d.LL, d.LLf, d.Tbuf, d.gates, d.cell_resp, d.cell_xy,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.sq_part, d.diag_save, d.cam_part, d.cam_save, d.HPc, d.Gc, d.Bc, d.zvec, d.yvec,
-                    e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq, d.Bq, d.Bexp, d.Lq, d.Lexp, d.Grow};
+                    e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq, d.Bq, d.Bexp, d.Lq, d.Lexp, d.Grow, d.Pdiag, d.Bstage};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &kv : e->pu_tables)
@@ -239,11 +241,16 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
             e->bq_rows = round_up((int)mcap, 64) + 64;
             if ((st = dalloc(&d.Bq, (size_t)PX_S * e->bq_rows * e->ldP)) != hipSuccess) return fail(st, "hipMalloc Bq");
             if ((st = dalloc(&d.Bexp, (size_t)e->ldP)) != hipSuccess) return fail(st, "hipMalloc Bexp");
-            if (world == 1) { // rows of B from digit planes (chol_bplanes.h): planes of L for the sweeps that form B
+            {   // rows of B from digit planes (chol_bplanes.h): planes of L for the sweeps that form B
                 e->lq_nbk = (std::min((int)mcap, B_SWEEP_MAX) + NB - 1) / NB + 2;
                 if ((st = dalloc(&d.Lq, (size_t)PX_S * e->lq_nbk * e->lq_nbk * 1024)) != hipSuccess) return fail(st, "hipMalloc Lq");
                 if ((st = dalloc(&d.Lexp, (size_t)mcap + 256)) != hipSuccess) return fail(st, "hipMalloc Lexp");
                 if ((st = dalloc(&d.Grow, (size_t)mcap + 256)) != hipSuccess) return fail(st, "hipMalloc Grow");
+            }
+            if (world > 1) { // sharded: the diagonal table and the exchange image of the planes (rows of B up to B_SWEEP_MAX)
+                if ((st = dalloc(&d.Pdiag, (size_t)e->ldP)) != hipSuccess) return fail(st, "hipMalloc Pdiag");
+                const size_t rows = (size_t)round_up(std::min((int)mcap, B_SWEEP_MAX) + NB, 64);
+                if ((st = dalloc(&d.Bstage, (size_t)PX_S * rows * e->ldP)) != hipSuccess) return fail(st, "hipMalloc Bstage");
             }
         }
         if ((st = dalloc(&raw, (size_t)(mcap + 1) * e->ldP * wb)) != hipSuccess) return fail(st, "hipMalloc G");
@@ -326,6 +333,7 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
         }
     }
     e->shard_feat_begin.assign(world + 1, 0);
+    e->exchange_hook = exchange_rows;
     *out = e;
     return EKF_OK;
 }
@@ -389,6 +397,7 @@ int ekf_comm_init(EkfEngine *e, const uint8_t id[EKF_COMM_ID_BYTES])
 static int exchange_rows(EkfEngine *e, int what, void *base, size_t row_bytes, const std::vector<int32_t> &rb, const char *name)
 {
     const int world = e->shard_world, me = e->shard_rank;
+    if (what == EKF_XCHG_BPLANES) e->xchg_bytes_planes += (long long)((size_t)(rb[world] - rb[0] - (rb[me + 1] - rb[me])) * row_bytes);
     if (e->comm && !e->xchg) { // a callback installed after ekf_comm_init takes over (ranks that fell back by consensus)
         RcclApi &api = rccl_api();
         ncclComm_t c = (ncclComm_t)e->comm;
@@ -430,6 +439,17 @@ int ekf_shard_info(const EkfEngine *e, int *rank, int *world, int *row_begin, in
     return EKF_OK;
 }
 
+int ekf_shard_counters(EkfEngine *e, int64_t *plane_bytes_received, int32_t *own_columns_begin, int32_t *own_columns_end)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    if (plane_bytes_received) *plane_bytes_received = e->xchg_bytes_planes;
+    const int n_pad = round_up(e->n, LD_ALIGN), W = e->shard_world, r = e->shard_rank;
+    auto col = [&](int k) { return k <= 0 ? 0 : (k >= W ? n_pad : std::min(n_pad, round_up(e->shard_row_begin.size() > (size_t)k ? e->shard_row_begin[k] : e->n, NB))); };
+    if (own_columns_begin) *own_columns_begin = col(r);
+    if (own_columns_end) *own_columns_end = col(r + 1);
+    return EKF_OK;
+}
+
 int ekf_device_copy(EkfEngine *e, void *dst, const void *src, size_t bytes)
 {
     if (!e || (bytes > 0 && (!dst || !src))) return EKF_ERR_INVALID_ARG;
@@ -446,6 +466,7 @@ static void refresh_row_map(EkfEngine *e)
         e->rm = RowMap{13, e->n, 13};
         e->shard_feat_begin.assign(2, 0);
         e->shard_feat_begin[1] = N;
+        e->shard_row_begin = {0, e->n};
         return;
     }
     const int per = N / W, extra = N % W;
@@ -453,6 +474,8 @@ static void refresh_row_map(EkfEngine *e)
     const int f0 = e->shard_feat_begin[e->shard_rank], f1 = e->shard_feat_begin[e->shard_rank + 1];
     auto row_of = [&](int f) { return f < N ? e->h_covpos[f] : e->n; };
     e->rm = RowMap{row_of(f0), row_of(f1), SHARD_BASE};
+    e->shard_row_begin.assign(W + 1, 0);
+    for (int r = 1; r <= W; ++r) e->shard_row_begin[r] = row_of(e->shard_feat_begin[r]);
     (void)hipMemcpyAsync(e->d.shard_feat, e->shard_feat_begin.data(), (size_t)(W + 1) * sizeof(int), hipMemcpyHostToDevice, e->stream);
     (void)hipStreamSynchronize(e->stream); // the host vector may be reassigned before the copy would otherwise run
 }

@@ -141,6 +141,8 @@ struct DeviceArrays {
     int8_t *Lq = nullptr;       // digit planes of L for the rows of B formed from planes (chol_bplanes.h): PX_S x lq_nbk^2 KB
     int *Lexp = nullptr;        // row scales of L (biased exponents)
     int *Grow = nullptr;        // row of the H P table behind every gathered row (k_gather without the copy)
+    float *Pdiag = nullptr;     // sharded exact configuration: diagonal of P, n floats, completed by an exchange
+    int8_t *Bstage = nullptr;   // ... and the digit planes of B in the exchange layout [column][plane][k / 16][16]
 };
 
 // current frame of the NCC matcher: gray pyramid (level 0 = full resolution) + the raw upload staging buffer
@@ -187,6 +189,10 @@ struct EkfEngine {
     void *comm = nullptr;                // ncclComm_t of the in-engine transport (ekf_comm_init), or null
     bool hp_complete = true;             // sharded: the H.P table holds EVERY rank's rows since the last prediction
     int (*after_gather)(EkfEngine *, int) = nullptr; // sharded step: completes the gathered rows right after k_gather
+    // the row-block exchange of engine.cpp (RCCL send / recv or the host callback), callable from the update's launcher
+    int (*exchange_hook)(EkfEngine *, int what, void *base, size_t row_bytes, const std::vector<int32_t> &rb, const char *name) = nullptr;
+    std::vector<int32_t> shard_row_begin; // [world + 1] first state row of each rank's share (0 for rank 0: it also holds the camera's), n at the end
+    long long xchg_bytes_planes = 0;      // bytes of digit planes this rank received (tests assert them against the model)
     int hook_rc = 0;                     // its status (launch_update returns nothing)
     std::vector<int32_t> shard_rb;       // row boundaries of the gathered rows by owner (from CNT_SHARD0..)
     void *xchg_user = nullptr;
@@ -300,6 +306,9 @@ void launch_ransac_init(EkfEngine *e, int M);
 void launch_update(EkfEngine *e, int M, bool update_cov);
 void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready = false, bool planes_ready = false); // kernels_pexact.hip
 void launch_round_P_f32(EkfEngine *e);                        // kernels_map.hip
+void launch_diag_extract(EkfEngine *e, float *diag);          // kernels_pexact.hip: sharded exact configuration
+void launch_planes_move(EkfEngine *e, bool pack, int m_k, int c_lo, int c_hi, int skip_lo, int skip_hi);
+void launch_dx_planes(EkfEngine *e, int m_k);
 void launch_rescue(EkfEngine *e, int M);
 void launch_state_only_predict(EkfEngine *e, EkfPrediction *d_out); // predictMeasurementState on current state
 void launch_add_features(EkfEngine *e, const double *d_uv, int count, double *d_Jpo, double *d_Jhr);

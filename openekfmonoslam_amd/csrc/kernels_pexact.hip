@@ -102,6 +102,87 @@ k_slice_B(const double *B, int ld, int m, int m_k, const double *Bc, const int *
     }
 }
 
+// ------------------------------------------------------------------------------------------------ sharded filter
+// Row-sharded engines in the exact configuration: rank r forms the rows of B only for ITS column blocks (the
+// columns of the state rows it owns: the m^2 n work of B = inv(L) G divided by the number of ranks), from digit planes whose
+// column scales need the diagonal of P of those columns; the downdate of its rows then needs every column's planes.
+//   k_diag_extract   the diagonal of the owned rows into a table of n floats (completed by an exchange of 4 n bytes)
+//   k_planes_pack    the planes of the columns [c_lo, c_hi) into the exchange layout [column][plane][k / 16][16]: a rank's share
+//                    is one contiguous run of "rows" of PX_S m / 16 x 16 bytes, which is what the engine's row-block exchange moves
+//   k_planes_unpack  the other ranks' columns back into [plane][k / 16][column][16]
+//   k_dx_planes      dx = B'z from the planes, every column (the fp64 rows of B exist only for the own columns)
+__global__ void __launch_bounds__(256) k_diag_extract(const float *P, int ld, RowMap rm, int n, float *diag)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n && owns_row(rm, j)) diag[j] = P[(size_t)local_row(rm, j) * ld + j];
+}
+
+template <bool PACK>
+__global__ void __launch_bounds__(256)
+k_planes_move(int8_t *Bq, size_t b_stride, int ldq, int m16, int c_lo, int c_hi, int skip_lo, int skip_hi, int8_t *stage)
+{
+    // one 16-byte group per thread; consecutive threads take consecutive columns of one (plane, k group)
+    const int ncol = c_hi - c_lo;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)ncol * PX_S * m16) return;
+    const int col = c_lo + (int)(idx % ncol);
+    const int sk = (int)(idx / ncol), s = sk / m16, kb = sk % m16;
+    if (!PACK && col >= skip_lo && col < skip_hi) return; // (unpack: the own columns are already in place)
+    uint4 *pl = (uint4 *)(Bq + (size_t)s * b_stride + ((size_t)kb * ldq + col) * 16);
+    uint4 *st = (uint4 *)(stage + (((size_t)col * PX_S + s) * m16 + kb) * 16);
+    if (PACK) *st = *pl;
+    else *pl = *st;
+}
+
+__global__ void __launch_bounds__(256)
+k_dx_planes(const int8_t *Bq, size_t b_stride, int ldq, int m16, int n, const int *bexp, const double *z, double *part, int ldpart)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, ks = blockIdx.y;
+    if (j >= n) return;
+    const int per = (m16 + DX_SPLIT - 1) / DX_SPLIT;
+    const int kb0 = ks * per, kb1 = min(m16, kb0 + per);
+    double sum = 0.0;
+    for (int kb = kb0; kb < kb1; ++kb) {
+        uint4 d[PX_S];
+#pragma unroll
+        for (int s = 0; s < PX_S; ++s) d[s] = *(const uint4 *)(Bq + (size_t)s * b_stride + ((size_t)kb * ldq + j) * 16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            long long X = 0;
+#pragma unroll
+            for (int s = 0; s < PX_S; ++s) {
+                const unsigned w = i < 4 ? d[s].x : (i < 8 ? d[s].y : (i < 12 ? d[s].z : d[s].w));
+                X = X * 256 + (long long)(signed char)((w >> (8 * (i & 3))) & 255u);
+            }
+            sum += (double)X * z[16 * kb + i];
+        }
+    }
+    part[(size_t)ks * ldpart + j] = ldexp(sum, (bexp[j] - 1022) - (8 * PX_S - 2));
+}
+
+void launch_diag_extract(EkfEngine *e, float *diag)
+{
+    k_diag_extract<<<(e->n + 255) / 256, 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->rm, e->n, diag);
+}
+
+void launch_planes_move(EkfEngine *e, bool pack, int m_k, int c_lo, int c_hi, int skip_lo, int skip_hi)
+{
+    const int m16 = m_k / 16;
+    const long long total = (long long)(c_hi - c_lo) * PX_S * m16;
+    if (total <= 0) return;
+    const size_t b_stride = (size_t)e->bq_rows * e->ldP;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (pack) k_planes_move<true><<<grid, 256, 0, e->stream>>>(e->d.Bq, b_stride, e->ldP, m16, c_lo, c_hi, 0, 0, e->d.Bstage);
+    else k_planes_move<false><<<grid, 256, 0, e->stream>>>(e->d.Bq, b_stride, e->ldP, m16, c_lo, c_hi, skip_lo, skip_hi, e->d.Bstage);
+}
+
+void launch_dx_planes(EkfEngine *e, int m_k)
+{
+    const size_t b_stride = (size_t)e->bq_rows * e->ldP;
+    k_dx_planes<<<dim3((e->n + 255) / 256, DX_SPLIT), 256, 0, e->stream>>>(e->d.Bq, b_stride, e->ldP, m_k / 16, e->n, e->d.Bexp, e->d.zvec,
+                                                                        e->d.dx_part, e->ldP);
+}
+
 // ------------------------------------------------------------------------------------------------ the downdate
 // Workgroup = 512 threads = 8 wavefronts (2 x 4), tile 128 x 128 of the upper triangle; wavefront (wr, wc) owns rows
 // 64 wr .. + 63 (two 32 x 32 MFMA blocks) and columns 32 wc .. + 31, five int32 accumulators per block (160 registers).

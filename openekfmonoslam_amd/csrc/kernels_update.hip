@@ -37,7 +37,7 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
     // b_rows_planes) read H P through the row map grow[row] = row of H P, -1 for the zero rows m .. m_pad; the launch then has
     // one workgroup column (grid.x = 1 covers the per-match bookkeeping; the column scales are written by grid.y = 0's columns)
     const int row = blockIdx.y;
-    if (bexp && grow) {
+    if (bexp && Pdiag) {
         // rows of B from digit planes (chol_bplanes.h): the column scales are known before B exists, |B_kj| <= sqrt(P_jj); the
         // m_pad workgroups of this launch (one per row, no copy) share the columns
         if (blockIdx.x == 0) {
@@ -292,7 +292,7 @@ k_chol_step(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
     // (gv lands in sLi inside each role, after the role's own loads have been requested: one round trip, not two)
     if constexpr (sizeof(T) == 8 && sizeof(TG) == 8) {
         if (bcol >= 0 && bp.Bq) { // EKF_PRECISION_F32_EXACT: the same role from int8 digit planes (chol_bplanes.h)
-            b_rows_planes(bp, (const double *)G, (double *)Bout, ld, m, k0, bcol, pool, sLi, gv);
+            b_rows_planes(bp, (const double *)G, (double *)Bout, ld, m, k0, bcol + bp.bcol0, pool, sLi, gv);
             SWEEP_TRACE(1)
             return;
         }
@@ -1210,23 +1210,44 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     const bool b_in_sweep = e->b_path == 1 || (e->b_path == 0 && m_pad <= B_SWEEP_MAX);
     // exact configuration on one GPU, B in the sweep: its rows are formed from int8 digit planes (chol_bplanes.h), in single-panel
     // launches (the planes of L cover B_SWEEP_MAX rows; a sharded rank does not know the diagonal of the rows it does not own)
-    const bool planes_b = EXACT && b_in_sweep && m_pad <= B_SWEEP_MAX && e->shard_world == 1 && e->d.Lq != nullptr && update_cov;
+    const bool sharded = e->shard_world > 1;
+    const bool planes_b = EXACT && b_in_sweep && m_pad <= B_SWEEP_MAX && e->d.Lq != nullptr && update_cov &&
+                          (!sharded || (e->exchange_hook && e->d.Bstage && (int)e->shard_row_begin.size() == e->shard_world + 1));
     BPlanes bp{};
+    // sharded: this rank forms the column blocks [cb0, cb1) of B -- the blocks whose first column lies in its share of the state
+    // rows (rank 0: from column 0) -- and receives the others' digit planes afterwards (the B role divided by the ranks)
+    int cb0 = 0, cb1 = n_pad / NB;
+    std::vector<int32_t> col_rb; // column boundaries of the ranks' shares of the planes
     if (planes_b) {
         bp.Bq = e->d.Bq; bp.b_stride = (size_t)e->bq_rows * ld; bp.ldq = ld; bp.bexp = e->d.Bexp;
         bp.Lq = e->d.Lq; bp.nbk = e->lq_nbk; bp.l_stride = (size_t)e->lq_nbk * e->lq_nbk * 1024; bp.lexp = e->d.Lexp;
-        bp.grow = e->d.Grow;
+        bp.grow = sharded ? nullptr : e->d.Grow;
+        if (sharded) {
+            const int W = e->shard_world;
+            col_rb.assign(W + 1, 0);
+            for (int r = 1; r < W; ++r) col_rb[r] = std::min(n_pad, round_up(e->shard_row_begin[r], NB));
+            col_rb[W] = n_pad;
+            cb0 = col_rb[e->shard_rank] / NB;
+            cb1 = col_rb[e->shard_rank + 1] / NB;
+            bp.bcol0 = cb0;
+            // the diagonal of P behind the a-priori column scales: every rank's own entries, then all of them
+            launch_diag_extract(e, e->d.Pdiag);
+            std::vector<int32_t> drb(e->shard_row_begin.begin(), e->shard_row_begin.end());
+            e->hook_rc = e->exchange_hook(e, EKF_XCHG_PDIAG, e->d.Pdiag, sizeof(float), drb, "the diagonal of P");
+            if (e->hook_rc) return;
+        }
     }
     double *V = e->d.Dinv, *W = b_in_sweep ? nullptr : e->d.W; // W = inv(L)' (and L row-major in LL): the GEMM path's
     float *Wf = sizeof(TB) == 4 && !b_in_sweep ? e->d.Wf : nullptr;
     {
         dim3 grid((n_pad / (int)(16 / sizeof(TB)) + 255) / 256, m_pad);
-        if (planes_b) grid.x = 1; // no copy: one workgroup per row (bookkeeping, row map, its share of the column scales)
+        if (planes_b && !sharded) grid.x = 1; // no copy: one workgroup per row (bookkeeping, row map, its share of the column scales)
         k_gather<TB><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const TB *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
                                          e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc, EXACT ? e->d.Bexp : nullptr,
-                                         planes_b ? (const float *)e->d.P : nullptr, ld, n, planes_b ? e->d.Grow : nullptr);
-        if (planes_b) G = (TB *)e->d.HP; // the consumers read H P through the row map
+                                         planes_b ? (sharded ? e->d.Pdiag : (const float *)e->d.P) : nullptr, sharded ? 0 : ld, n,
+                                         planes_b && !sharded ? e->d.Grow : nullptr);
+        if (planes_b && !sharded) G = (TB *)e->d.HP; // the consumers read H P through the row map
     }
     // sharded step: every rank gathered the rows of the matches it owns; the others arrive here (engine.cpp)
     e->hook_rc = e->after_gather ? e->after_gather(e, M) : 0;
@@ -1235,9 +1256,9 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         dim3 grid((M + 15) / 16, (M + 15) / 16);
         k_assemble_S<TB><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts,
-                                             planes_b ? e->d.Lexp : nullptr, planes_b ? e->d.Grow : nullptr);
+                                             planes_b ? e->d.Lexp : nullptr, planes_b && !sharded ? e->d.Grow : nullptr);
     }
-    const int n_bblocks = b_in_sweep ? n_pad / NB : 0; // row block k of B = inv(L) G rides in the launch of panel k
+    const int n_bblocks = b_in_sweep ? cb1 - cb0 : 0; // row block k of B = inv(L) G rides in the launch of panel k (sharded planes: own column blocks)
     hipEvent_t sw0 = nullptr, sw1 = nullptr;
     if (e->timing) { // the sweep's launches of this update, bracketed on the engine's stream (ekf_timing_sweep)
         (void)hipEventCreate(&sw0);
@@ -1337,7 +1358,19 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         g.n_split = g.tiles_i / 2; // k-depth of row tile i is ~(i+1) TM: halve the units of the longer half
         launch_xty(e, g, 1, sizeof(TB) == 4, s);
     }
-    {
+    if (planes_b && sharded) {
+        // every rank's column blocks of the digit planes to every rank: pack [column][plane][k group], row-block exchange, unpack;
+        // dx = B'z then comes from the planes (the fp64 rows of B exist only for the own columns)
+        const int m_k = round_up(m, 32), m16 = m_k / 16;
+        launch_planes_move(e, true, m_k, col_rb[e->shard_rank], col_rb[e->shard_rank + 1], 0, 0);
+        e->hook_rc = e->exchange_hook(e, EKF_XCHG_BPLANES, e->d.Bstage, (size_t)PX_S * m16 * 16, col_rb, "the digit planes of B");
+        if (e->hook_rc) return;
+        launch_planes_move(e, false, m_k, 0, n_pad, col_rb[e->shard_rank], col_rb[e->shard_rank + 1]);
+        launch_dx_planes(e, m_k);
+        const int nt = max(e->N * 6, 1);
+        k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
+                                                       e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
+    } else {
         dim3 grid((n + 255) / 256, DX_SPLIT);
         const bool fix = update_cov && sizeof(T) == 4 && !EXACT; // (the exact downdate needs no fp64 repair of the diagonal / camera rows)
         const int avg = e->p_exact_sym ? 0 : 1; // an AVG downdate only exists on an unsharded engine: every row is local

@@ -110,6 +110,7 @@ ABI = {
     "ekf_comm_unique_id": (_i, [_vp]),
     "ekf_comm_init": (_i, [_vp, _vp]),
     "ekf_shard_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "ekf_shard_counters": (_i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ekf_device_copy": (_i, [_vp, _vp, _vp, C.c_size_t]),
 }
 
@@ -234,6 +235,12 @@ class EkfEngine:
         r, w, lo, hi = _i(0), _i(1), _i(0), _i(0)
         self._chk(self.L.ekf_shard_info(self.h, C.byref(r), C.byref(w), C.byref(lo), C.byref(hi)))
         return r.value, w.value, lo.value, hi.value
+
+    def shard_counters(self):
+        """(bytes of digit planes received so far, first own column, one past the last own column) -- exact configuration"""
+        b, c0, c1 = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        self._chk(self.L.ekf_shard_counters(self.h, C.byref(b), C.byref(c0), C.byref(c1)))
+        return b.value, c0.value, c1.value
 
     def device_copy(self, dst, src, nbytes):
         self._chk(self.L.ekf_device_copy(self.h, _vp(dst), _vp(src), nbytes))

@@ -245,3 +245,88 @@ def test_n2000_four_ranks_against_the_oracle(eng_mod, oracle_lib, precision):
     assert not over_tolerance(be, F32_TOL, N, componentwise=precision == 2), be
     np.testing.assert_array_equal(P, P.T)
     grp.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_n2000_exact_ranks_two_frames_vs_oracle_and_model(eng_mod, oracle_lib, world):
+    """BASELINE configs[3] shape in the EKF_PRECISION_F32_EXACT configuration on 2 / 4 / 8 emulated ranks, two frames against the fp64
+    ORACLE: identical decisions, every block and every feature parameter within 1e-5, the assembled P bitwise symmetric across
+    ranks.  The second frame's updates (m = 1342 and 1568 rows) form B inside the sweep: every rank its OWN column blocks from int8
+    digit planes (the m^2 n of B = inv(L) H P divided by the ranks), then the planes travel -- the bytes a rank
+    receives and the columns it forms are asserted against the cost model of DESIGN.md section 8:
+    bytes = (n_pad - own columns) x 5 x round_up(m, 32) per update, own columns = its share of the state rows rounded to 32."""
+    from parity_metric import over_tolerance, parity_report
+
+    N, F = 2000, 2
+    seq = SyntheticSequence(N, F, width=1280, height=720)
+    grp, infos = _run_group(seq, world, 2, F)
+    o = oracle_lib.Oracle(seq.cam, seq.par, N + 8)
+    o.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, _sym(seq.P0))
+    for t in range(F):
+        oi = o.step(*seq.frames[t], ALGORITHMIC)
+        for r in range(world):
+            for f in INFO_FIELDS:
+                assert getattr(infos[r][t], f) == getattr(oi, f), (r, t, f)
+    x, fp, P = grp.get_state()
+    assert not np.isnan(P).any()
+    be = parity_report(x, fp, P, o.x13(), o.feature_pos(), o.P())
+    print(f"N=2000 exact, {world} emulated ranks, 2 frames vs oracle:", {k: f"{v:.2e}" for k, v in be.items()})
+    assert not over_tolerance(be, F32_TOL, N), be
+    np.testing.assert_array_equal(P, P.T)
+    # cost model: which updates formed B in the sweep (m_pad <= 2048), what each rank received, what it formed
+    n = 13 + 6 * N
+    n_pad = (n + 127) // 128 * 128
+    planes_rows = []
+    for t in range(F):
+        for M in (infos[0][t].n_inliers, infos[0][t].n_rescued):
+            if M > 0 and (2 * M + 31) // 32 * 32 <= 2048:
+                planes_rows.append((2 * M + 31) // 32 * 32)
+    assert planes_rows, "no update of these frames took the digit-plane path"
+    cols = []
+    for r, e in enumerate(grp.engines):
+        got, c0, c1 = e.shard_counters()
+        cols.append((c0, c1))
+        want = sum((n_pad - (c1 - c0)) * 5 * mk for mk in planes_rows)
+        assert got == want, (r, got, want)
+    assert cols[0][0] == 0 and cols[-1][1] == n_pad and all(cols[r][1] == cols[r + 1][0] for r in range(world - 1)), cols
+    share = [(c1 - c0) / n_pad for c0, c1 in cols]
+    print(f"  column shares of the rows of B: {[f'{s:.3f}' for s in share]}; planes received by rank 0: {grp.engines[0].shard_counters()[0] / 1e6:.1f} MB")
+    assert max(share) <= 1.0 / world + 0.02  # the B role's m^2 n is divided by the ranks
+    grp.close()
+
+
+def test_n5000_exact_eight_ranks_vs_committed_summary(eng_mod):
+    """BASELINE configs[4] shape (N = 5000, 1920x1080) on EIGHT emulated ranks in the exact configuration, one frame against the
+    committed oracle summary: identical decisions, every block of the state within 1e-5, camera block / diagonal / sample / trace /
+    Frobenius norm of the ASSEMBLED covariance within 1e-5 of max|P|, and the assembled P bitwise symmetric (each rank computed
+    both triangles of its rows with integer sums: swapping the operands changes no bit)."""
+    import os
+
+    from parity_metric import block_errs
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_n5000_f1_summary.npz")
+    if not os.path.exists(path):
+        pytest.skip("summary fixture not minted")
+    z = np.load(path)
+    N = int(z["n_features"])
+    seq = SyntheticSequence(N, 1, width=int(z["width"]), height=int(z["height"]))
+    grp, infos = _run_group(seq, 8, 2, 1)
+    i = infos[0][0]
+    assert [i.n_predicted, i.n_matches, i.n_hypotheses, i.n_inliers, i.n_outliers, i.n_rescued, i.status] == list(z["info"][0])
+    x, fp, P = grp.get_state()
+    grp.close()
+    assert not np.isnan(P).any()
+    be = block_errs(x, fp, z["x13"], z["feature_pos"])
+    maxabs, idx = float(z["maxabs"]), z["sample_idx"]
+    be["P13_max"] = float(np.abs(P[:13, :13] - z["P13"]).max() / maxabs)
+    be["P_sample_max"] = float(np.abs(P[np.ix_(idx, idx)] - z["sample"]).max() / maxabs)
+    be["P_diag_max"] = float(np.abs(np.diag(P) - z["diag"]).max() / maxabs)
+    be["trace"] = abs(float(np.trace(P)) - float(z["trace"])) / float(z["trace"])
+    be["fro"] = abs(float(np.linalg.norm(P)) - float(z["fro"])) / float(z["fro"])
+    print("N=5000 exact, 8 emulated ranks vs committed oracle summary:", {k: f"{v:.2e}" for k, v in be.items()})
+    assert not {k: v for k, v in be.items() if not v <= F32_TOL}, be
+    # symmetry, block row by block row (a full P == P.T would need a second 7 GB temporary)
+    n = P.shape[0]
+    for r0 in range(0, n, 2048):
+        r1 = min(n, r0 + 2048)
+        assert np.array_equal(P[r0:r1, :], P[:, r0:r1].T), (r0, r1)
