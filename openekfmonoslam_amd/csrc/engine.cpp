@@ -249,8 +249,8 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
             }
             if (world > 1) { // sharded: the diagonal table and the exchange image of the planes (rows of B up to B_SWEEP_MAX)
                 if ((st = dalloc(&d.Pdiag, (size_t)e->ldP)) != hipSuccess) return fail(st, "hipMalloc Pdiag");
-                const size_t rows = (size_t)round_up(std::min((int)mcap, B_SWEEP_MAX) + NB, 64);
-                if ((st = dalloc(&d.Bstage, (size_t)PX_S * rows * e->ldP)) != hipSuccess) return fail(st, "hipMalloc Bstage");
+                e->bstage_rows = e->bq_rows; // any update's rows of B
+                if ((st = dalloc(&d.Bstage, (size_t)PX_S * e->bstage_rows * e->ldP)) != hipSuccess) return fail(st, "hipMalloc Bstage");
             }
         }
         if ((st = dalloc(&raw, (size_t)(mcap + 1) * e->ldP * wb)) != hipSuccess) return fail(st, "hipMalloc G");

@@ -212,6 +212,7 @@ struct EkfEngine {
     int pu_per_xcd = 0;
     int bq_rows = 0;          // rows of B a digit plane holds (multiple of 64)
     int lq_nbk = 0;           // 32-row blocks per side of the digit planes of L
+    int bstage_rows = 0;      // rows of B the exchange image of the planes holds (sharded exact configuration)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> px_events; // exact downdate: brackets of the column-scale + digit-plane kernels
     int pu_slots = 0;         // resident workgroups of the downdate kernel on this device (0: not asked yet, -1: unknown)
     hipStream_t stream = nullptr;
@@ -255,6 +256,7 @@ struct XtyArgs {
     int row0_first, row0_stride, m_lim;   // rows of element b that exist: min(M, m_lim - (row0_first + b row0_stride))
     int tri;                              // 0: all k; 1: Y[k][j] = 0 for k < j; 2: X[k][i] = 0 for k > i
     int tiles_i, tiles_j;                 // row tiles / column tiles
+    int tj0;                              // first column tile (row-sharded engines form their own columns of B only)
     int n_split;                          // bottom row tiles cut into two half units (tri == 2, batch 1 only)
     double alpha;
 };
@@ -309,6 +311,7 @@ void launch_round_P_f32(EkfEngine *e);                        // kernels_map.hip
 void launch_diag_extract(EkfEngine *e, float *diag);          // kernels_pexact.hip: sharded exact configuration
 void launch_planes_move(EkfEngine *e, bool pack, int m_k, int c_lo, int c_hi, int skip_lo, int skip_hi);
 void launch_dx_planes(EkfEngine *e, int m_k);
+void launch_slice_columns(EkfEngine *e, int m, int c_lo, int c_hi);
 void launch_rescue(EkfEngine *e, int M);
 void launch_state_only_predict(EkfEngine *e, EkfPrediction *d_out); // predictMeasurementState on current state
 void launch_add_features(EkfEngine *e, const double *d_uv, int count, double *d_Jpo, double *d_Jhr);

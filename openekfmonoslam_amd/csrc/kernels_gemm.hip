@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256, BK * sizeof(T) >= 128 ? 2 : 3) k_xty(XtyA
         ti = a.tri == 2 ? a.tiles_i - 1 - a.n_split - t / a.tiles_j : a.n_split + t / a.tiles_j;
         tj = t % a.tiles_j;
     }
-    const int I0 = ti * TM, J0 = tj * TM;
+    const int I0 = ti * TM, J0 = (tj + a.tj0) * TM;
     // rows of this batch element that exist (the last pair of a level may be cut by m_pad)
     const int Mb = min(a.M, a.m_lim - (a.row0_first + b * a.row0_stride));
     if (I0 >= Mb) return;

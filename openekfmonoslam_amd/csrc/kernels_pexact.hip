@@ -68,9 +68,11 @@ k_col_exp(const double *B, int ld, int m, int n_pad, const double *Bc, int *bexp
 // per row), writes 16 bytes per plane at Bq[s][kb][column][0..15] (the wavefront writes 1 KB contiguous per plane).
 // Workgroup = 64 columns x 4 row groups; grid (n_pad / 64, m_k / 64).  Rows >= m are zero.
 __global__ void __launch_bounds__(256)
-k_slice_B(const double *B, int ld, int m, int m_k, const double *Bc, const int *bexp, int8_t *Bq, int ldq, size_t plane_stride)
+k_slice_B(const double *B, int ld, int m, int m_k, const double *Bc, const int *bexp, int8_t *Bq, int ldq, size_t plane_stride, int c_lo,
+          int c_hi)
 {
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int col = (c_lo / 64) * 64 + blockIdx.x * 64 + (threadIdx.x & 63);
+    if (col < c_lo || col >= c_hi) return; // (row-sharded engines cut their own columns only)
     const int kb = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (kb * 16 >= m_k) return;
     const bool cam = Bc && col < 13;
@@ -158,6 +160,15 @@ k_dx_planes(const int8_t *Bq, size_t b_stride, int ldq, int m16, int n, const in
         }
     }
     part[(size_t)ks * ldpart + j] = ldexp(sum, (bexp[j] - 1022) - (8 * PX_S - 2));
+}
+
+void launch_slice_columns(EkfEngine *e, int m, int c_lo, int c_hi)
+{
+    const int m_k = round_up(m, 32);
+    if (c_hi <= c_lo) return;
+    const int nb = (c_hi - (c_lo / 64) * 64 + 63) / 64;
+    k_slice_B<<<dim3(nb, (m_k + 63) / 64), 256, 0, e->stream>>>((const double *)e->d.A, e->ldP, m, m_k, nullptr, e->d.Bexp, e->d.Bq, e->ldP,
+                                                              (size_t)e->bq_rows * e->ldP, c_lo, c_hi);
 }
 
 void launch_diag_extract(EkfEngine *e, float *diag)
@@ -638,7 +649,7 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bo
         (void)hipMemsetAsync(e->d.Bexp, 0, sizeof(int) * (size_t)ld, s);
         k_col_exp<<<dim3((n_pad + 255) / 256, PX_KSPLIT), 256, 0, s>>>(B, ld, m, n_pad, Bc, e->d.Bexp);
     }
-    if (!planes_ready) k_slice_B<<<dim3(n_pad / 64, (m_k + 63) / 64), 256, 0, s>>>(B, ld, m, m_k, Bc, e->d.Bexp, e->d.Bq, ld, plane_stride);
+    if (!planes_ready) k_slice_B<<<dim3(n_pad / 64, (m_k + 63) / 64), 256, 0, s>>>(B, ld, m, m_k, Bc, e->d.Bexp, e->d.Bq, ld, plane_stride, 0, n_pad);
     const int nt = (n + 127) / 128;
     const bool rect = e->shard_world > 1;
     const int owned = e->rm.r1 - e->rm.r0;

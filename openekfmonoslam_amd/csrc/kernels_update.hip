@@ -1211,8 +1211,9 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     // exact configuration on one GPU, B in the sweep: its rows are formed from int8 digit planes (chol_bplanes.h), in single-panel
     // launches (the planes of L cover B_SWEEP_MAX rows; a sharded rank does not know the diagonal of the rows it does not own)
     const bool sharded = e->shard_world > 1;
-    const bool planes_b = EXACT && b_in_sweep && m_pad <= B_SWEEP_MAX && e->d.Lq != nullptr && update_cov &&
-                          (!sharded || (e->exchange_hook && e->d.Bstage && (int)e->shard_row_begin.size() == e->shard_world + 1));
+    const bool shard_cols = EXACT && sharded && update_cov && e->exchange_hook && e->d.Bstage && m_pad + NB <= e->bstage_rows &&
+                            (int)e->shard_row_begin.size() == e->shard_world + 1; // every rank forms its own columns of B
+    const bool planes_b = EXACT && b_in_sweep && m_pad <= B_SWEEP_MAX && e->d.Lq != nullptr && update_cov && (!sharded || shard_cols);
     BPlanes bp{};
     // sharded: this rank forms the column blocks [cb0, cb1) of B -- the blocks whose first column lies in its share of the state
     // rows (rank 0: from column 0) -- and receives the others' digit planes afterwards (the B role divided by the ranks)
@@ -1222,14 +1223,18 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         bp.Bq = e->d.Bq; bp.b_stride = (size_t)e->bq_rows * ld; bp.ldq = ld; bp.bexp = e->d.Bexp;
         bp.Lq = e->d.Lq; bp.nbk = e->lq_nbk; bp.l_stride = (size_t)e->lq_nbk * e->lq_nbk * 1024; bp.lexp = e->d.Lexp;
         bp.grow = sharded ? nullptr : e->d.Grow;
+    }
+    if (planes_b || shard_cols) {
         if (sharded) {
             const int W = e->shard_world;
             col_rb.assign(W + 1, 0);
             for (int r = 1; r < W; ++r) col_rb[r] = std::min(n_pad, round_up(e->shard_row_begin[r], NB));
             col_rb[W] = n_pad;
-            cb0 = col_rb[e->shard_rank] / NB;
-            cb1 = col_rb[e->shard_rank + 1] / NB;
-            bp.bcol0 = cb0;
+            if (planes_b) {
+                cb0 = col_rb[e->shard_rank] / NB;
+                cb1 = col_rb[e->shard_rank + 1] / NB;
+                bp.bcol0 = cb0;
+            }
             // the diagonal of P behind the a-priori column scales: every rank's own entries, then all of them
             launch_diag_extract(e, e->d.Pdiag);
             std::vector<int32_t> drb(e->shard_row_begin.begin(), e->shard_row_begin.end());
@@ -1245,7 +1250,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         k_gather<TB><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const TB *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
                                          e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc, EXACT ? e->d.Bexp : nullptr,
-                                         planes_b ? (sharded ? e->d.Pdiag : (const float *)e->d.P) : nullptr, sharded ? 0 : ld, n,
+                                         (planes_b || shard_cols) ? (sharded ? e->d.Pdiag : (const float *)e->d.P) : nullptr, sharded ? 0 : ld, n,
                                          planes_b && !sharded ? e->d.Grow : nullptr);
         if (planes_b && !sharded) G = (TB *)e->d.HP; // the consumers read H P through the row map
     }
@@ -1355,13 +1360,18 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         g.M = m_pad; g.N = n_pad; g.K = m_pad;
         g.row0_first = 0; g.row0_stride = 0; g.m_lim = m_pad;
         g.tri = 2; g.tiles_i = (m_pad + TM - 1) / TM; g.tiles_j = (n_pad + TM - 1) / TM; g.alpha = 1.0;
+        if (shard_cols) { // own columns only (tile-rounded outwards: a few columns of the neighbours are formed twice)
+            g.tj0 = col_rb[e->shard_rank] / TM;
+            g.tiles_j = (col_rb[e->shard_rank + 1] + TM - 1) / TM - g.tj0;
+        }
         g.n_split = g.tiles_i / 2; // k-depth of row tile i is ~(i+1) TM: halve the units of the longer half
         launch_xty(e, g, 1, sizeof(TB) == 4, s);
     }
-    if (planes_b && sharded) {
+    if (shard_cols) {
         // every rank's column blocks of the digit planes to every rank: pack [column][plane][k group], row-block exchange, unpack;
         // dx = B'z then comes from the planes (the fp64 rows of B exist only for the own columns)
         const int m_k = round_up(m, 32), m16 = m_k / 16;
+        if (!planes_b) launch_slice_columns(e, m, col_rb[e->shard_rank], col_rb[e->shard_rank + 1]); // B came out of the GEMM in fp64
         launch_planes_move(e, true, m_k, col_rb[e->shard_rank], col_rb[e->shard_rank + 1], 0, 0);
         e->hook_rc = e->exchange_hook(e, EKF_XCHG_BPLANES, e->d.Bstage, (size_t)PX_S * m16 * 16, col_rb, "the digit planes of B");
         if (e->hook_rc) return;
@@ -1386,7 +1396,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
 #define DX_LAUNCH(USEG) k_dx_partial<TB, USEG, T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, \
                                              fix ? e->d.sq_part : nullptr, fix ? e->d.cam_part : nullptr, Bc, (const T *)e->d.P, \
                                              e->rm, e->d.diag_save, fix ? e->d.cam_save : nullptr, avg, Gy, e->d.yvec, \
-                                             (EXACT && update_cov && !planes_b) ? e->d.Bexp : nullptr);
+                                             (EXACT && update_cov && !planes_b && !shard_cols) ? e->d.Bexp : nullptr);
         if (Gy) { DX_LAUNCH(true) } else { DX_LAUNCH(false) }
 #undef DX_LAUNCH
 
@@ -1396,7 +1406,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     }
     if (!update_cov) return;
     const bool fix_diag = sizeof(T) == 4 && !EXACT;
-    if (EXACT) launch_p_update_exact(e, m, false, true, planes_b); // (column scales: k_gather + k_dx_partial, or a-priori; planes: the sweep's)
+    if (EXACT) launch_p_update_exact(e, m, false, true, planes_b || shard_cols); // (column scales: k_gather + k_dx_partial, or a-priori; planes: the sweep's / the ranks')
     else launch_p_update(e, m_pad, m);
     if (fix_diag) {
         k_fix_normalize<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save,
