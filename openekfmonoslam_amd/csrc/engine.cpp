@@ -125,7 +125,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
                     d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.W, d.Wf, d.G, d.LL, d.LLf, d.Tbuf, d.gates, d.cell_resp, d.cell_xy,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.sq_part, d.diag_save, d.cam_part, d.cam_save, d.HPc, d.Gc, d.Bc, d.zvec, d.yvec,
-                    e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq, d.Bq, d.Bexp, d.Lq, d.Lexp, d.Grow, d.Pdiag, d.Bstage};
+                    e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq, d.Bq, d.Bexp, d.Lq, d.Lexp, d.Grow, d.Pdiag, d.Bstage, d.Wq, d.Gq, d.Wexp, d.Gexp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &kv : e->pu_tables)
@@ -246,6 +246,12 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
                 if ((st = dalloc(&d.Lq, (size_t)PX_S * e->lq_nbk * e->lq_nbk * 1024)) != hipSuccess) return fail(st, "hipMalloc Lq");
                 if ((st = dalloc(&d.Lexp, (size_t)mcap + 256)) != hipSuccess) return fail(st, "hipMalloc Lexp");
                 if ((st = dalloc(&d.Grow, (size_t)mcap + 256)) != hipSuccess) return fail(st, "hipMalloc Grow");
+            }
+            if ((int)mcap > B_SWEEP_MAX) { // B = inv(L) G on the int8 MFMA for updates above B_SWEEP_MAX rows: planes of inv(L)' and of G
+                if ((st = dalloc(&d.Wq, (size_t)PX_S * e->bq_rows * (round_up((int)mcap, 128) + 128))) != hipSuccess) return fail(st, "hipMalloc Wq");
+                if ((st = dalloc(&d.Gq, (size_t)PX_S * e->bq_rows * e->ldP)) != hipSuccess) return fail(st, "hipMalloc Gq");
+                if ((st = dalloc(&d.Wexp, (size_t)round_up((int)mcap, 128) + 128)) != hipSuccess) return fail(st, "hipMalloc Wexp");
+                if ((st = dalloc(&d.Gexp, (size_t)e->ldP)) != hipSuccess) return fail(st, "hipMalloc Gexp");
             }
             if (world > 1) { // sharded: the diagonal table and the exchange image of the planes (rows of B up to B_SWEEP_MAX)
                 if ((st = dalloc(&d.Pdiag, (size_t)e->ldP)) != hipSuccess) return fail(st, "hipMalloc Pdiag");

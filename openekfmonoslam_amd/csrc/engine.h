@@ -141,6 +141,8 @@ struct DeviceArrays {
     int8_t *Lq = nullptr;       // digit planes of L for the rows of B formed from planes (chol_bplanes.h): PX_S x lq_nbk^2 KB
     int *Lexp = nullptr;        // row scales of L (biased exponents)
     int *Grow = nullptr;        // row of the H P table behind every gathered row (k_gather without the copy)
+    int8_t *Wq = nullptr, *Gq = nullptr; // digit planes of inv(L)' and of G for B = inv(L) G on the int8 MFMA (updates above B_SWEEP_MAX rows)
+    int *Wexp = nullptr, *Gexp = nullptr; // their column scales
     float *Pdiag = nullptr;     // sharded exact configuration: diagonal of P, n floats, completed by an exchange
     int8_t *Bstage = nullptr;   // ... and the digit planes of B in the exchange layout [column][plane][k / 16][16]
 };
@@ -312,6 +314,7 @@ void launch_diag_extract(EkfEngine *e, float *diag);          // kernels_pexact.
 void launch_planes_move(EkfEngine *e, bool pack, int m_k, int c_lo, int c_hi, int skip_lo, int skip_hi);
 void launch_dx_planes(EkfEngine *e, int m_k);
 void launch_slice_columns(EkfEngine *e, int m, int c_lo, int c_hi);
+void launch_b_gemm_planes(EkfEngine *e, int m, int c_lo, int c_hi);
 void launch_rescue(EkfEngine *e, int M);
 void launch_state_only_predict(EkfEngine *e, EkfPrediction *d_out); // predictMeasurementState on current state
 void launch_add_features(EkfEngine *e, const double *d_uv, int count, double *d_Jpo, double *d_Jhr);

@@ -614,7 +614,168 @@ k_p_update_i8p(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__
 #undef PXP_ISSUE
 }
 
+
+// ------------------------------------------------------------------------------- B = inv(L) G as digit planes (m > 2048 rows)
+// Above B_SWEEP_MAX rows the sweep only factorises S; inv(L) is formed explicitly (k_inv_diag, k_triinv_level) and B = inv(L) G is
+// one GEMM.  In fp64 (k_xty<double>) that GEMM was the largest item of an N = 5000 update after the downdate (m^2 n flop at ~45
+// TFLOP/s: 13 ms at m = 8900).  Here it runs on the int8 MFMA with the machinery of the downdate: W = inv(L)' (k-major: row k =
+// all rows i of inv(L)) and G (k-major) are cut into digit planes with their columns' true scales (k_col_exp / k_slice_B: both are
+// complete before the GEMM), the products of level < PX_S are accumulated exactly, and the epilogue cuts B -- with the a-priori
+// column scale sqrt(P_jj), see chol_bplanes.h -- straight into the digit planes the downdate reads; B never exists in fp64
+// (dx = B'z comes from the planes, k_dx_planes).  Tile = 128 rows of B x 128 columns, same wavefront layout, ring and issue
+// scheme as k_p_update_i8p; the k-range of a row tile ends at its last row (inv(L) is lower triangular).
+__global__ void __launch_bounds__(512, 2)
+k_b_gemm_i8p(const int8_t *__restrict__ Wq, int ldw, size_t w_stride, const int *__restrict__ wexp, const int8_t *__restrict__ Gq, int ldq,
+             size_t g_stride, const int *__restrict__ gexp, int8_t *__restrict__ Bq, size_t b_stride, const int *__restrict__ bexp, int m,
+             int tiles_j, int tj0, int n_units_total)
+{
+    constexpr int TM = 128, MB = 32, SLAB = PX_S * 8192;
+    __shared__ __attribute__((aligned(16))) unsigned char ring[PX_RING * SLAB];
+    __shared__ __attribute__((aligned(16))) unsigned char sBy[8][PX_S][MB][16]; // per wavefront: digit bytes [plane][column][16 rows]
+    __shared__ int sExp[2][2 * TM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wv >> 2, wc = wv & 3;
+    const int kg = lane >> 5, idx = lane & 31;
+    // units: u = blockIdx.x, + gridDim.x, ...; unit u -> row tile (from the BOTTOM: the longest k-ranges first) and column tile
+    const int G_ = gridDim.x;
+    auto tile_of = [&](int u, int &ti, int &tj) {
+        ti = (m + TM - 1) / TM - 1 - u / tiles_j;
+        tj = tj0 + u % tiles_j;
+    };
+    auto steps_of = [&](int ti) { return min((ti + 1) * TM, ((m + 31) / 32 * 32)) / 32; }; // k < first row past the tile (multiples of 32)
+    int n_units = 0, total = 0;
+    for (int u = blockIdx.x; u < n_units_total; u += G_) {
+        int ti, tj;
+        tile_of(u, ti, tj);
+        total += steps_of(ti);
+        ++n_units;
+    }
+    if (n_units == 0) return;
+    const int pside = wv >> 2, pkg = (wv >> 1) & 1, phalf = wv & 1;
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const int poff = wv * 1024;
+    int iu = 0, it = 0, ig = 0, ink;
+    const int8_t *gsrc;
+    size_t sstride, pstride;
+    auto point = [&](int ui) {
+        int ti, tj;
+        tile_of(blockIdx.x + ui * G_, ti, tj);
+        ink = steps_of(ti);
+        if (pside) { gsrc = Gq + ((size_t)pkg * ldq + tj * TM + 64 * phalf + lane) * 16; sstride = (size_t)2 * ldq * 16; pstride = g_stride; }
+        else { gsrc = Wq + ((size_t)pkg * ldw + ti * TM + 64 * phalf + lane) * 16; sstride = (size_t)2 * ldw * 16; pstride = w_stride; }
+    };
+    point(0);
+#define BG_ISSUE()                                                                                                            \
+    if (ig < total) {                                                                                                         \
+        const int rb = (ig % PX_RING) * SLAB + poff;                                                                          \
+        _Pragma("unroll") for (int s = 0; s < PX_S; ++s)                                                                      \
+            __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + (size_t)s * pstride + (size_t)it * sstride),                     \
+                                             (lptr_t)(&ring[rb + s * 8192]), 16, 0, 0);                                       \
+        ++ig;                                                                                                                 \
+        if (++it == ink) {                                                                                                    \
+            it = 0;                                                                                                           \
+            if (++iu < n_units) point(iu);                                                                                    \
+        }                                                                                                                     \
+    }
+    BG_ISSUE()
+    BG_ISSUE()
+    int g = 0;
+    const unsigned ring_lds = (unsigned)(size_t)(lptr_t)&ring[0];
+    const bool late = wv >= 4;
+    for (int ui = 0; ui < n_units; ++ui) {
+        int ti, tj;
+        tile_of(blockIdx.x + ui * G_, ti, tj);
+        const int nk = steps_of(ti);
+        const int I0 = ti * TM, J0 = tj * TM;
+        const int rbase = wr * 2 * MB;
+        const int offA = (kg * TM + rbase + idx) * 16, offB = (kg * TM + wc * MB + idx) * 16;
+        if (tid < 2 * TM) { // scales of the tile's rows of W' (= rows of inv(L)) and of its columns of G, for the epilogue
+            const int c = tid < TM ? I0 + tid : J0 + tid - TM;
+            sExp[ui & 1][tid] = (tid < TM ? (c < m ? wexp[c] : 1022) : gexp[c]) - 1022;
+        }
+        v16i acc[2][PX_S];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int L = 0; L < PX_S; ++L)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][L][r] = 0;
+        for (int t = 0; t < nk; ++t, ++g) {
+            if (g + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PX_S) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!late) { BG_ISSUE() }
+            px_step_ring<true>(ring_lds + (g % PX_RING) * SLAB + offA, ring_lds + (g % PX_RING) * SLAB + offB, acc);
+            if (late) { BG_ISSUE() }
+        }
+        // epilogue: B_ij = 2^(e_i + e_j - 12) sum_L acc_L 256^-L, cut with the a-priori scale of column j into PX_S digit bytes, through
+        // the wavefront's byte image [plane][column][row] into the planes' 16-byte groups (16 consecutive rows of one column)
+        const int *se = sExp[ui & 1];
+        const int gj = J0 + wc * MB + idx;
+        const int ej = se[TM + wc * MB + idx];
+        const int shb = 8 * PX_S - 2 - (bexp[gj] - 1022);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { // rows 16 h .. 16 h + 15 of the block: the accumulator registers 8 h .. 8 h + 7
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = 8 * h + rr;
+                    const int li = (r & 3) + 8 * (r >> 2) + 4 * kg; // row of the block, 16 h <= li < 16 h + 16
+                    double tsum = (double)acc[x][PX_S - 1][r];
+#pragma unroll
+                    for (int L = PX_S - 2; L >= 0; --L) tsum = fma(tsum, 1.0 / 256.0, (double)acc[x][L][r]);
+                    const int gi = I0 + rbase + x * MB + li;
+                    const double v = gi < m ? ldexp(tsum, se[rbase + x * MB + li] + ej - 12) : 0.0;
+                    const unsigned long long dw = px_digit_word(v, shb);
+#pragma unroll
+                    for (int s = 0; s < PX_S; ++s) sBy[wv][s][idx][li - 16 * h] = (unsigned char)px_digit_byte(dw, s);
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+                __builtin_amdgcn_wave_barrier();
+                const size_t kb = (size_t)(I0 + rbase + x * MB) / 16 + h;
+                if (lane < 32 && (int)(kb * 16) < (m + 31) / 32 * 32) { // lane = column: its sixteen rows, one 16-byte group per plane
+#pragma unroll
+                    for (int s = 0; s < PX_S; ++s) {
+                        const uint4 q = *(const uint4 *)&sBy[wv][s][lane][0];
+                        *(uint4 *)(Bq + (size_t)s * b_stride + (kb * ldq + J0 + wc * MB + lane) * 16) = q;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+#undef BG_ISSUE
+}
 #endif
+
+// B = inv(L) G on the int8 MFMA, straight into the digit planes of B (columns [c_lo, c_hi), multiples of 128 rounded outwards).
+// W = inv(L)' in e->d.W (k-major, ldW), G in e->d.G (k-major fp64); e->d.Bexp holds the a-priori column scales of B.
+void launch_b_gemm_planes(EkfEngine *e, int m, int c_lo, int c_hi)
+{
+    hipStream_t s = e->stream;
+    const int m_k = round_up(m, 32), ld = e->ldP, ldw = e->ldW;
+    const int n_pad = round_up(e->n, LD_ALIGN);
+    const size_t g_stride = (size_t)e->bq_rows * ld, w_stride = (size_t)e->bq_rows * ldw;
+    const int mw_pad = round_up(m, 128); // columns of W' the row tiles read
+    // digit planes of W' (columns = rows of inv(L)) and of G, each with its columns' true scales
+    (void)hipMemsetAsync(e->d.Wexp, 0, sizeof(int) * (size_t)ldw, s);
+    k_col_exp<<<dim3((mw_pad + 255) / 256, PX_KSPLIT), 256, 0, s>>>(e->d.W, ldw, m, mw_pad, nullptr, e->d.Wexp);
+    k_slice_B<<<dim3(mw_pad / 64, (m_k + 63) / 64), 256, 0, s>>>(e->d.W, ldw, m, m_k, nullptr, e->d.Wexp, e->d.Wq, ldw, w_stride, 0, mw_pad);
+    const int tj0 = c_lo / 128, tiles_j = (std::min(c_hi, n_pad) + 127) / 128 - tj0;
+    const int g_lo = tj0 * 128, g_hi = (tj0 + tiles_j) * 128;
+    (void)hipMemsetAsync(e->d.Gexp, 0, sizeof(int) * (size_t)ld, s);
+    k_col_exp<<<dim3((n_pad + 255) / 256, PX_KSPLIT), 256, 0, s>>>((const double *)e->d.G, ld, m, n_pad, nullptr, e->d.Gexp);
+    k_slice_B<<<dim3((g_hi - g_lo) / 64, (m_k + 63) / 64), 256, 0, s>>>((const double *)e->d.G, ld, m, m_k, nullptr, e->d.Gexp, e->d.Gq, ld, g_stride,
+                                                                      g_lo, g_hi);
+    const int tiles_i = (m + 127) / 128;
+    const int n_units = tiles_i * tiles_j;
+    k_b_gemm_i8p<<<std::min(e->n_cus, n_units), 512, 0, s>>>(e->d.Wq, ldw, w_stride, e->d.Wexp, e->d.Gq, ld, g_stride, e->d.Gexp, e->d.Bq,
+                                                           (size_t)e->bq_rows * ld, e->d.Bexp, m, tiles_j, tj0, n_units);
+}
 
 // ------------------------------------------------------------------------------------------------ launcher
 void build_units(EkfEngine *e, int nt, int nrt, bool rect, int order); // kernels_pupdate.hip

@@ -1214,6 +1214,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     const bool shard_cols = EXACT && sharded && update_cov && e->exchange_hook && e->d.Bstage && m_pad + NB <= e->bstage_rows &&
                             (int)e->shard_row_begin.size() == e->shard_world + 1; // every rank forms its own columns of B
     const bool planes_b = EXACT && b_in_sweep && m_pad <= B_SWEEP_MAX && e->d.Lq != nullptr && update_cov && (!sharded || shard_cols);
+    const bool apriori = planes_b || shard_cols || (EXACT && !b_in_sweep && update_cov && e->d.Wq != nullptr); // column scales of B from diag(P)
     BPlanes bp{};
     // sharded: this rank forms the column blocks [cb0, cb1) of B -- the blocks whose first column lies in its share of the state
     // rows (rank 0: from column 0) -- and receives the others' digit planes afterwards (the B role divided by the ranks)
@@ -1250,7 +1251,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         k_gather<TB><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const TB *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
                                          e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc, EXACT ? e->d.Bexp : nullptr,
-                                         (planes_b || shard_cols) ? (sharded ? e->d.Pdiag : (const float *)e->d.P) : nullptr, sharded ? 0 : ld, n,
+                                         apriori ? (sharded ? e->d.Pdiag : (const float *)e->d.P) : nullptr, sharded ? 0 : ld, n,
                                          planes_b && !sharded ? e->d.Grow : nullptr);
         if (planes_b && !sharded) G = (TB *)e->d.HP; // the consumers read H P through the row map
     }
@@ -1351,7 +1352,12 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             k_triinv_level<<<npairs * tiles, 256, 0, s>>>(e->d.LL, ldS, m, m_pad, V, W, Wf, e->d.Tbuf, ldw, sz, 1);
         }
     }
-    if (!b_in_sweep) {   // B = inv(L) G = W' G : one GEMM, k <= row (W upper triangular)
+    // exact configuration above B_SWEEP_MAX rows: the GEMM on the int8 MFMA, straight into the digit planes of B (kernels_pexact.hip)
+    const bool gemm_planes = EXACT && !b_in_sweep && update_cov && e->d.Wq != nullptr && (!sharded || shard_cols);
+    if (gemm_planes) {
+        const int c_lo = shard_cols ? col_rb[e->shard_rank] : 0, c_hi = shard_cols ? col_rb[e->shard_rank + 1] : n_pad;
+        launch_b_gemm_planes(e, m, c_lo, c_hi);
+    } else if (!b_in_sweep) {   // B = inv(L) G = W' G : one GEMM, k <= row (W upper triangular)
         const int TM = sizeof(TB) == 4 ? 128 : 64;
         XtyArgs g{};
         g.X = sizeof(TB) == 4 ? (const void *)Wf : (const void *)W; g.ldx = ldw;
@@ -1371,12 +1377,17 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         // every rank's column blocks of the digit planes to every rank: pack [column][plane][k group], row-block exchange, unpack;
         // dx = B'z then comes from the planes (the fp64 rows of B exist only for the own columns)
         const int m_k = round_up(m, 32), m16 = m_k / 16;
-        if (!planes_b) launch_slice_columns(e, m, col_rb[e->shard_rank], col_rb[e->shard_rank + 1]); // B came out of the GEMM in fp64
+        if (!planes_b && !gemm_planes) launch_slice_columns(e, m, col_rb[e->shard_rank], col_rb[e->shard_rank + 1]); // B came out of the GEMM in fp64
         launch_planes_move(e, true, m_k, col_rb[e->shard_rank], col_rb[e->shard_rank + 1], 0, 0);
         e->hook_rc = e->exchange_hook(e, EKF_XCHG_BPLANES, e->d.Bstage, (size_t)PX_S * m16 * 16, col_rb, "the digit planes of B");
         if (e->hook_rc) return;
         launch_planes_move(e, false, m_k, 0, n_pad, col_rb[e->shard_rank], col_rb[e->shard_rank + 1]);
         launch_dx_planes(e, m_k);
+        const int nt = max(e->N * 6, 1);
+        k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
+                                                       e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
+    } else if (gemm_planes) { // B exists as digit planes only
+        launch_dx_planes(e, round_up(m, 32));
         const int nt = max(e->N * 6, 1);
         k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
                                                        e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
@@ -1396,7 +1407,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
 #define DX_LAUNCH(USEG) k_dx_partial<TB, USEG, T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, \
                                              fix ? e->d.sq_part : nullptr, fix ? e->d.cam_part : nullptr, Bc, (const T *)e->d.P, \
                                              e->rm, e->d.diag_save, fix ? e->d.cam_save : nullptr, avg, Gy, e->d.yvec, \
-                                             (EXACT && update_cov && !planes_b && !shard_cols) ? e->d.Bexp : nullptr);
+                                             (EXACT && update_cov && !apriori) ? e->d.Bexp : nullptr);
         if (Gy) { DX_LAUNCH(true) } else { DX_LAUNCH(false) }
 #undef DX_LAUNCH
 
@@ -1406,7 +1417,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     }
     if (!update_cov) return;
     const bool fix_diag = sizeof(T) == 4 && !EXACT;
-    if (EXACT) launch_p_update_exact(e, m, false, true, planes_b || shard_cols); // (column scales: k_gather + k_dx_partial, or a-priori; planes: the sweep's / the ranks')
+    if (EXACT) launch_p_update_exact(e, m, false, true, planes_b || shard_cols || gemm_planes); // (column scales: k_gather + k_dx_partial, or a-priori; planes: the sweep's / the GEMM's / the ranks')
     else launch_p_update(e, m_pad, m);
     if (fix_diag) {
         k_fix_normalize<T><<<(n + 255) / 256, 256, 0, s>>>((T *)e->d.P, ld, n, e->rm, e->d.diag_save, e->d.sq_part, e->d.cam_save,
