@@ -254,7 +254,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: n1000_f32x on one GPU (configs[2] in the parity-conforming EKF_PRECISION_F32_EXACT "
-                         "configuration; n1000_f32 = the fast fp32 MFMA configuration); n2000_f32 on 2 or 4 GPUs; n5000_f32 on 8 GPUs")
+                         "configuration; n1000_f32 = the fast fp32 MFMA configuration); n2000_f32x on 2 or 4 GPUs; n5000_f32x on 8 GPUs")
     ap.add_argument("--mode", default="auto", choices=["auto", "replicas", "sharded"],
                     help="G > 1: ONE filter row-sharded over the ranks (auto / sharded; SURVEY 8(e)) or G independent "
                          "replicas (replicas: what the path is at N <= 1000)")
@@ -277,6 +277,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-all-matched", action="store_true", help="skip the secondary all-matched update line (N = 1000)")
     ap.add_argument("--no-roofline-pass", action="store_true")
+    ap.add_argument("--no-fast-line", action="store_true",
+                    help="exact-configuration workloads: skip the secondary fast-fp32 line (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -292,7 +294,7 @@ def main():
     from openekfmonoslam_amd.synth import SyntheticSequence
 
     if args.workload is None:
-        args.workload = "n1000_f32x" if (world == 1 or args.mode == "replicas") else ("n5000_f32" if world >= 8 else "n2000_f32")
+        args.workload = "n1000_f32x" if (world == 1 or args.mode == "replicas") else ("n5000_f32x" if world >= 8 else "n2000_f32x")
     if args.mode == "auto":
         args.mode = "sharded" if world > 1 else "replicas"
     if args.transport is None:  # ranks that share one GPU (gloo, functional checks) cannot form an RCCL communicator
@@ -548,7 +550,7 @@ def main():
         out["single_gpu_same_workload"] = single_ref
     if world == 1 and not group and not ncc and args.workload.startswith("n1000") and not args.no_all_matched:
         out["all_matched"] = all_matched_line(eng, seq, dtype)
-    if exact and world == 1 and not group and not ncc:
+    if exact and world == 1 and not group and not ncc and not args.no_fast_line:
         # the fast fp32 MFMA configuration on the same frames, labelled: NOT the parity configuration (its component-wise figure
         # is reported by `--workload n1000_f32`, ungated)
         ef = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=1, device=local_rank)

@@ -1208,6 +1208,13 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     // longer than the factorisation it hides behind, and the explicit inverse + one big-tile GEMM is the better use of
     // the MFMA pipe.  e->b_path (ekf_set_update_path): 0 by size, 1 always in the sweep, 2 always by GEMM.
     const bool b_in_sweep = e->b_path == 1 || (e->b_path == 0 && m_pad <= B_SWEEP_MAX);
+    if (sizeof(TB) == 4 && b_in_sweep && m_pad > B_SWEEP_MAX) {
+        // fp32 forward substitution over more than 64 panels changes the filter's decisions (measured at N = 5000, DESIGN.md
+        // section 6): the size switch to inverse + GEMM is an accuracy boundary -- EKF_UPDATE_PATH_SWEEP is refused there
+        e->err = "EKF_UPDATE_PATH_SWEEP with more than 2048 measurement rows in the fp32 configuration";
+        e->hook_rc = EKF_ERR_INVALID_ARG;
+        return;
+    }
     // exact configuration on one GPU, B in the sweep: its rows are formed from int8 digit planes (chol_bplanes.h), in single-panel
     // launches (the planes of L cover B_SWEEP_MAX rows; a sharded rank does not know the diagonal of the rows it does not own)
     const bool sharded = e->shard_world > 1;

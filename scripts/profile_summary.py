@@ -1,4 +1,5 @@
 """Turns rocprofv3 rocpd databases (kernel trace / PMC passes) into the small text summaries kept under profiles/."""
+import os
 import sqlite3
 import sys
 
@@ -12,7 +13,10 @@ def kernel_stats(db_path, out_path, limit=40):
             f.write(f"\"{name}\",{calls},{total / 1e3:.2f},{avg:.2f},{pct:.2f}\n")
 
 
-def pmc(db_path, counter, like="%k_p_update%"):
+LIKE = os.environ.get("PMC_KERNEL_LIKE", "%k_p_update%")
+
+
+def pmc(db_path, counter, like=LIKE):
     cur = sqlite3.connect(db_path).cursor()
     rows = list(cur.execute(
         "select kernel_name, value, duration from counters_collection where counter_name=? and kernel_name like ? "
@@ -20,7 +24,7 @@ def pmc(db_path, counter, like="%k_p_update%"):
     return rows
 
 
-def pmc_sq(db_paths, out_path, like="%k_p_update%"):
+def pmc_sq(db_paths, out_path, like=LIKE):
     """SQ / GRBM counters of the downdate kernel from several single-purpose PMC passes: mean per launch, for all
     launches and for the longer / shorter half (the low- and high-innovation updates), plus the derived ratios."""
     import statistics as st
@@ -37,7 +41,7 @@ def pmc_sq(db_paths, out_path, like="%k_p_update%"):
             means[name] = (st.mean(x[0] for x in v), st.mean(x[0] for x in hi), st.mean(x[0] for x in lo),
                            st.mean(x[1] for x in hi) / 1e3, st.mean(x[1] for x in lo) / 1e3, len(v))
     with open(out_path, "w") as f:
-        f.write("# k_p_update, rocprofv3 --pmc (one pass per counter group, counters only); per launch means; 'long' = the longer half of\n")
+        f.write(f"# {like.strip('%')}, rocprofv3 --pmc (one pass per counter group, counters only); per launch means; 'long' = the longer half of\n")
         f.write("# the launches (low-innovation updates), 'short' = the shorter half (high-innovation updates)\n")
         f.write("counter,launches,mean,mean_long,mean_short,duration_long_us,duration_short_us\n")
         for name, (m, hi, lo, dh, dl, n) in means.items():

@@ -1,38 +1,40 @@
 #!/bin/bash
-# Everything profiles/ holds for a round, from the repo root on the GPU box: scripts/round_artifacts.sh <outdir>
+# Everything profiles/ holds for a round, from the repo root on the GPU box: scripts/round_artifacts.sh <outdir> [skip-tests]
+# (every profiler run sits under `timeout`; copy <outdir>/* to profiles/<round>_* afterwards: scripts/collect_profiles.sh)
 out=$(realpath -m "$1"); root=$(pwd); mkdir -p "$out"
-python -m pytest tests -m gpu -q > "$out/pytest_gpu.log" 2>&1
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$out/smoke.log" 2>&1
-python bench.py > "$out/bench_n1000_f32.json" 2> "$out/bench_n1000_f32.err"
-python bench.py --workload n200_f64 --steps 60 --warmup 10 > "$out/bench_n200_f64.json" 2> /dev/null
-python bench.py --workload n1000_f64 --steps 20 --warmup 5 > "$out/bench_n1000_f64.json" 2> /dev/null
-python bench.py --workload n2000_f32 --steps 20 --warmup 5 > "$out/bench_n2000_f32.json" 2> /dev/null
-python bench.py --workload n5000_f32 --steps 3 --warmup 1 > "$out/bench_n5000_f32.json" 2> /dev/null
-python bench.py --workload n5000_f64 --steps 3 --warmup 1 --no-cpu-baseline > "$out/bench_n5000_f64.json" 2> /dev/null
-python bench.py --matcher ncc --workload n2000_f32 --steps 20 --warmup 5 > "$out/bench_n2000_f32_ncc.json" 2> /dev/null
-scripts/micro/pu_bench 1000 298,1014,2000 15 > "$out/pu_bench.txt" 2>&1
+if [ -z "$2" ]; then
+  timeout 2900 python -m pytest tests -m gpu -q > "$out/pytest_gpu.log" 2>&1
+  tail -3 "$out/pytest_gpu.log"
+fi
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$out/smoke.log" 2>&1
+B="timeout 600 python bench.py"
+$B > "$out/bench_n1000_f32x.json" 2> "$out/bench_n1000_f32x.err"
+$B --workload n1000_f32 > "$out/bench_n1000_f32.json" 2> /dev/null
+$B --workload n200_f64 --steps 60 --warmup 10 > "$out/bench_n200_f64.json" 2> /dev/null
+$B --workload n2000_f32x --steps 20 --warmup 5 > "$out/bench_n2000_f32x.json" 2> /dev/null
+$B --workload n2000_f32 --steps 20 --warmup 5 > "$out/bench_n2000_f32.json" 2> /dev/null
+$B --workload n5000_f32x --steps 3 --warmup 1 > "$out/bench_n5000_f32x.json" 2> /dev/null
+$B --workload n5000_f32 --steps 3 --warmup 1 > "$out/bench_n5000_f32.json" 2> /dev/null
+$B --matcher ncc --workload n2000_f32x --steps 20 --warmup 5 > "$out/bench_n2000_f32x_ncc.json" 2> /dev/null
+$B --emulate-shards 4 --workload n2000_f32x --steps 6 --warmup 2 --no-cpu-baseline > "$out/bench_n2000_f32x_emulated4.json" 2> /dev/null
+# the downdate kernel alone: variants (0 persistent, 1 first version), bitwise check against the CPU, ablations when built
+for v in 0 1; do timeout 300 scripts/micro/pu_i8_bench 1000 298,1014,2000 15 $v; done > "$out/pu_i8_bench.txt" 2>&1
+for a in 1 3 7 11 15; do
+  [ -x scripts/micro/pu_i8_bench_abl$a ] && { echo "== PX_ABL=$a"; timeout 120 scripts/micro/pu_i8_bench_abl$a 1000 1014 15 0 | tail -3; }
+done >> "$out/pu_i8_bench.txt" 2>&1
 # per-role sweep traces: only when the debug build is there (scripts/build_trace_variant.sh)
 if [ -f variants/libekf_engine_trace.so ]; then
-  EKF_ENGINE_LIB=variants/libekf_engine_trace.so SWEEP_MODE=1 python scripts/sweep_trace.py 1000 15 2>/dev/null | grep -v amdgpu.ids > "$out/sweep_trace_n1000_f32.txt"
-  EKF_ENGINE_LIB=variants/libekf_engine_trace.so SWEEP_MODE=0 python scripts/sweep_trace.py 1000 15 2>/dev/null | grep -v amdgpu.ids > "$out/sweep_trace_pairs_n1000_f32.txt"
-  EKF_ENGINE_LIB=variants/libekf_engine_trace.so SWEEP_MODE=2 python scripts/sweep_trace.py 2000 6 2>/dev/null | grep -v amdgpu.ids > "$out/sweep_trace_n2000_f32.txt"
+  EKF_ENGINE_LIB=variants/libekf_engine_trace.so SWEEP_MODE=1 PRECISION=2 timeout 300 python scripts/sweep_trace.py 1000 15 2>/dev/null | grep -v amdgpu.ids > "$out/sweep_trace_n1000_f32x.txt"
+  EKF_ENGINE_LIB=variants/libekf_engine_trace.so SWEEP_MODE=1 PRECISION=1 timeout 300 python scripts/sweep_trace.py 1000 15 2>/dev/null | grep -v amdgpu.ids > "$out/sweep_trace_n1000_f32.txt"
+  EKF_ENGINE_LIB=variants/libekf_engine_trace.so SWEEP_MODE=1 PRECISION=2 timeout 300 python scripts/sweep_trace.py 2000 6 2>/dev/null | grep -v amdgpu.ids > "$out/sweep_trace_n2000_f32x.txt"
 fi
-EKF_ENGINE_LIB=variants/libekf_engine_trace.so python scripts/contention_probe.py 30 2>/dev/null | grep -v amdgpu.ids > "$out/contention_probe.txt"
-python scripts/diag_n5000_paths.py 0 1 2>/dev/null | grep -E "^path|^   " > "$out/n5000_three_frames_fp32.txt"
 bash scripts/profile_all.sh "$out/prof"
-for w in n1000_f32 n200_f64 n2000_f32 n5000_f32; do
-  db=$(find "$out/prof/$w" -name "*.db" | head -1)
-  [ -n "$db" ] && python3 scripts/profile_summary.py stats "$db" "$out/kernel_stats_$w.csv"
-  rm -rf "$out/prof/$w"
-done
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$out/prof/ncc" -- python3 "$root/bench.py" --matcher ncc --workload n2000_f32 --steps 12 --warmup 3 --no-cpu-baseline > /dev/null 2>&1 )
-db=$(find "$out/prof/ncc" -name "*.db" | head -1)
-[ -n "$db" ] && python3 scripts/profile_summary.py stats "$db" "$out/kernel_stats_n2000_f32_ncc.csv"
-rm -rf "$out/prof/ncc"
+mv "$out"/prof/kernel_stats_*.csv "$out"/ 2>/dev/null
 bash scripts/pmc_p_update.sh "$out/pmc"
 dbs=""
-for i in 1 2 3 4; do dbs="$dbs $(find $out/pmc/pass$i -name '*.db' | head -1)"; done
-python3 scripts/profile_summary.py pmc_sq "$out/pmc_sq_p_update_n1000_f32.csv" $dbs
-python3 scripts/profile_summary.py pmc "$(find $out/pmc/pass5 -name '*.db' | head -1)" "$(find $out/pmc/pass6 -name '*.db' | head -1)" "$out/pmc_hbm_p_update_n1000_f32.csv" 21
-rm -rf "$out/pmc"/pass*/ 
-tail -3 "$out/pytest_gpu.log"; tail -c 600 "$out/bench_n1000_f32.json"
+for i in 1 2 3 4 7; do d=$(find $out/pmc/pass$i -name '*.db' 2>/dev/null | head -1); [ -n "$d" ] && dbs="$dbs $d"; done
+export PMC_KERNEL_LIKE="%k_p_update_i8p%"
+python3 scripts/profile_summary.py pmc_sq "$out/pmc_sq_p_update_n1000_f32x.csv" $dbs
+python3 scripts/profile_summary.py pmc "$(find $out/pmc/pass5 -name '*.db' | head -1)" "$(find $out/pmc/pass6 -name '*.db' | head -1)" "$out/pmc_hbm_p_update_n1000_f32x.csv" 20
+rm -rf "$out"/pmc/pass*/
+tail -c 600 "$out/bench_n1000_f32x.json"

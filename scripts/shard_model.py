@@ -1,0 +1,74 @@
+"""Cost model of the row-sharded filter in the exact configuration, from the one-GPU measurements under
+profiles/: python scripts/shard_model.py [round-prefix, default r04]
+
+Inputs  : profiles/<r>_bench_n2000_f32x.json, <r>_bench_n5000_f32x.json (ms per frame, downdate launches, sweep time, panels),
+          profiles/<r>_kernel_stats_n5000_f32x.csv (the int8 GEMM and the triangular inverse, which only exist above 2048 rows).
+Model   : downdate x 2/G (a rank computes both triangles of its own rows); rows of B / G with the sweep bounded below by the
+          dependent chain (CHAIN_US per 32-row panel, the fast configuration's measured launch period); the GEMM / G; the inverse
+          and everything else replicated; per update a rank receives (G-1)/G of the rows of G (8 B per element) and of the five
+          digit planes of B (5 B per element) over G-1 xGMI links of LINK_GBS each, not overlapped with compute.
+No multi-GPU measurement exists on this pool: this is arithmetic on one-GPU measurements, not a scaling result."""
+import csv
+import json
+import os
+import sys
+
+CHAIN_US = 9.1    # us per panel of the dependent chain (k_chol_step with the rows-of-B role hidden; profiles/r04_bench_n1000_f32.json)
+LINK_GBS = 153.0  # one xGMI link, one direction (MI355X_MICROARCH.md)
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+
+
+def kernel_ms(path, needles, frames):
+    tot = 0.0
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            name = row.get("Name") or row.get("kernel")
+            if any(n in name for n in needles):
+                tot += float(row["TotalDurationNs"]) / 1e6 if "TotalDurationNs" in row else float(row["total_ms"])
+    return tot / frames
+
+
+def model(tag, d, n_state, gemm_ms, inv_ms, ranks):
+    t1 = d["ms_per_step"]
+    roof, sw = d["roofline"], d["roofline_sweep"]
+    steps = d["steps"]
+    down = roof["avg_launch_ms"] * roof["launches"] / steps
+    sweep = sw["ms_per_frame"]
+    panels = sw["panels_per_frame"]
+    b_in_sweep = sw["flops_rows_of_B"] > 0
+    rest = t1 - down - sweep - gemm_ms - inv_ms
+    rows_m = panels * 32.0  # sum of the (padded) rows of both updates of a frame
+    print(f"{tag}: one GPU {t1:.2f} ms/frame = downdate {down:.2f} + sweep {sweep:.2f} ({panels:.0f} panels) + inverse {inv_ms:.2f} "
+          f"+ GEMM {gemm_ms:.2f} + rest {rest:.2f}")
+    for g in ranks:
+        dg = down * 2.0 / g
+        chain = panels * CHAIN_US * 1e-3
+        sg = max(chain, sweep / g) if b_in_sweep else sweep
+        gg = gemm_ms / g
+        recv_g = rows_m * n_state * 8.0 * (g - 1) / g
+        recv_p = rows_m * n_state * 5.0 * (g - 1) / g
+        xt = (recv_g + recv_p) / ((g - 1) * LINK_GBS * 1e9) * 1e3
+        tg = dg + sg + inv_ms + gg + rest + xt
+        print(f"  G={g}: downdate {dg:.2f}  sweep {sg:.2f}  inverse {inv_ms:.2f}  GEMM {gg:.2f}  rest {rest:.2f}  "
+              f"received {recv_g / 1e6:.0f} + {recv_p / 1e6:.0f} MB -> {xt:.2f} ms  total {tg:.2f} ms  speed-up {t1 / tg:.2f}x")
+
+
+def main():
+    r = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    d2 = json.load(open(os.path.join(ROOT, f"{r}_bench_n2000_f32x.json")))
+    model("N=2000 (1280x720)", d2, 13 + 6 * 2000, 0.0, 0.0, (2, 4, 8))
+    d5 = json.load(open(os.path.join(ROOT, f"{r}_bench_n5000_f32x.json")))
+    ks = os.path.join(ROOT, f"{r}_kernel_stats_n5000_f32x.csv")
+    frames = 4  # scripts/profile_all.sh: 3 timed + 1 warm-up frame in that trace
+    gemm = kernel_ms(ks, ["k_b_gemm_i8p"], frames)
+    inv = kernel_ms(ks, ["k_inv_diag", "k_triinv_level"], frames)
+    if gemm is None:
+        print("(no kernel statistics for N=5000: GEMM and inverse counted in 'rest', i.e. as replicated)")
+        gemm, inv = 0.0, 0.0
+    model("N=5000 (1920x1080)", d5, 13 + 6 * 5000, gemm, inv, (4, 8))
+
+
+if __name__ == "__main__":
+    main()
