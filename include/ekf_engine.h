@@ -260,7 +260,8 @@ int ekf_timing_p_update_launches(EkfEngine *e, int capacity, int32_t *m_rows, fl
  * 0 for updates that went through the explicit inverse + GEMM).  Any output pointer may be null. */
 int ekf_timing_sweep(EkfEngine *e, double *kernel_ms, int64_t *panels, int64_t *updates, double *flops_fp64, double *flops_b);
 /* ... and the number of kernel launches behind those panels (a launch of the two-panels-per-launch scheme covers two), plus,
- * EKF_PRECISION_F32_EXACT only, the HIP-event time of the column-scale + digit-plane kernels that precede each exact downdate. */
+ * EKF_PRECISION_F32_EXACT only, the HIP-event time between the end of each update's sweep and the start of its downdate kernel
+ * (dx, the state update and, above 2048 rows, the triangular inverse and the int8 GEMM B = inv(L) G). */
 int ekf_timing_sweep_launches(EkfEngine *e, int64_t *launches, double *slice_ms);
 /* Measurement aid, EKF_PRECISION_F64 engines only: replaces every entry of the device-resident covariance by its nearest fp32
  * value, in place (asynchronous, on the engine's stream).  Called between the stage functions at the points where an

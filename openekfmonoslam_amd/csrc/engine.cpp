@@ -133,6 +133,7 @@ void ekf_engine_destroy(EkfEngine *e)
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &pr : e->px_events) (void)hipEventDestroy(pr.first);
+    if (e->px_mid) (void)hipEventDestroy(e->px_mid);
     for (auto &pr : e->pu_events) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);

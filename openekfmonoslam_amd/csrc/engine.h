@@ -215,7 +215,8 @@ struct EkfEngine {
     int bq_rows = 0;          // rows of B a digit plane holds (multiple of 64)
     int lq_nbk = 0;           // 32-row blocks per side of the digit planes of L
     int bstage_rows = 0;      // rows of B the exchange image of the planes holds (sharded exact configuration)
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> px_events; // exact downdate: brackets of the column-scale + digit-plane kernels
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> px_events; // exact configuration: end of the sweep -> start of the downdate (inverse, GEMM, digit planes, dx, state)
+    hipEvent_t px_mid = nullptr;                               // recorded after the sweep's last launch (timing only)
     int pu_slots = 0;         // resident workgroups of the downdate kernel on this device (0: not asked yet, -1: unknown)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // image-only work of the next frame, overlapped with the update
@@ -237,7 +238,7 @@ struct EkfEngine {
     std::vector<int> sw_launch;                                // launches of each bracket (pair launches cover two panels)
     double sweep_ms = 0.0, sweep_flops_f64 = 0.0, sweep_flops_b = 0.0; // harvested totals (ekf_timing_sweep)
     long long sweep_panels = 0, sweep_updates = 0, sweep_launches = 0;
-    double slice_ms = 0.0;                                     // exact downdate: column scales + digit planes (harvested)
+    double slice_ms = 0.0;                                     // exact configuration: sweep end -> downdate start (harvested)
     // host scratch
     std::vector<int> h_counts;
     int *h_mirror = nullptr, *d_mirror = nullptr; // GPU-writable host page: counters + sequence number (read_counts)

@@ -615,6 +615,313 @@ k_p_update_i8p(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__
 }
 
 
+// ------------------------------------------------------------------------ the downdate, four wavefronts with 64 x 64 each
+// (scripts/micro/pu_i8_bench.hip, variant 3, only: a MEASURED ALTERNATIVE that lost -- bit-identical results, 330 us against 259 us
+// at m = 1014, N = 1000; profiles/r04_pu_i8_bench.txt.  Kept out of the library.)
+// The idea: k_p_update_i8p reads 15 operands of 1 KB for 30 products per wavefront and step, eight wavefronts 120 KB per step --
+// 940 LDS cycles at 128 B/clk beside 960 MFMA cycles per wavefront, plus the 40 KB the LDS-DMA writes.  Here the workgroup is
+// FOUR wavefronts (one per SIMD, up to 512 registers each), wavefront (wr, wc) owns 64 x 64 = 2 x 2 MFMA blocks with five int32
+// accumulators each (320 registers): 20 operand reads for 60 products, 80 KB per step.  Same units, slabs, ring, scalar
+// descriptor loads and epilogue scheme as k_p_update_i8p; a wavefront fetches two 1 KB pieces per plane and step, one plane
+// ahead of every product group.  What the ablations say (same switches as PX_ABL): the product stream alone is SLOWER from one
+// wavefront per SIMD than from two (190 against 173 us), the LDS-DMA instructions cost 44 us where the second wavefront of
+// the SIMD hides 16 of them (28), and the epilogue -- nobody multiplies meanwhile -- 68 against 30 us.  The operand reads were
+// never the bound: 17-20 us in either kernel.
+#ifdef PX_BENCH
+#define PXQ_READ(dst, addr, off)                                                                                              \
+    do {                                                                                                                      \
+        if (PX_ABL & 8) asm volatile("" : "=v"(dst));                                                                         \
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));                                 \
+    } while (0)
+template <bool FULL, class ISSUE>
+__device__ __forceinline__ void px_step_q(unsigned ldsA, unsigned ldsB, v16i (&acc)[2][2][PX_S], ISSUE &&issue)
+{
+    v4i b00, b01, b10, b11, b20, b21, b30, b31, b40, b41, a[2][2];
+    PXQ_READ(b00, ldsB, 4096);
+    PXQ_READ(b01, ldsB, 4096 + 512);
+    PXQ_READ(a[0][0], ldsA, 0);
+    if (FULL) PXQ_READ(a[0][1], ldsA, 512);
+    PXQ_READ(b10, ldsB, 4096 + 8192);
+    PXQ_READ(b11, ldsB, 4096 + 8192 + 512);
+    PXQ_READ(b20, ldsB, 4096 + 2 * 8192);
+    PXQ_READ(b21, ldsB, 4096 + 2 * 8192 + 512);
+    PXQ_READ(b30, ldsB, 4096 + 3 * 8192);
+    PXQ_READ(b31, ldsB, 4096 + 3 * 8192 + 512);
+    PXQ_READ(b40, ldsB, 4096 + 4 * 8192);
+    PXQ_READ(b41, ldsB, 4096 + 4 * 8192 + 512);
+    PXQ_READ(a[1][0], ldsA, 8192);
+    if (FULL) PXQ_READ(a[1][1], ldsA, 8192 + 512);
+    // LDS operations complete in order: "at most k newer reads outstanding".  14 reads issued, the products of digit t of the
+    // first group need the first 4 + 2 t of them (half units: one read less in front and one less behind: the same counts)
+#define PXQ_WAIT(k, ...) asm volatile("s_waitcnt lgkmcnt(" #k ")" : __VA_ARGS__)
+    // The products are written out as instructions: with more than 256 registers per lane the compiler puts EVERY MFMA result into
+    // the accumulator file (256 registers) and, the 320 not fitting, copies accumulators to and fro in every step.  Here fifteen of
+    // the twenty accumulators are pinned to the accumulator file ("a") and the five of block (1, 1) to the vector file ("v"; the
+    // epilogue takes that block first, which frees its 80 registers for the rest).  An accumulator is written again four products later at the earliest, so no MFMA-after-MFMA hazard
+    // arises; the caller separates the last product from the epilogue's reads (s_nop).
+#define PXQ_MFMA(x_, c_, L_, av, bv)                                                                                          \
+    if constexpr ((x_) == 1 && (c_) == 1)                                                                                     \
+        asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc[x_][c_][L_]) : "v"(av), "v"(bv));                     \
+    else                                                                                                                      \
+        asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(acc[x_][c_][L_]) : "v"(av), "v"(bv));
+#define PXQ_PROD(s_, t_, cur, bt0, bt1)                                                                                       \
+    if constexpr ((s_) + (t_) < PX_S) {                                                                                       \
+        PXQ_MFMA(0, 0, (s_) + (t_), a[cur][0], bt0)                                                                           \
+        PXQ_MFMA(0, 1, (s_) + (t_), a[cur][0], bt1)                                                                           \
+        if constexpr (FULL) {                                                                                                 \
+            PXQ_MFMA(1, 0, (s_) + (t_), a[cur][1], bt0)                                                                       \
+            PXQ_MFMA(1, 1, (s_) + (t_), a[cur][1], bt1)                                                                       \
+        }                                                                                                                     \
+    }
+    issue(0);
+    if constexpr (FULL) {
+        PXQ_WAIT(10, "+v"(b00), "+v"(b01), "+v"(a[0][0]), "+v"(a[0][1]));
+    } else {
+        PXQ_WAIT(10, "+v"(b00), "+v"(b01), "+v"(a[0][0]));
+    }
+    PXQ_PROD(0, 0, 0, b00, b01)
+    PXQ_WAIT(8, "+v"(b10), "+v"(b11));
+    PXQ_PROD(0, 1, 0, b10, b11)
+    PXQ_WAIT(6, "+v"(b20), "+v"(b21));
+    PXQ_PROD(0, 2, 0, b20, b21)
+    PXQ_WAIT(4, "+v"(b30), "+v"(b31));
+    PXQ_PROD(0, 3, 0, b30, b31)
+    PXQ_WAIT(2, "+v"(b40), "+v"(b41));
+    PXQ_PROD(0, 4, 0, b40, b41)
+    // groups 1 .. 4: the I digits of group s + 1 are requested before the products of group s
+#define PXQ_GROUP(s_, cur, nxt)                                                                                               \
+    issue(s_);                                                                                                                \
+    if constexpr ((s_) + 1 < PX_S) {                                                                                          \
+        PXQ_READ(a[nxt][0], ldsA, ((s_) + 1) * 8192);                                                                         \
+        if constexpr (FULL) {                                                                                                 \
+            PXQ_READ(a[nxt][1], ldsA, ((s_) + 1) * 8192 + 512);                                                               \
+            PXQ_WAIT(2, "+v"(a[cur][0]), "+v"(a[cur][1]));                                                                    \
+        } else {                                                                                                              \
+            PXQ_WAIT(1, "+v"(a[cur][0]));                                                                                     \
+        }                                                                                                                     \
+    } else {                                                                                                                  \
+        if constexpr (FULL) { PXQ_WAIT(0, "+v"(a[cur][0]), "+v"(a[cur][1])); } else { PXQ_WAIT(0, "+v"(a[cur][0])); }         \
+    }                                                                                                                         \
+    PXQ_PROD(s_, 0, cur, b00, b01)                                                                                            \
+    PXQ_PROD(s_, 1, cur, b10, b11)                                                                                            \
+    PXQ_PROD(s_, 2, cur, b20, b21)                                                                                            \
+    PXQ_PROD(s_, 3, cur, b30, b31)
+    PXQ_GROUP(1, 1, 0)
+    PXQ_GROUP(2, 0, 1)
+    PXQ_GROUP(3, 1, 0)
+    PXQ_GROUP(4, 0, 1)
+#undef PXQ_GROUP
+#undef PXQ_PROD
+#undef PXQ_MFMA
+#undef PXQ_WAIT
+}
+
+template <bool RECT>
+__global__ void __launch_bounds__(256, 1)
+k_p_update_i8q(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq, int ldq, size_t plane_stride, int m_k,
+               const int *__restrict__ bexp, int per_xcd, const int4 *__restrict__ units, int slots, RowMap rm)
+{
+    constexpr int TM = 128, MB = 32, SLAB = PX_S * 8192;
+    constexpr int ST = MB + 4; // row stride of the epilogue's staging image: 16-byte aligned rows
+    __shared__ __attribute__((aligned(16))) unsigned char ring[PX_RING * SLAB];
+    __shared__ __attribute__((aligned(16))) float sTall[4 * MB * ST];
+    __shared__ int sExp[2][2 * TM];
+    __shared__ int sMeta[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wv >> 1, wc = wv & 1;
+    const int kg = lane >> 5, idx = lane & 31;
+    const int nk = m_k / 32;
+    const int4 *ul = units + (size_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    auto unit_at = [&](int k) -> int4 { // scalar load: a vector load would sit on the LDS-DMA's counter
+        v4i u;
+        const int4 *p = ul + (size_t)k * slots;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(u) : "s"(p) : "memory");
+        return make_int4(u[0], u[1], u[2], u[3]);
+    };
+    int n_units = 0;
+    for (int u = blockIdx.x >> 3; u < per_xcd; u += slots) {
+        if (unit_at(n_units).x < 0) break;
+        ++n_units;
+    }
+    if (n_units == 0) return;
+    if (tid == 0) {
+        sMeta[0] = ldp;
+        sMeta[1] = 0;
+    }
+    __syncthreads();
+    const int total = n_units * nk; // steps of the whole pipeline
+
+    // this wavefront's two pieces of every plane and step: wavefronts 0, 1 the I side (k-group 0, 1), 2, 3 the J side; piece h =
+    // columns 64 h .. + 63 of the side
+    const int pside = wv >> 1, pkg = wv & 1;
+    const size_t step_stride = (size_t)2 * ldq * 16;
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const int poff = wv * 2048;
+    int iu = 0, it = 0, ig = 0; // issue cursor: unit, step, global step
+    const int8_t *gsrc;
+    auto row0 = [&](int t) { return RECT ? (t == 0 ? 0 : rm.r0 + (t - 1) * TM) : t * TM; };
+    {
+        const int4 u0 = unit_at(0);
+        gsrc = Bq + ((size_t)pkg * ldq + (pside ? u0.y * TM : row0(u0.x)) + lane) * 16;
+    }
+    auto issue_plane = [&](int s) { // the two pieces of plane s of step ig; after the last plane the cursor moves on
+        if (ig < total) {
+            const int rb = (ig % PX_RING) * SLAB + poff + s * 8192;
+            const int8_t *src = gsrc + (size_t)s * plane_stride + (size_t)it * step_stride;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&ring[rb]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + 1024), (lptr_t)(&ring[rb + 1024]), 16, 0, 0);
+            if (s == PX_S - 1) {
+                ++ig;
+                if (++it == nk) {
+                    it = 0;
+                    ++iu;
+                    if (iu < n_units) {
+                        const int4 un = unit_at(iu);
+                        gsrc = Bq + ((size_t)pkg * ldq + (pside ? un.y * TM : row0(un.x)) + lane) * 16;
+                    }
+                }
+            }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < PX_S; ++s) issue_plane(s);
+#pragma unroll
+    for (int s = 0; s < PX_S; ++s) issue_plane(s);
+    int g = 0; // global step being multiplied
+    const unsigned ring_lds = (unsigned)(size_t)(lptr_t)&ring[0];
+    float *sT = sTall + wv * MB * ST;
+    for (int ui = 0; ui < n_units; ++ui) {
+        const int4 unit = unit_at(ui);
+        const int ti = __builtin_amdgcn_readfirstlane(unit.x), tj = __builtin_amdgcn_readfirstlane(unit.y);
+        const int uz = __builtin_amdgcn_readfirstlane(unit.z);
+        const bool full = uz < 0;
+        const bool diag = RECT || ti == tj;
+        const int I0 = row0(ti), J0 = tj * TM;
+        const int p_off = RECT ? (ti == 0 ? 0 : rm.base - rm.r0) : 0; // local minus global row
+        const int ilim = RECT ? (ti == 0 ? 13 : rm.r1) : n;
+        const int rbase = full ? wr * 2 * MB : uz * 2 * MB + wr * MB; // first tile row of the wavefront (64 or 32 rows)
+        const int offA = (kg * TM + rbase + idx) * 16, offB = (kg * TM + wc * 2 * MB + idx) * 16;
+        { // the tile's row and column scales, for the epilogue
+            const int c = (tid < TM ? I0 : J0 - TM) + tid;
+            sExp[ui & 1][tid] = c < n ? bexp[c] - 1022 : 0;
+        }
+        v16i acc[2][2][PX_S];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int L = 0; L < PX_S; ++L)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[x][c][L][r] = 0;
+#define PXQ_LOOP(FULL_)                                                                                                       \
+    for (int t = 0; t < nk; ++t, ++g) {                                                                                       \
+        /* step g has landed (this wavefront's pieces): everything but the 2 PX_S loads of step g + 1 is complete */          \
+        if (g + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PX_S) : "memory");                                    \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                 \
+        if (!(PX_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); /* everyone's have; everyone has left buffer g - 1 */ \
+        if (PX_ABL & 2) px_step_q<FULL_>(ring_lds + (g % PX_RING) * SLAB + offA, ring_lds + (g % PX_RING) * SLAB + offB, acc, [](int) {}); \
+        else px_step_q<FULL_>(ring_lds + (g % PX_RING) * SLAB + offA, ring_lds + (g % PX_RING) * SLAB + offB, acc, issue_plane); \
+    }
+        if (full) { PXQ_LOOP(true) } else { PXQ_LOOP(false) }
+#undef PXQ_LOOP
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // the last products' results, before the epilogue reads them
+        if (PX_ABL & 1) {
+            int h = 0;
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int L = 0; L < PX_S; ++L)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) h ^= acc[x][c][L][r];
+            if (h == 0x12345677) P[0] = 0.f;
+            continue;
+        }
+        // epilogue: as k_p_update_i8p, four blocks per wavefront
+        float *Pe = P;
+        const int lde = __builtin_amdgcn_readfirstlane(sMeta[0]); // = ldp, read back from LDS after the loop
+        float *sTe = sT + __builtin_amdgcn_readfirstlane(sMeta[1]); // + 0
+        const int *se = sExp[ui & 1];
+        float *pe = Pe + (size_t)(I0 + p_off + rbase) * lde + J0 + wc * 2 * MB;
+        const int le = 4 * kg * lde + idx;
+        float pv[2][2][16];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            if (x == 1 && !full) continue;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pv[x][c][r] = (pe + (x * MB + (r & 3) + 8 * (r >> 2)) * lde + c * MB)[le];
+        }
+        const int q8 = lane >> 3, q4 = lane & 7;
+        float *sTd = sTe + 4 * kg * ST + idx;  // + (row of the register) x ST: an immediate offset
+        float *sTt = sTe + idx * ST + 4 * kg;  // + (row of the register)
+        const float4 *sTq = reinterpret_cast<const float4 *>(sTe + q8 * ST + 4 * q4);
+        const int lq = q8 * lde + 4 * q4;
+#pragma unroll
+        for (int xi = 0; xi < 2; ++xi) {
+            const int x = 1 - xi; // block (1, 1) first: its accumulators sit in the vector file
+            if (x == 1 && !full) continue;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                const int c = 1 - ci;
+                const int bi = I0 + rbase + x * MB, bj = J0 + (wc * 2 + c) * MB;
+                const int ej = se[TM + (wc * 2 + c) * MB + idx];
+                float *pm = Pe + (size_t)bj * lde + I0 + rbase + x * MB; // the block's mirror image (never used when RECT)
+                float out[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int li = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    double tsum = (double)acc[x][c][PX_S - 1][r];
+#pragma unroll
+                    for (int L = PX_S - 2; L >= 0; --L) tsum = fma(tsum, 1.0 / 256.0, (double)acc[x][c][L][r]);
+                    const double v = ldexp(tsum, se[rbase + x * MB + li] + ej - 12);
+                    out[r] = (float)((double)pv[x][c][r] - v);
+                    sTd[((r & 3) + 8 * (r >> 2)) * ST] = out[r];
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const float4 v = sTq[i4 * 8 * ST / 4];
+                    const int gi = bi + 8 * i4 + q8, gj0 = bj + 4 * q4;
+                    float *dst = (pe + (x * MB + 8 * i4) * lde + c * MB) + lq;
+                    if (gi < ilim) {
+                        if (gj0 + 3 < n) *reinterpret_cast<float4 *>(dst) = v;
+                        else { // the ragged last column tile (n is not a multiple of 4): the padding stays untouched
+                            if (gj0 < n) dst[0] = v.x;
+                            if (gj0 + 1 < n) dst[1] = v.y;
+                            if (gj0 + 2 < n) dst[2] = v.z;
+                        }
+                    }
+                }
+                if (!diag) { // rows of an off-diagonal tile are all < n (its row range ends before its column range starts)
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sTt[(r & 3) + 8 * (r >> 2)] = out[r];
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        const float4 v = sTq[i4 * 8 * ST / 4];
+                        const int mj = bj + 8 * i4 + q8; // row of the mirror = column of the block
+                        if (mj < n) *reinterpret_cast<float4 *>((pm + 8 * i4 * lde) + lq) = v;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+#endif // PX_BENCH (k_p_update_i8q)
+
+
 // ------------------------------------------------------------------------------- B = inv(L) G as digit planes (m > 2048 rows)
 // Above B_SWEEP_MAX rows the sweep only factorises S; inv(L) is formed explicitly (k_inv_diag, k_triinv_level) and B = inv(L) G is
 // one GEMM.  In fp64 (k_xty<double>) that GEMM was the largest item of an N = 5000 update after the downdate (m^2 n flop at ~45
@@ -803,8 +1110,13 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bo
     if (e->timing) {
         (void)hipEventCreate(&e0);
         (void)hipEventCreate(&e1);
-        (void)hipEventCreate(&e2);
-        (void)hipEventRecord(e2, s);
+        if (e->px_mid) { // the update recorded the end of its sweep: the bracket covers everything up to the downdate
+            e2 = e->px_mid;
+            e->px_mid = nullptr;
+        } else {
+            (void)hipEventCreate(&e2);
+            (void)hipEventRecord(e2, s);
+        }
     }
     if (!exps_ready) {
         (void)hipMemsetAsync(e->d.Bexp, 0, sizeof(int) * (size_t)ld, s);
@@ -826,6 +1138,10 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bo
     if (!e->p_exact_sym && !rect) k_p_update_i8<true><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
     else if (g_px_variant == 1 || PX_S != 5) k_p_update_i8<false><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
 #if PX_S_VALUE == 5
+#ifdef PX_BENCH
+    else if (g_px_variant == 3 && rect) k_p_update_i8q<true><<<e->n_cus, 256, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
+    else if (g_px_variant == 3) k_p_update_i8q<false><<<e->n_cus, 256, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
+#endif
     else if (rect) k_p_update_i8p<true><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
     else k_p_update_i8p<false><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
 #endif
@@ -842,7 +1158,7 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bo
         e->pu_events.emplace_back(e0, e1);
         e->pu_work.push_back(rect ? (double)(owned + 13) * (double)n * (double)m * 2.0 : (double)n * (double)n * (double)m);
         e->pu_m.push_back(m);
-        e->px_events.emplace_back(e2, e0); // the two slicing kernels
+        e->px_events.emplace_back(e2, e0); // sweep end (or this call's start) -> downdate start
     }
     e->p_exact_sym = true;
 }

@@ -1341,6 +1341,11 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     if (e->timing) {
         (void)hipEventRecord(sw1, s);
         e->sw_events.emplace_back(sw0, sw1);
+        if (EXACT && update_cov) { // -> launch_p_update_exact: the bracket "sweep end .. downdate start"
+            if (e->px_mid) (void)hipEventDestroy(e->px_mid); // (an update that failed between the two left it behind)
+            e->px_mid = nullptr;
+            if (hipEventCreate(&e->px_mid) == hipSuccess) (void)hipEventRecord(e->px_mid, s);
+        }
         e->sw_m.push_back(b_in_sweep ? m : -m); // negative: the rows of B were not formed in these launches
         e->sw_launch.push_back(n_sweep_launches);
     }

@@ -41,7 +41,7 @@ int main(int argc, char **argv)
     }
     const int rounds = argc > 3 ? atoi(argv[3]) : 7;
     const int variant = argc > 4 ? atoi(argv[4]) : 0; // 0 persistent kernel; 1 one workgroup per unit; 2 the AVG instance (first update after an upload)
-    g_px_variant = variant == 1 ? 1 : 0;
+    g_px_variant = (variant == 1 || variant == 3) ? variant : 0; // 3: four wavefronts with 64 x 64 each (k_p_update_i8q)
     const int n = 13 + 6 * N, ld = round_up(n, LD_ALIGN);
     int m_max = 0;
     for (int m : ms) m_max = std::max(m_max, m);
@@ -182,6 +182,23 @@ int main(int argc, char **argv)
                "max |v - fp64 B'B| %.3e (max |B'B| %.3e); max |P_new - fp64 result|: exact path %.3e, fp32 MFMA kernel %.3e\n",
                m, n, n_chk - n_bad, n_chk, asym, max_err64, max_ref, max_e32_new, max_e32_old);
         if (n_bad || asym) rc = 1;
+        if (variant == 3) { // the whole matrix against the eight-wavefront kernel's bits
+            const int keep = g_px_variant;
+            g_px_variant = 0;
+            hipMemcpy(dP, dP0, hP.size() * 4, hipMemcpyDeviceToDevice);
+            e.d.A = dB;
+            launch_p_update_exact(&e, m, false);
+            hipStreamSynchronize(e.stream);
+            g_px_variant = keep;
+            std::vector<float> ref(hP.size());
+            hipMemcpy(ref.data(), dP, ref.size() * 4, hipMemcpyDeviceToHost);
+            long long diff = 0;
+            for (int i = 0; i < n; ++i)
+                if (memcmp(&ref[(size_t)i * ld], &out[(size_t)i * ld], 4 * (size_t)n) != 0)
+                    for (int j = 0; j < n; ++j) diff += memcmp(&ref[(size_t)i * ld + j], &out[(size_t)i * ld + j], 4) != 0;
+            printf("m=%d: entries that differ from k_p_update_i8p's: %lld of %lld\n", m, diff, (long long)n * n);
+            if (diff) rc = 1;
+        }
         for (auto &pr : e.pu_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
         for (auto &pr : e.px_events) { hipEventDestroy(pr.first); }
         e.pu_events.clear(); e.px_events.clear(); e.pu_work.clear(); e.pu_m.clear();

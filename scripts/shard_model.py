@@ -1,8 +1,10 @@
 """Cost model of the row-sharded filter in the exact configuration, from the one-GPU measurements under
 profiles/: python scripts/shard_model.py [round-prefix, default r04]
 
-Inputs  : profiles/<r>_bench_n2000_f32x.json, <r>_bench_n5000_f32x.json (ms per frame, downdate launches, sweep time, panels),
-          profiles/<r>_kernel_stats_n5000_f32x.csv (the int8 GEMM and the triangular inverse, which only exist above 2048 rows).
+Inputs  : profiles/<r>_bench_n2000_f32x.json, <r>_bench_n5000_f32x.json (ms per frame, downdate launches, sweep time, panels, and
+          the time between the end of a sweep and the start of its downdate = dx, state update, triangular inverse, int8 GEMM);
+          profiles/<r>_kernel_stats_n5000_f32x.csv only for the RATIO GEMM : inverse inside that interval (the trace includes the
+          first frame twice, so its totals are not per-frame figures of the timed frames).
 Model   : downdate x 2/G (a rank computes both triangles of its own rows); rows of B / G with the sweep bounded below by the
           dependent chain (CHAIN_US per 32-row panel, the fast configuration's measured launch period); the GEMM / G; the inverse
           and everything else replicated; per update a rank receives (G-1)/G of the rows of G (8 B per element) and of the five
@@ -30,7 +32,7 @@ def kernel_ms(path, needles, frames):
     return tot / frames
 
 
-def model(tag, d, n_state, gemm_ms, inv_ms, ranks):
+def model(tag, d, n_state, gemm_share, ranks):
     t1 = d["ms_per_step"]
     roof, sw = d["roofline"], d["roofline_sweep"]
     steps = d["steps"]
@@ -38,6 +40,9 @@ def model(tag, d, n_state, gemm_ms, inv_ms, ranks):
     sweep = sw["ms_per_frame"]
     panels = sw["panels_per_frame"]
     b_in_sweep = sw["flops_rows_of_B"] > 0
+    post = sw.get("sweep_end_to_downdate_ms_per_frame", 0.0)
+    gemm_ms = post * gemm_share if not b_in_sweep else 0.0              # / G
+    inv_ms = post * (1.0 - gemm_share) if not b_in_sweep else 0.0       # replicated (with dx and the state update)
     rest = t1 - down - sweep - gemm_ms - inv_ms
     rows_m = panels * 32.0  # sum of the (padded) rows of both updates of a frame
     print(f"{tag}: one GPU {t1:.2f} ms/frame = downdate {down:.2f} + sweep {sweep:.2f} ({panels:.0f} panels) + inverse {inv_ms:.2f} "
@@ -58,16 +63,14 @@ def model(tag, d, n_state, gemm_ms, inv_ms, ranks):
 def main():
     r = sys.argv[1] if len(sys.argv) > 1 else "r04"
     d2 = json.load(open(os.path.join(ROOT, f"{r}_bench_n2000_f32x.json")))
-    model("N=2000 (1280x720)", d2, 13 + 6 * 2000, 0.0, 0.0, (2, 4, 8))
+    model("N=2000 (1280x720)", d2, 13 + 6 * 2000, 0.0, (2, 4, 8))
     d5 = json.load(open(os.path.join(ROOT, f"{r}_bench_n5000_f32x.json")))
     ks = os.path.join(ROOT, f"{r}_kernel_stats_n5000_f32x.csv")
-    frames = 4  # scripts/profile_all.sh: 3 timed + 1 warm-up frame in that trace
-    gemm = kernel_ms(ks, ["k_b_gemm_i8p"], frames)
-    inv = kernel_ms(ks, ["k_inv_diag", "k_triinv_level"], frames)
-    if gemm is None:
-        print("(no kernel statistics for N=5000: GEMM and inverse counted in 'rest', i.e. as replicated)")
-        gemm, inv = 0.0, 0.0
-    model("N=5000 (1920x1080)", d5, 13 + 6 * 5000, gemm, inv, (4, 8))
+    gemm = kernel_ms(ks, ["k_b_gemm_i8p", "k_slice_B", "k_col_exp"], 1)
+    inv = kernel_ms(ks, ["k_inv_diag", "k_triinv_level", "k_dx_planes", "k_state_apply"], 1)
+    share = gemm / (gemm + inv) if gemm else 0.68
+    print(f"(N=5000: GEMM + its digit planes = {share:.2f} of the interval between sweep and downdate, by the kernel trace)")
+    model("N=5000 (1920x1080)", d5, 13 + 6 * 5000, share, (4, 8))
 
 
 if __name__ == "__main__":
