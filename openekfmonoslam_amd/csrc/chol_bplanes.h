@@ -38,6 +38,7 @@ struct BPlanes {
     const int *lexp = nullptr; // biased exponent of the row scale of L
     const int *grow = nullptr; // row of the H P table behind every row of G (-1: a zero row), see k_gather; null: G is a copy
     int bcol0 = 0;             // first column block of this rank (row-sharded engines form their own blocks only)
+    int no_fp64 = 0;           // the rows of B are not stored in fp64 (dx = B'z comes from the planes, k_dx_planes)
 };
 
 // Digit planes of TWO 32 x 32 blocks of L (rows i0a.. and i0b.., columns k0 .. k0 + kb - 1, in LDS; n_blk = 1: the first
@@ -174,7 +175,7 @@ __device__ __forceinline__ void b_rows_planes(const BPlanes &bp, const double *G
         const acc4_t o = quad_prod<false>(acc4_t{0, 0, 0, 0}, sLi, sR, bi, bj, lr, lk);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            Bout[(size_t)(k0 + 16 * bi + lk + 4 * q) * ld + c0 + 16 * bj + lr] = o[q];
+            if (!bp.no_fp64) Bout[(size_t)(k0 + 16 * bi + lk + 4 * q) * ld + c0 + 16 * bj + lr] = o[q];
             sO[16 * bi + lk + 4 * q][16 * bj + lr] = o[q];
         }
     }

@@ -1231,6 +1231,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         bp.Bq = e->d.Bq; bp.b_stride = (size_t)e->bq_rows * ld; bp.ldq = ld; bp.bexp = e->d.Bexp;
         bp.Lq = e->d.Lq; bp.nbk = e->lq_nbk; bp.l_stride = (size_t)e->lq_nbk * e->lq_nbk * 1024; bp.lexp = e->d.Lexp;
         bp.grow = sharded ? nullptr : e->d.Grow;
+        bp.no_fp64 = 1; // dx = B'z from the planes: the fp64 rows of B (8 bytes per element written, then read by k_dx_partial) never exist
     }
     if (planes_b || shard_cols) {
         if (sharded) {
@@ -1398,7 +1399,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const int nt = max(e->N * 6, 1);
         k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
                                                        e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
-    } else if (gemm_planes) { // B exists as digit planes only
+    } else if (gemm_planes || planes_b) { // B exists as digit planes only
         launch_dx_planes(e, round_up(m, 32));
         const int nt = max(e->N * 6, 1);
         k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
