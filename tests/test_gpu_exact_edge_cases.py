@@ -1,0 +1,208 @@
+"""Edge cases of the path in the EKF_PRECISION_F32_EXACT configuration (fp32 storage of P, fp64 B from int8 digit planes, exact
+int8 downdate -- the configuration bench.py headlines), HIP engine through the C ABI vs the fp64 oracle: update sizes that
+straddle every blocking boundary (32-row panels, 16-row digit groups, the 128-wide tiles of the downdate) on both ways of
+forming B, empty and ragged inputs, a frame of outliers, mixed XYZ / inverse-depth maps (columns of three and of six per
+feature), map management between frames, an indefinite innovation covariance, a long run, and two engines on two streams.
+One tolerance: every block AND every feature parameter within 1e-5 (parity_metric.over_tolerance)."""
+import threading
+
+import numpy as np
+import pytest
+
+from openekfmonoslam_amd.ekftypes import KEYPOINT_DTYPE, MATCH_DTYPE
+from openekfmonoslam_amd.synth import SyntheticSequence
+from parity_metric import F32_TOL, over_tolerance, parity_report
+from tests.oracle_lib import ALGORITHMIC, align_to_matches
+from tests.test_gpu_edge_cases import INFO, _matches_from_predictions, _same_info  # noqa: F401
+from tests.test_gpu_parity import eng_mod, make_pair  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+EXACT = 2
+
+
+def assert_parity(e, o, what, n_features=0):
+    x, fp, P = e.get_state()
+    be = parity_report(x, fp, P, o.x13(), o.feature_pos(), o.P())
+    bad = over_tolerance(be, F32_TOL, n_features, componentwise=True)
+    assert not bad, (what, bad)
+    # the exact downdate leaves P bitwise symmetric
+    assert np.array_equal(P, P.T), what
+    return be
+
+
+@pytest.mark.parametrize("path", [pytest.param(1, id="sweep"), pytest.param(2, id="gemm")])
+@pytest.mark.parametrize("M", [1, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 160])
+def test_update_sizes_across_block_boundaries_exact(eng_mod, oracle_lib, M, path):
+    """m = 2M rows of S, 2 .. 320: below / at / above a 16-row digit group, a 32-row panel, a 128-column tile; rows of B
+    inside the sweep (from digit planes) or by inverse + GEMM"""
+    seq = SyntheticSequence(170, 1, outlier_fraction=0.0, distractors_per_feature=0.0, max_bit_flips=0)
+    e, o = make_pair(eng_mod, oracle_lib, seq, precision=EXACT)
+    e.set_update_path(path)
+    e.predict()
+    o.predict()
+    e.predict_measurements()
+    preds, Hs, Hf = o.predict_measurements()
+    mo = _matches_from_predictions(preds, M)
+    mp, mHs, mHf = align_to_matches(preds, Hs, Hf, mo)
+    assert o.update(mo, mp, mHs, mHf, ALGORITHMIC) == 0
+    e.update(mo)
+    assert_parity(e, o, f"update with M = {M}", 170)
+
+
+@pytest.mark.parametrize("mode", [pytest.param(0, id="pairs"), pytest.param(1, id="single")])
+def test_sweep_modes_exact(eng_mod, oracle_lib, mode):
+    """ekf_set_sweep_mode in the exact configuration (the rows of B from digit planes exist for one panel per launch: a
+    request for pairs must still give the right answer)"""
+    seq = SyntheticSequence(170, 2, outlier_fraction=0.0, distractors_per_feature=0.0, max_bit_flips=0)
+    e, o = make_pair(eng_mod, oracle_lib, seq, precision=EXACT)
+    e.set_sweep_mode(mode)
+    for t in range(2):
+        gi = e.step(*seq.frames[t])
+        oi = o.step(*seq.frames[t], ALGORITHMIC)
+        _same_info(gi, oi, f"frame {t}")
+    assert_parity(e, o, f"sweep mode {mode}", 170)
+
+
+def test_ragged_inputs_exact(eng_mod, oracle_lib, seq12):
+    """no keypoints, then a normal frame; camera turned away; a frame in which every keypoint is displaced"""
+    e, o = make_pair(eng_mod, oracle_lib, seq12, precision=EXACT)
+    kps = np.zeros(0, dtype=KEYPOINT_DTYPE)
+    desc = np.zeros((0, 32), dtype=np.uint8)
+    _same_info(e.step(kps, desc), o.step(kps, desc, ALGORITHMIC), "empty frame")
+    assert_parity(e, o, "empty frame (prediction only)", 12)
+    _same_info(e.step(*seq12.frames[1]), o.step(*seq12.frames[1], ALGORITHMIC), "frame after the empty one")
+    assert_parity(e, o, "frame after the empty one", 12)
+    # every keypoint displaced: one-point hypothesis, re-prediction / rescue path
+    e, o = make_pair(eng_mod, oracle_lib, seq12, precision=EXACT)
+    kps, desc = seq12.frames[0]
+    bad = kps.copy()
+    rng = np.random.default_rng(9)
+    bad["x"] += rng.uniform(-6, 6, len(bad)).astype(np.float32)
+    bad["y"] += rng.uniform(-6, 6, len(bad)).astype(np.float32)
+    _same_info(e.step(bad, desc), o.step(bad, desc, ALGORITHMIC), "scattered keypoints")
+    assert_parity(e, o, "scattered keypoints", 12)
+    # nothing visible
+    e, o = make_pair(eng_mod, oracle_lib, seq12, precision=EXACT)
+    x = np.array(seq12.x13)
+    x[3:7] = [0.0, 0.0, 1.0, 0.0]
+    for f in (e, o):
+        f.set_state(x, seq12.feature_pos, seq12.feature_type, seq12.feature_desc, seq12.P0)
+    gi = e.step(*seq12.frames[0])
+    _same_info(gi, o.step(*seq12.frames[0], ALGORITHMIC), "nothing visible")
+    assert gi.n_predicted == 0
+    assert_parity(e, o, "nothing visible", 12)
+
+
+def test_empty_map_exact(eng_mod, oracle_lib, seq12):
+    """N = 0: the 13-state filter alone, then features added by the engine's own map management and two more frames"""
+    e = eng_mod.EkfEngine(seq12.cam, seq12.par, 16, precision=EXACT)
+    o = oracle_lib.Oracle(seq12.cam, seq12.par, 16)
+    e.reset()
+    o.reset()
+    for t in range(2):
+        _same_info(e.step(*seq12.frames[t]), o.step(*seq12.frames[t], ALGORITHMIC), f"empty map, frame {t}")
+    assert e.n == 13
+    assert_parity(e, o, "empty map")
+
+
+def test_mixed_depth_and_inverse_depth_map_exact(eng_mod, oracle_lib):
+    """columns of three (XYZ) and of six (inverse depth) per feature in one map: one conversion per frame after the updates
+    (EKF.cpp:594, threshold raised so that every call converts the first remaining inverse-depth feature), then the next
+    step; the digit planes, their a-priori column scales and the tiles of the downdate must not care where a feature's
+    columns start.  Three frames: converting features that are NOT linear yet is an ill-conditioned stress (the fp64 engine
+    itself agrees with the oracle to 1e-8 instead of 1e-12 on it, tests/test_gpu_map_management.py) that multiplies any
+    rounding of P by 3-10 per frame -- the fp32-storage floor (scripts/dbg_mixed_map.py) is 1e-8, 4e-8, 3e-6 on these three
+    frames, the exact configuration 2e-8, 1e-7, 6e-6, and both leave 1e-5 two frames later."""
+    seq = SyntheticSequence(50, 3)
+    seq.par.inverseDepthLinearityIndexThreshold = 1e9
+    e, o = make_pair(eng_mod, oracle_lib, seq, precision=EXACT)
+    for t, (kps, desc) in enumerate(seq.frames):
+        _same_info(e.step(kps, desc), o.step(kps, desc, ALGORITHMIC), f"frame {t}")
+        assert e.convert_inverse_depth_to_depth() == o.convert_inverse_depth_to_depth() == t
+        be = assert_parity(e, o, f"mixed map, frame {t}", 50)
+        print(f"mixed map frame {t}:", {k: f"{v:.1e}" for k, v in be.items()})
+    assert e.n == 313 - 3 * 3
+    # removeBadMapFeatures (MapManagement.cpp:279): same features go on both sides (the removal takes the largest entries of P
+    # with it, so the norm-wise measure of P is not comparable across it: the state blocks are)
+    assert e.remove_bad_features() == o.remove_bad_features()
+    x, fp, P = e.get_state()
+    assert P.shape == o.P().shape and np.array_equal(P, P.T)
+    bad = over_tolerance(parity_report(x, fp, P, o.x13(), o.feature_pos(), o.P()), F32_TOL, 50)
+    assert not {k: v for k, v in bad.items() if not k.startswith("P_")}, bad
+
+
+def test_remove_features_between_frames_exact(eng_mod, oracle_lib, seq50):
+    """features removed from the middle of the map between frames (MapManagement.cpp:212): P is compacted in fp32, the next
+    update runs on the shorter state"""
+    e, o = make_pair(eng_mod, oracle_lib, seq50, precision=EXACT)
+    _same_info(e.step(*seq50.frames[0]), o.step(*seq50.frames[0], ALGORITHMIC), "frame 0")
+    gone = [3, 4, 17, 30, 49]
+    e.remove_features(gone)
+    o.remove_features(gone)
+    assert e.n == 13 + 6 * 45
+    for t in (1, 2):
+        kps, desc = seq50.frames[t]
+        _same_info(e.step(kps, desc), o.step(kps, desc, ALGORITHMIC), f"frame {t} after removal")
+    assert_parity(e, o, "after removal", 45)
+
+
+def test_indefinite_innovation_covariance_is_reported_exact(eng_mod, seq12):
+    e = eng_mod.EkfEngine(seq12.cam, seq12.par, 16, max_keypoints=128, precision=EXACT)
+    P = -1e3 * np.eye(seq12.state_dim)
+    e.set_state(seq12.x13, seq12.feature_pos, seq12.feature_type, seq12.feature_desc, P)
+    e.predict()
+    preds, _, _ = e.predict_measurements()
+    m = np.zeros(4, dtype=MATCH_DTYPE)
+    m["featureIndex"] = preds["featureIndex"][:4]
+    m["imagePos"] = preds["imagePos"][:4] + 0.5
+    with pytest.raises(eng_mod.EkfError) as ei:
+        e.update(m)
+    assert ei.value.code == 3
+
+
+@pytest.mark.parametrize("path", [pytest.param(1, id="sweep"), pytest.param(2, id="gemm")])
+def test_n200_exact_frames_vs_oracle(eng_mod, oracle_lib, path):
+    """BASELINE configs[1] map size in the exact configuration, three frames, both ways of forming B"""
+    seq = SyntheticSequence(200, 3)
+    e, o = make_pair(eng_mod, oracle_lib, seq, precision=EXACT)
+    e.set_update_path(path)
+    for t in range(3):
+        _same_info(e.step(*seq.frames[t]), o.step(*seq.frames[t], ALGORITHMIC), f"frame {t}")
+    be = assert_parity(e, o, "N = 200, three frames", 200)
+    print(f"N=200 exact, update path {path}:", {k: f"{v:.2e}" for k, v in be.items()})
+
+
+def test_exact_drift_over_90_frames(eng_mod, oracle_lib):
+    """SURVEY 8(d) drift check in the exact configuration: N = 100, 90 frames against the fp64 oracle, identical decisions"""
+    seq = SyntheticSequence(100, 90)
+    e, o = make_pair(eng_mod, oracle_lib, seq, precision=EXACT)
+    for t in range(90):
+        _same_info(e.step(*seq.frames[t]), o.step(*seq.frames[t], ALGORITHMIC), f"frame {t}")
+    be = assert_parity(e, o, "90 frames", 100)
+    print("exact configuration after 90 frames:", {k: f"{v:.2e}" for k, v in be.items()})
+
+
+def test_concurrent_exact_engines_give_the_sequential_result(eng_mod):
+    """two exact engines stepped from two host threads (their own streams, work lists and digit-plane buffers): bit for bit the
+    result of running them one after the other"""
+    seq = SyntheticSequence(300, 4)
+
+    def run(out, k):
+        e = eng_mod.EkfEngine(seq.cam, seq.par, 300, max_keypoints=len(seq.frames[0][0]) + 64, precision=EXACT)
+        e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+        for t in range(4):
+            e.step(*seq.frames[t])
+        out[k] = e.get_state()
+        e.close()
+
+    ref = {}
+    run(ref, 0)
+    got = {}
+    th = [threading.Thread(target=run, args=(got, k)) for k in (1, 2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in (1, 2):
+        for a, b in zip(ref[0], got[k]):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), k
