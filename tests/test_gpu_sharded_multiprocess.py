@@ -54,7 +54,9 @@ WORKER = textwrap.dedent(
         for a, b in zip(infos, rinfos):
             assert (a.n_matches, a.n_inliers, a.n_rescued, a.status) == (b.n_matches, b.n_inliers, b.n_rescued, b.status)
         xr, fpr, Pr = ref.get_state()
-        tol = 1e-12 if precision == 0 else 1e-6
+        # (precision 2: each rank cuts ITS columns of B into digit planes, the unsharded engine all of them in one sweep: the
+        # same quantisation, different summation order of the fp64 rows of B -> 1e-6 does not always hold, 1e-5 does)
+        tol = 1e-12 if precision == 0 else (1e-6 if precision == 1 else 1e-5)
         assert np.abs(x - xr).max() <= tol * max(1.0, np.abs(xr).max())
         assert np.abs(Pfull - Pr).max() / np.abs(Pr).max() <= tol
         assert np.array_equal(Pfull, Pfull.T)
@@ -73,7 +75,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("precision", [0, 1, 2])
 def test_two_processes_one_filter(tmp_path, precision):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % ROOT)
