@@ -517,6 +517,11 @@ def main():
                                       # own timed frames (FETCH_SIZE x2, WRITE_SIZE; null without a profile)
                                       "traffic": (pmc_traffic[2].get(name) or {}).get("total_MB", None),
                                       "traffic_detail": pmc_traffic[2].get(name)}
+                    tr_mb = by_class[name]["traffic"]
+                    if tr_mb:  # which roof this class sits under: PMC bytes per launch / launch time against 8 TB/s
+                        by_class[name]["hbm_GBps"] = tr_mb * 1e6 / (tt / int(sel.sum())) / 1e9
+                        by_class[name]["hbm_frac"] = by_class[name]["hbm_GBps"] / 8000.0
+                        by_class[name]["bound"] = "hbm" if by_class[name]["hbm_frac"] > by_class[name]["frac"] else "mfma"
             roof["by_launch_class"] = by_class
         if roof is not None and hasattr(eng, "sweep_timing"):
             sw = eng.sweep_timing()
