@@ -198,3 +198,158 @@ __device__ __forceinline__ void b_rows_planes(const BPlanes &bp, const double *G
         for (int s = 0; s < PX_S; ++s) *(unsigned *)(dst + (size_t)s * bp.b_stride) = w[s];
     }
 }
+
+// The same role for a launch that eliminates TWO panels A = [k0, k0 + 32) and B = [k0 + 32, ..) (chol_pair.h):
+//     R_X = G_X - sum_{j < A} L_Xj B_j   (X = A, B),     B_A = Linv_A R_A,     B_B = C R_A + Linv_B R_B
+// Every finished block B_j is fetched from the memory-side cache ONCE per pair instead of once per panel: wavefronts 0, 1 form the
+// sum of panel A over the blocks j = 0, 2, .. / 1, 3, .., wavefronts 2, 3 the sum of panel B over the same blocks (their loads
+// of B_j's planes hit the L1 / L2 lines their neighbours just pulled).  `two` false (the first launch of a sweep, or a short last
+// launch): panel A alone, its blocks dealt to all four wavefronts as in b_rows_planes.
+// pool: [0..3] partial sums, then C and Linv_B in [0], [1]; [4], [5] the right-hand sides R_A, R_B; [2], [3] the finished blocks.
+__device__ __forceinline__ void b_pair_rows_planes(const BPlanes &bp, const double *G, int ld, int m, int k0, bool two, int bcol,
+                                                   double (*pool)[NB][NB + 1], double (*sLi)[NB + 1], const double (&gv)[4],
+                                                   const double (&gC)[4], const double (&gB)[4])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int kg = lane >> 5, idx = lane & 31;
+    const int c0 = bcol * NB, kp = k0 / NB, kB0 = k0 + NB;
+    double(*red)[NB][NB + 1] = pool; // [0..3]
+    double(*sRA)[NB + 1] = pool[4];
+    double(*sRB)[NB + 1] = pool[5];
+    const int r4 = tid >> 3, cg = (tid & 7) * 4;
+    double gA4[4], gB4[4];
+    {
+        const int ra = bp.grow ? bp.grow[k0 + r4] : k0 + r4;
+        const int rb = two ? (bp.grow ? bp.grow[kB0 + r4] : kB0 + r4) : -1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gA4[e] = ra >= 0 ? G[(size_t)ra * ld + c0 + cg + e] : 0.0;
+            gB4[e] = rb >= 0 ? G[(size_t)rb * ld + c0 + cg + e] : 0.0;
+        }
+    }
+    bp_v16i acc[PX_S];
+#pragma unroll
+    for (int L = 0; L < PX_S; ++L)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[L][r] = 0;
+    // this wavefront's panel (row block of L) and its share of the finished blocks
+    const int side = two ? (wv >> 1) : 0;            // 0: panel A, 1: panel B
+    const int j_first = two ? (wv & 1) : wv, j_step = two ? 2 : 4;
+    const int kprow = kp + side;
+    const int8_t *pl = bp.Lq + ((size_t)kprow * bp.nbk * 2 + kg) * 512 + idx * 16; // + j * 1024 + s * l_stride
+    const int8_t *pb = bp.Bq + ((size_t)kg * bp.ldq + c0 + idx) * 16;               // + 2 j * ldq * 16 + s * b_stride
+    const size_t bstep = (size_t)2 * bp.ldq * 16;
+    bp_v4i la[2][PX_S], lb[2][PX_S];
+#define BPP_LOAD(S_, J_)                                                                                          \
+    _Pragma("unroll") for (int s = 0; s < PX_S; ++s) {                                                            \
+        la[S_][s] = *(const bp_v4i *)(pl + (size_t)(J_) * 1024 + (size_t)s * bp.l_stride);                        \
+        lb[S_][s] = *(const bp_v4i *)(pb + (size_t)(J_) * bstep + (size_t)s * bp.b_stride);                       \
+    }
+#define BPP_MMA(S_)                                                                                               \
+    _Pragma("unroll") for (int s = 0; s < PX_S; ++s)                                                              \
+        _Pragma("unroll") for (int t = 0; t < PX_S - s; ++t)                                                      \
+            acc[s + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(la[S_][s], lb[S_][t], acc[s + t], 0, 0, 0);
+    const int cnt = kp > j_first ? (kp - j_first + j_step - 1) / j_step : 0; // blocks j < kp (the pair's own blocks go through C)
+    if (cnt > 0) { BPP_LOAD(0, j_first) }
+    for (int i = 0; i < cnt; i += 2) {
+        if (i + 1 < cnt) { BPP_LOAD(1, j_first + j_step * (i + 1)) }
+        BPP_MMA(0)
+        if (i + 1 < cnt) {
+            if (i + 2 < cnt) { BPP_LOAD(0, j_first + j_step * (i + 2)) }
+            BPP_MMA(1)
+        }
+    }
+#undef BPP_LOAD
+#undef BPP_MMA
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sLi[(tid + q * 256) / NB][(tid + q * 256) % NB] = gv[q];
+    const int ec = bp.bexp[c0 + idx] - 1022;
+    const int krow0 = side ? kB0 : k0;
+    double part[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
+        double tsum = (double)acc[PX_S - 1][r];
+#pragma unroll
+        for (int L = PX_S - 2; L >= 0; --L) tsum = fma(tsum, 1.0 / 256.0, (double)acc[L][r]);
+        const int er = krow0 + row < m ? bp.lexp[krow0 + row] - 1022 : 0;
+        part[r] = cnt > 0 ? ldexp(tsum, er + ec - 12) : 0.0;
+    }
+    if (two) { // every wavefront stores its partial sum: [0], [1] panel A, [2], [3] panel B
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wv][(r & 3) + 8 * (r >> 2) + 4 * kg][idx] = part[r];
+        __syncthreads();
+    } else { // four partial sums of panel A: 2, 3 store, 0, 1 add
+        if (wv >= 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wv - 2][(r & 3) + 8 * (r >> 2) + 4 * kg][idx] = part[r];
+        }
+        __syncthreads();
+        if (wv < 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wv][(r & 3) + 8 * (r >> 2) + 4 * kg][idx] += part[r];
+        }
+        __syncthreads();
+    }
+    double ra[4], rb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        ra[e] = gA4[e] - (red[0][r4][cg + e] + red[1][r4][cg + e]);
+        rb[e] = two ? gB4[e] - (red[2][r4][cg + e] + red[3][r4][cg + e]) : 0.0;
+    }
+    __syncthreads(); // the partial sums are dead: their space takes C, Linv_B and the finished blocks
+    double(*sC)[NB + 1] = pool[0];
+    double(*sLB)[NB + 1] = pool[1];
+    double(*sOA)[NB + 1] = pool[2];
+    double(*sOB)[NB + 1] = pool[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sRA[r4][cg + e] = ra[e];
+        sRB[r4][cg + e] = rb[e];
+    }
+    if (two) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sC[(tid + q * 256) / NB][(tid + q * 256) % NB] = gC[q];
+            sLB[(tid + q * 256) / NB][(tid + q * 256) % NB] = gB[q];
+        }
+    }
+    __syncthreads();
+    {   // B_A = Linv_A R_A, B_B = C R_A + Linv_B R_B on the fp64 MFMA, one 16 x 16 quadrant per wavefront
+        const int bi = wv >> 1, bj = wv & 1, lr = lane & 15, lk = lane >> 4;
+        const acc4_t z4 = {0, 0, 0, 0};
+        const acc4_t oa = quad_prod<false>(z4, sLi, sRA, bi, bj, lr, lk);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sOA[16 * bi + lk + 4 * q][16 * bj + lr] = oa[q];
+        if (two) {
+            acc4_t ob = quad_prod<false>(z4, sC, sRA, bi, bj, lr, lk);
+            ob = quad_prod<false>(ob, sLB, sRB, bi, bj, lr, lk);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sOB[16 * bi + lk + 4 * q][16 * bj + lr] = ob[q];
+        }
+    }
+    __syncthreads();
+    {   // digit planes of the finished block(s): thread (k half, 4-row quarter, column) cuts four rows of its column
+        const int col = tid & 31, qr = (tid >> 5) & 3, kh = tid >> 7;
+        const int sh = 8 * PX_S - 2 - (bp.bexp[c0 + col] - 1022);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            if (x == 1 && !two) break;
+            const double(*sO)[NB + 1] = x ? sOB : sOA;
+            const int kr0 = x ? kB0 : k0;
+            unsigned w[PX_S];
+#pragma unroll
+            for (int s = 0; s < PX_S; ++s) w[s] = 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * kh + 4 * qr + i;
+                const unsigned long long dw = px_digit_word(kr0 + row < m ? sO[row][col] : 0.0, sh);
+#pragma unroll
+                for (int s = 0; s < PX_S; ++s) w[s] |= px_digit_byte(dw, s) << (8 * i);
+            }
+            int8_t *dst = bp.Bq + ((size_t)(2 * (kp + x) + kh) * bp.ldq + c0 + col) * 16 + 4 * qr;
+#pragma unroll
+            for (int s = 0; s < PX_S; ++s) *(unsigned *)(dst + (size_t)s * bp.b_stride) = w[s];
+        }
+    }
+}

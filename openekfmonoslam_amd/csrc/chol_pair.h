@@ -60,6 +60,8 @@ __device__ __forceinline__ void block_prod_bt(acc4_t (&c)[2][2], const double (*
 
 // partial sums of the rows of B over the panels j = wv, wv + 4, ... < kp, for NP row panels at once (columns k0 + 32 p of L'):
 // the operands of the next two blocks are in flight while one is multiplied (as in k_chol_step); B_j is read once for all NP
+#include "chol_bplanes.h" // BPlanes, store_l_planes, b_pair_rows_planes (EKF_PRECISION_F32_EXACT: the rows of B from digit planes)
+
 template <typename T, int NP>
 __device__ __forceinline__ void b_row_sums(const T *Lt, const T *Bout, int ldS, int ld, int k0, int c0, int kp, int wv, int lm, int lq,
                                            typename Mma<T>::acc_t (&acc0)[NB / Mma<T>::MB][NB / Mma<T>::MB],
@@ -220,11 +222,11 @@ __device__ __forceinline__ void b_pair_rows_wide(const float *Lt, const float *G
     }
 }
 
-template <typename T, typename TG> // T: type of B and of its MFMA; TG: storage type of the gathered rows G (see k_chol_step)
-__global__ void __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1) // fp32: 239 registers, two workgroups per CU (LDS: 70 KB each)
+template <typename T, typename TG, bool PL = false> // T: type of B and of its MFMA; TG: storage type of the gathered rows G (see k_chol_step); PL: rows of B from digit planes
+__global__ void __launch_bounds__(256, (sizeof(T) == 4 || PL) ? 2 : 1) // fp32 / planes: two workgroups per CU (LDS: 70 KB each)
 k_chol_pair(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0, int kbA, int kbB, int k2, double *nu, int n_stiles,
             double *V, double *W, float *Wf, int ldw, int *counts, double *Gc, double *zout, double *Bc, const TG *G, T *Bout, int ld,
-            int n_bblocks, int n_rhs, int tiles_first, int spacer, unsigned long long *trace, int b_wide)
+            int n_bblocks, int n_rhs, int tiles_first, int spacer, unsigned long long *trace, int b_wide, BPlanes bp = BPlanes{})
 {
 #ifdef EKF_SWEEP_TRACE // debug builds only (scripts/sweep_trace.py): slot 0 first start, 1..4 end of role 0..3, 8.. milestones
     const unsigned long long t_in = trace ? wall_clock64() : 0ull;
@@ -283,6 +285,13 @@ k_chol_pair(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
             PAIR_TRACE(2)
         }
         return;
+    }
+    if constexpr (PL) {
+        if (bcol >= 0) { // EKF_PRECISION_F32_EXACT: the same role from int8 digit planes (chol_bplanes.h)
+            b_pair_rows_planes(bp, (const double *)G, ld, m, k0, two, bcol + bp.bcol0, pool, sLi, gv, gC, gB);
+            PAIR_TRACE(2)
+            return;
+        }
     }
     if (bcol >= 0) {
         // ---- rows of B: B_A = Linv_A R_A, B_B = C R_A + Linv_B R_B, columns 32 bcol ..
@@ -463,6 +472,7 @@ k_chol_pair(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         if (TJ == 0) { // L leaves the groups of the first group column (mirrored; row-major too on the inverse + GEMM path)
             store_l_block(LL, LLf, W != nullptr, ldS, m_pad, k2 + 2 * TI * NB, k0, kbA, sP[0]);
             store_l_block(LL, LLf, W != nullptr, ldS, m_pad, k2 + (2 * TI + 1) * NB, k0, kbA, sP[1]);
+            if constexpr (PL) store_l_planes(bp, m, 2, k2 + 2 * TI * NB, sP[0], k2 + (2 * TI + 1) * NB, sP[1], k0, kbA);
         }
         if (two) {
             __syncthreads(); // every L_xA has been read
@@ -488,6 +498,7 @@ k_chol_pair(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
             if (TJ == 0) {
                 store_l_block(LL, LLf, W != nullptr, ldS, m_pad, k2 + 2 * TI * NB, kB0, kbB, sP[0]);
                 store_l_block(LL, LLf, W != nullptr, ldS, m_pad, k2 + (2 * TI + 1) * NB, kB0, kbB, sP[1]);
+                if constexpr (PL) store_l_planes(bp, m, 2, k2 + 2 * TI * NB, sP[0], k2 + (2 * TI + 1) * NB, sP[1], kB0, kbB);
             }
         }
         if (tile_live) {
@@ -602,6 +613,10 @@ k_chol_pair(double *S, double *LL, float *LLf, int ldS, int m, int m_pad, int k0
         if (n_stiles == 1) { // P's rows of L when there is no tile group to store them
             store_l_block(LL, LLf, W != nullptr, ldS, m_pad, k2, k0, kbA, pool[0]);
             if (two) store_l_block(LL, LLf, W != nullptr, ldS, m_pad, k2, kB0, kbB, pool[1]);
+            if constexpr (PL) {
+                store_l_planes(bp, m, 1, k2, pool[0], k2, pool[0], k0, kbA);
+                if (two) store_l_planes(bp, m, 1, k2, pool[1], k2, pool[1], kB0, kbB);
+            }
         }
         if (hasQ) {
             const acc4_t lqp = quad_prod<true>(z4, pool[6], pool[5], bi, bj, lr, lk); // L_QP = T_QP Linv_P'

@@ -1300,7 +1300,11 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const bool want_pairs = e->sweep_mode == EKF_SWEEP_PAIRS ||
                                 (e->sweep_mode == EKF_SWEEP_AUTO &&
                                  (b_in_sweep ? (long long)(k0 / NB) * n_pad >= PAIR_FROM : m - k0 >= PAIR_ROWS));
-        const bool pair_launch = !planes_b && (have_pair || want_pairs);
+        // rows of B from digit planes (chol_bplanes.h b_pair_rows_planes): two panels per launch halve the re-reads of the finished
+        // planes and the rounds of workgroups of a wide map -- N = 2000: 15.4 -> 13.3 us per panel; N = 1000: 9.9 either way, so
+        // AUTO takes pairs from 8192 state columns on (profiles/r04_sweep_pairs_planes.txt)
+        const bool want_pairs_pl = e->sweep_mode == EKF_SWEEP_PAIRS || (e->sweep_mode == EKF_SWEEP_AUTO && n_pad >= 8192);
+        const bool pair_launch = planes_b ? (have_pair || want_pairs_pl) : (have_pair || want_pairs);
         const int kbA = min(NB, m - k0);
         const int kbB = have_pair ? max(0, min(NB, m - k0 - NB)) : 0;
         const int k2 = k0 + kbA + (pair_launch ? kbB : 0); // first row of the trailing matrix (= m: nothing below)
@@ -1326,9 +1330,18 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         }
 #endif
         if (pair_launch) {
-            k_chol_pair<TB, TB><<<n_wgs + n_spacers, 256, 0, s>>>(e->d.S, e->d.LL, sizeof(TB) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, kbB, k2,
-                                                             e->d.nu, n_stiles, V, W, Wf, ldw, e->d.counts, sizeof(TB) == 4 ? e->d.Gc : nullptr,
-                                                             e->d.zvec, e->d.Bc, G, A, ld, n_bw, n_rhs_blocks, n_wgs > e->n_cus ? 1 : 0, spacer, tr, b_wide ? 1 : 0);
+#define PAIR_ARGS e->d.S, e->d.LL, sizeof(TB) == 4 ? e->d.LLf : nullptr, ldS, m, m_pad, k0, kbA, kbB, k2, e->d.nu, n_stiles, V, W, Wf, ldw,      \
+                  e->d.counts, sizeof(TB) == 4 ? e->d.Gc : nullptr, e->d.zvec, e->d.Bc, G, A, ld, n_bw, n_rhs_blocks,                          \
+                  n_wgs > e->n_cus ? 1 : 0, spacer, tr, b_wide ? 1 : 0
+            bool launched = false;
+            if constexpr (EXACT) {
+                if (planes_b) {
+                    k_chol_pair<TB, TB, true><<<n_wgs + n_spacers, 256, 0, s>>>(PAIR_ARGS, bp);
+                    launched = true;
+                }
+            }
+            if (!launched) k_chol_pair<TB, TB><<<n_wgs + n_spacers, 256, 0, s>>>(PAIR_ARGS);
+#undef PAIR_ARGS
             k0 += have_pair ? 2 * NB : NB;
             have_pair = true;
         } else {

@@ -49,6 +49,25 @@ def test_update_sizes_across_block_boundaries_exact(eng_mod, oracle_lib, M, path
     assert_parity(e, o, f"update with M = {M}", 170)
 
 
+@pytest.mark.parametrize("M", [1, 16, 17, 32, 33, 48, 49, 64, 65, 80, 96, 97, 128, 129, 160])
+def test_update_sizes_two_panels_per_launch_exact(eng_mod, oracle_lib, M):
+    """the sweep in its two-panels-per-launch form with the rows of B from digit planes (chol_bplanes.h b_pair_rows_planes):
+    odd and even panel counts, a short last panel in either half of a pair"""
+    seq = SyntheticSequence(170, 1, outlier_fraction=0.0, distractors_per_feature=0.0, max_bit_flips=0)
+    e, o = make_pair(eng_mod, oracle_lib, seq, precision=EXACT)
+    e.set_update_path(1)
+    e.set_sweep_mode(0)
+    e.predict()
+    o.predict()
+    e.predict_measurements()
+    preds, Hs, Hf = o.predict_measurements()
+    mo = _matches_from_predictions(preds, M)
+    mp, mHs, mHf = align_to_matches(preds, Hs, Hf, mo)
+    assert o.update(mo, mp, mHs, mHf, ALGORITHMIC) == 0
+    e.update(mo)
+    assert_parity(e, o, f"update with M = {M}, two panels per launch", 170)
+
+
 @pytest.mark.parametrize("mode", [pytest.param(0, id="pairs"), pytest.param(1, id="single")])
 def test_sweep_modes_exact(eng_mod, oracle_lib, mode):
     """ekf_set_sweep_mode in the exact configuration (the rows of B from digit planes exist for one panel per launch: a
