@@ -1,12 +1,12 @@
 import sys, os
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
 import numpy as np
 import oracle_lib as ol
 from openekfmonoslam_amd import engine
 from openekfmonoslam_amd.synth import SyntheticSequence
-N=int(sys.argv[1]); F=int(sys.argv[2])
+N=int(sys.argv[1]); F=int(sys.argv[2]); PREC=int(sys.argv[3]) if len(sys.argv)>3 else 1  # 1 fast fp32, 2 exact
 seq=SyntheticSequence(N,F)
-e=engine.EkfEngine(seq.cam,seq.par,N,max_keypoints=2*N+64,precision=1)
+e=engine.EkfEngine(seq.cam,seq.par,N,max_keypoints=2*N+64,precision=PREC)
 o=ol.Oracle(seq.cam,seq.par,N+8)
 e.set_state(seq.x13,seq.feature_pos,seq.feature_type,seq.feature_desc,seq.P0)
 o.set_state(seq.x13,seq.feature_pos,seq.feature_type,seq.feature_desc,seq.P0)
