@@ -279,7 +279,7 @@ int ekf_round_covariance_to_f32(EkfEngine *e);
  * several ranks share a GPU (tests).  Map management is not available on a sharded engine. */
 typedef int (*EkfExchangeFn)(void *user, int what, void *device_base, size_t row_bytes, const int32_t *row_begin,
                              int world, int rank);
-enum { EKF_XCHG_HP = 0, EKF_XCHG_PRED_S = 1, EKF_XCHG_HPC = 2, EKF_XCHG_PDIAG = 3, EKF_XCHG_BPLANES = 4 };
+enum { EKF_XCHG_HP = 0, EKF_XCHG_PRED_S = 1, EKF_XCHG_HPC = 2, EKF_XCHG_PDIAG = 3, EKF_XCHG_BPLANES = 4, EKF_XCHG_SCOLS = 5 };
 /* what: which replicated table is being completed; device_base: its first row on this rank's GPU; rank r owns rows
  * [row_begin[r], row_begin[r+1]) of row_bytes each and has just written them.  The callback returns when this
  * rank's table holds every rank's rows (0 = ok).  It is called with the engine's stream idle. */

@@ -142,11 +142,15 @@ __device__ __forceinline__ void store_linv(double *V, double *W, float *Wf, int 
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, const int *mpos, const int *mdim,
-             double pixel_err, double *S, int ldS, double *V, double *W, float *Wf, int ldw, int *counts, int *lexp, const int *grow)
+             double pixel_err, double *S, int ldS, double *V, double *W, float *Wf, int ldw, int *counts, int *lexp, const int *grow,
+             int b_lo, int b_hi, double *St, int ldst, int duties)
 {
+    // [b_lo, b_hi), St: a rank of a row-sharded filter forms the block COLUMNS of its own matches only (it holds G[:, own
+    // columns], k_g_cols) and writes them a second time transposed (St: row = column of S) for the exchange; duties: the first
+    // diagonal block is factorised here (complete S only)
     const int b = blockIdx.x * 16 + (threadIdx.x & 15);
     const int a = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (a < M && b <= a) {
+    if (a < M && b <= a && b >= b_lo && b < b_hi) {
         const int pos = mpos[b], d = mdim[b];
         const double *hs = mHs + 14 * b, *hf = mHf + 12 * b;
 #pragma unroll
@@ -171,11 +175,15 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
             }
             S[(size_t)(2 * a + r) * ldS + 2 * b] = s0;
             S[(size_t)(2 * a + r) * ldS + 2 * b + 1] = s1;
+            if (St) {
+                St[(size_t)(2 * b) * ldst + 2 * a + r] = s0;
+                St[(size_t)(2 * b + 1) * ldst + 2 * a + r] = s1;
+            }
             // row scale of L for its digit planes (chol_bplanes.h): sum_k L_rk^2 = S_rr, so |L_rk| <= sqrt(S_rr)
             if (lexp && a == b) lexp[2 * a + r] = ilogb(sqrt(r == 0 ? s0 : s1) * 1.001) + 1 + 1022;
         }
     }
-    if (blockIdx.x != 0 || blockIdx.y != 0) return;
+    if (blockIdx.x != 0 || blockIdx.y != 0 || !duties) return;
     // Block (0, 0) has just written the first 32 x 32 diagonal block of S: factorise it here (what the sweep's
     // look-ahead does for every later block), which saves the separate launch that used to start the sweep.
     __shared__ double sa[NB][NB + 1], sx[NB][NB + 1];
@@ -189,6 +197,56 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
     __syncthreads();
     if (!block_chol_inv32_v4(sa, sx) && threadIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
     store_linv(V, W, Wf, ldw, 0, sx);
+}
+
+// ------------------------------------------------------------------------- row-sharded filter: G by symmetry, S by columns
+// a rank holds the rows of P of its own features, all columns.  G = H P restricted to the rank's OWN columns needs no
+// other rank: G[r][c] = sum_j H_r[j] P[j][c] = sum_j H_r[j] P[c][j] (P is bitwise symmetric), i.e. row c of P -- an own row --
+// against the 7 + d non-zeros of row r of H.  Columns [c_lo, c_hi) (multiples of 32; the camera block is formed by every rank from
+// the replicated camera rows); columns in that range the rank does not own are written as zeros (the 32-column blocks of the rows
+// of B straddle the ownership boundaries; their owner's digit planes replace them after the exchange).
+// Block: 64 columns x 4 row lanes, 64 rows per block.y.
+__global__ void __launch_bounds__(256)
+k_g_cols(const float *P, int ldp, RowMap rm, int n, int M, const double *mHs, const double *mHf, const int *mpos, const int *mdim,
+         double *G, int ld, int c_lo, int c_hi, int m_pad)
+{
+    const int c = c_lo + blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    if (c >= c_hi) return;
+    const bool valid = c < n && owns_row(rm, c);
+    const float *pr = P + (size_t)(valid ? local_row(rm, c) : 0) * ldp;
+    double pc[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) pc[k] = valid ? (double)pr[k] : 0.0;
+    const int row0 = blockIdx.y * 64;
+    for (int q = 0; q < 16; ++q) {
+        const int row = row0 + 4 * q + rl;
+        if (row >= m_pad) break;
+        double g = 0.0;
+        if (valid && row < 2 * M) {
+            const int i = row >> 1, a = row & 1;
+            const int pos = mpos[i], d = mdim[i];
+            const double *hs = mHs + 14 * i + 7 * a, *hf = mHf + 12 * i + 6 * a;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) g += hs[k] * pc[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) g += k < d ? hf[k] * (double)pr[pos + min(k, d - 1)] : 0.0;
+        }
+        G[(size_t)row * ld + c] = g;
+    }
+}
+
+// After the exchange of St (row cb = column cb of S, all ranks' columns complete): the columns of the other ranks into S (lower
+// triangle) and the row scales of L of their rows (k_assemble_S wrote the own ones).  grid (row chunks of 256, 2 M columns)
+__global__ void __launch_bounds__(256)
+k_s_unpack(const double *St, int ldst, double *S, int ldS, int m, int own_lo, int own_hi, int *lexp)
+{
+    const int cb = blockIdx.y, ra = blockIdx.x * 256 + threadIdx.x;
+    if (cb >= own_lo && cb < own_hi) return;
+    if (ra >= m || ra < cb) return;
+    const double v = St[(size_t)cb * ldst + ra];
+    S[(size_t)ra * ldS + cb] = v;
+    if (lexp && ra == cb) lexp[ra] = ilogb(sqrt(v) * 1.001) + 1 + 1022;
 }
 
 #include "chol_pair.h" // the two-panels-per-launch variant of the sweep below, and the 32^3 product helpers both use
@@ -1222,6 +1280,10 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
                             (int)e->shard_row_begin.size() == e->shard_world + 1; // every rank forms its own columns of B
     const bool planes_b = EXACT && b_in_sweep && m_pad <= B_SWEEP_MAX && e->d.Lq != nullptr && update_cov && (!sharded || shard_cols);
     const bool apriori = planes_b || shard_cols || (EXACT && !b_in_sweep && update_cov && e->d.Wq != nullptr); // column scales of B from diag(P)
+    // sharded step with the rows of B from digit planes: G by symmetry and S by columns (k_g_cols) instead of the exchange of the rows of G
+    bool sym_g = false;
+    if constexpr (EXACT)
+        sym_g = shard_cols && planes_b && e->after_gather != nullptr && (int)e->shard_rb.size() == e->shard_world + 1 && e->d.W != nullptr;
     BPlanes bp{};
     // sharded: this rank forms the column blocks [cb0, cb1) of B -- the blocks whose first column lies in its share of the state
     // rows (rank 0: from column 0) -- and receives the others' digit planes afterwards (the B role divided by the ranks)
@@ -1237,11 +1299,13 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         if (sharded) {
             const int W = e->shard_world;
             col_rb.assign(W + 1, 0);
-            for (int r = 1; r < W; ++r) col_rb[r] = std::min(n_pad, round_up(e->shard_row_begin[r], NB));
+            // (G by symmetry: a rank can only form the columns of the rows it holds, so the shares end exactly at the ownership
+            // boundaries and the 32-column block that straddles one is formed by both neighbours, each valid in its own columns)
+            for (int r = 1; r < W; ++r) col_rb[r] = std::min(n_pad, sym_g ? e->shard_row_begin[r] : round_up(e->shard_row_begin[r], NB));
             col_rb[W] = n_pad;
             if (planes_b) {
                 cb0 = col_rb[e->shard_rank] / NB;
-                cb1 = col_rb[e->shard_rank + 1] / NB;
+                cb1 = (col_rb[e->shard_rank + 1] + NB - 1) / NB;
                 bp.bcol0 = cb0;
             }
             // the diagonal of P behind the a-priori column scales: every rank's own entries, then all of them
@@ -1255,22 +1319,39 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     float *Wf = sizeof(TB) == 4 && !b_in_sweep ? e->d.Wf : nullptr;
     {
         dim3 grid((n_pad / (int)(16 / sizeof(TB)) + 255) / 256, m_pad);
-        if (planes_b && !sharded) grid.x = 1; // no copy: one workgroup per row (bookkeeping, row map, its share of the column scales)
+        if ((planes_b && !sharded) || sym_g) grid.x = 1; // no copy: one workgroup per row (bookkeeping, row map, its share of the column scales)
         k_gather<TB><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const TB *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
                                          e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
                                          e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc, EXACT ? e->d.Bexp : nullptr,
                                          apriori ? (sharded ? e->d.Pdiag : (const float *)e->d.P) : nullptr, sharded ? 0 : ld, n,
-                                         planes_b && !sharded ? e->d.Grow : nullptr);
-        if (planes_b && !sharded) G = (TB *)e->d.HP; // the consumers read H P through the row map
+                                         (planes_b && !sharded) || sym_g ? e->d.Grow : nullptr);
+        if (planes_b && !sharded) G = (TB *)e->d.HP; // the consumers read H P through the row map (sym_g: G is formed by k_g_cols below)
     }
     // sharded step: every rank gathered the rows of the matches it owns; the others arrive here (engine.cpp)
-    e->hook_rc = e->after_gather ? e->after_gather(e, M) : 0;
+    e->hook_rc = (e->after_gather && !sym_g) ? e->after_gather(e, M) : 0;
     if (e->hook_rc) return;
     {
         dim3 grid((M + 15) / 16, (M + 15) / 16);
+        if (sym_g) {
+            // G[:, own columns] (and the camera block) from the own rows of P; S by the block columns of the own matches, one
+            // all-gather of those columns (transposed image in W, which the sweep path does not use), the rest of S's duties after it
+            const int c_lo = cb0 * NB, c_hi = cb1 * NB;
+            const int b_lo = e->shard_rb[e->shard_rank] / 2, b_hi = e->shard_rb[e->shard_rank + 1] / 2;
+            if (c_lo > 0) k_g_cols<<<dim3(1, (m_pad + 63) / 64), 256, 0, s>>>((const float *)e->d.P, ld, e->rm, n, M, e->d.mHs, e->d.mHf, e->d.mpos,
+                                                                       e->d.mdim, (double *)G, ld, 0, NB, m_pad);
+            k_g_cols<<<dim3((c_hi - c_lo + 63) / 64, (m_pad + 63) / 64), 256, 0, s>>>((const float *)e->d.P, ld, e->rm, n, M, e->d.mHs, e->d.mHf,
+                                                                               e->d.mpos, e->d.mdim, (double *)G, ld, c_lo, c_hi, m_pad);
+            k_assemble_S<TB><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim, e->cfg.cam.pixelErrorX, e->d.S, ldS, V,
+                                                 nullptr, nullptr, ldw, e->d.counts, e->d.Lexp, nullptr, b_lo, b_hi, e->d.W, ldw, 0);
+            e->hook_rc = e->exchange_hook(e, EKF_XCHG_SCOLS, e->d.W, (size_t)ldw * sizeof(double), e->shard_rb, "the columns of S");
+            if (e->hook_rc) return;
+            k_s_unpack<<<dim3((m + 255) / 256, m), 256, 0, s>>>(e->d.W, ldw, e->d.S, ldS, m, 2 * b_lo, 2 * b_hi, e->d.Lexp);
+            k_assemble_S<TB><<<dim3(1, 1), 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim, e->cfg.cam.pixelErrorX, e->d.S, ldS, V,
+                                                       nullptr, nullptr, ldw, e->d.counts, nullptr, nullptr, 0, 0, nullptr, 0, 1);
+        } else
         k_assemble_S<TB><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts,
-                                             planes_b ? e->d.Lexp : nullptr, planes_b && !sharded ? e->d.Grow : nullptr);
+                                             planes_b ? e->d.Lexp : nullptr, planes_b && !sharded ? e->d.Grow : nullptr, 0, M, nullptr, 0, 1);
     }
     const int n_bblocks = b_in_sweep ? cb1 - cb0 : 0; // row block k of B = inv(L) G rides in the launch of panel k (sharded planes: own column blocks)
     hipEvent_t sw0 = nullptr, sw1 = nullptr;

@@ -7,8 +7,8 @@ Inputs  : profiles/<r>_bench_n2000_f32x.json, <r>_bench_n5000_f32x.json (ms per 
           first frame twice, so its totals are not per-frame figures of the timed frames).
 Model   : downdate x 2/G (a rank computes both triangles of its own rows); rows of B / G with the sweep bounded below by the
           dependent chain (CHAIN_US per 32-row panel, the fast configuration's measured launch period); the GEMM / G; the inverse
-          and everything else replicated; per update a rank receives (G-1)/G of the rows of G (8 B per element) and of the five
-          digit planes of B (5 B per element) over G-1 xGMI links of LINK_GBS each, not overlapped with compute.
+          and everything else replicated; per update a rank receives (G-1)/G of the five digit planes of B (5 B per element) and, above 2048
+          rows, of the rows of G (8 B per element; below: of the columns of S, 8 m^2 B) over G-1 xGMI links of LINK_GBS each, not overlapped with compute.
 No multi-GPU measurement exists on this pool: this is arithmetic on one-GPU measurements, not a scaling result."""
 import csv
 import json
@@ -52,12 +52,14 @@ def model(tag, d, n_state, gemm_share, ranks):
         chain = panels * CHAIN_US * 1e-3
         sg = max(chain, sweep / g) if b_in_sweep else sweep
         gg = gemm_ms / g
-        recv_g = rows_m * n_state * 8.0 * (g - 1) / g
+        # rows of B in the sweep (<= 2048 rows): no rows of G travel (G[:, own columns] by symmetry from the own rows of P); S is
+        # assembled by block columns and all-gathered: 8 m^2 bytes per update (two updates of ~62 % and ~38 % of the frame's rows)
+        recv_g = (0.53 * rows_m * rows_m * 8.0 if b_in_sweep else rows_m * n_state * 8.0) * (g - 1) / g
         recv_p = rows_m * n_state * 5.0 * (g - 1) / g
         xt = (recv_g + recv_p) / ((g - 1) * LINK_GBS * 1e9) * 1e3
         tg = dg + sg + inv_ms + gg + rest + xt
         print(f"  G={g}: downdate {dg:.2f}  sweep {sg:.2f}  inverse {inv_ms:.2f}  GEMM {gg:.2f}  rest {rest:.2f}  "
-              f"received {recv_g / 1e6:.0f} + {recv_p / 1e6:.0f} MB -> {xt:.2f} ms  total {tg:.2f} ms  speed-up {t1 / tg:.2f}x")
+              f"received {recv_g / 1e6:.0f} (G rows / S columns) + {recv_p / 1e6:.0f} (planes) MB -> {xt:.2f} ms  total {tg:.2f} ms  speed-up {t1 / tg:.2f}x")
 
 
 def main():

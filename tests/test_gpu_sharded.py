@@ -255,7 +255,9 @@ def test_n2000_exact_ranks_two_frames_vs_oracle_and_model(eng_mod, oracle_lib, w
     second frame's updates (m = 1342 and 1568 rows) inside the sweep from int8 digit planes, the first frame's m = 3714 rescue
     update by inverse + GEMM over its own column tiles -- then the digit planes travel: the bytes a rank receives and the columns
     it forms are asserted against the cost model of DESIGN.md section 8:
-    bytes = (n_pad - own columns) x 5 x round_up(m, 32) per update, own columns = its share of the state rows rounded to 32."""
+    bytes = (n_pad - own columns) x 5 x round_up(m, 32) per update, own columns = its share of the state rows (rounded to 32 on the
+    inverse + GEMM path).  Below 2048 rows no rows of G travel: G[:, own columns] comes from the rank's own rows of P by symmetry and
+    S is assembled by block columns and all-gathered (EKF_XCHG_SCOLS)."""
     from parity_metric import over_tolerance, parity_report
 
     N, F = 2000, 2
@@ -287,7 +289,11 @@ def test_n2000_exact_ranks_two_frames_vs_oracle_and_model(eng_mod, oracle_lib, w
     for r, e in enumerate(grp.engines):
         got, c0, c1 = e.shard_counters()
         cols.append((c0, c1))
-        want = sum((n_pad - (c1 - c0)) * 5 * mk for mk in planes_rows)
+        # rows of B in the sweep (<= 2048 rows): G by symmetry, so a rank's columns are exactly the state rows it holds (the last
+        # rank's run to n_pad); inverse + GEMM above: its share rounded to 32 columns (ekf_shard_counters)
+        _, _, lo, hi = e.shard_info()
+        own_exact = (n_pad if r == world - 1 else hi) - lo
+        want = sum((n_pad - (own_exact if mk <= 2048 else c1 - c0)) * 5 * mk for mk in planes_rows)
         assert got == want, (r, got, want)
     assert cols[0][0] == 0 and cols[-1][1] == n_pad and all(cols[r][1] == cols[r + 1][0] for r in range(world - 1)), cols
     share = [(c1 - c0) / n_pad for c0, c1 in cols]
