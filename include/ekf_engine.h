@@ -276,7 +276,11 @@ int ekf_round_covariance_to_f32(EkfEngine *e);
  * S, its factor, B) is replicated.  Owned rows are predicted, multiplied (H_f P) and downdated locally; the one
  * exchange per prediction is an all-gather of the H.P row blocks (and of the 2x2 S_i of the owned features), done by
  * the callback the host installs: RCCL broadcasts/all-gather between processes, device-to-device copies when
- * several ranks share a GPU (tests).  Map management is not available on a sharded engine. */
+ * several ranks share a GPU (tests).  Map management is not available on a sharded engine.
+ * EKF_PRECISION_F32_EXACT (round 4): B is NOT replicated -- every rank forms the columns of B = inv(L) H P that belong to the state
+ * rows it holds and the ranks all-gather B's int8 digit planes (EKF_XCHG_BPLANES; EKF_XCHG_PDIAG carries the diagonal of P behind
+ * their column scales); for updates of at most 2048 rows no rows of H P travel either: G[:, own columns] follows from the own rows
+ * of P by symmetry and S is assembled by block columns and all-gathered (EKF_XCHG_SCOLS).  DESIGN.md section 8. */
 typedef int (*EkfExchangeFn)(void *user, int what, void *device_base, size_t row_bytes, const int32_t *row_begin,
                              int world, int rank);
 enum { EKF_XCHG_HP = 0, EKF_XCHG_PRED_S = 1, EKF_XCHG_HPC = 2, EKF_XCHG_PDIAG = 3, EKF_XCHG_BPLANES = 4, EKF_XCHG_SCOLS = 5 };
