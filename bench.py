@@ -255,7 +255,7 @@ def cpu_baseline_committed(seq, workload, eng, tol, componentwise):
     }
 
 
-def all_matched_line(eng, seq, dtype, updates=8):
+def all_matched_line(eng, seq, dtype, updates=8, exact=False):
     """Secondary line: one update with EVERY feature matched (M = N, m = 2N: the size BASELINE.md's
     1.53 ms budget is computed on), which the 2-best list rule never produces on the synthetic keypoints.  Stage calls
     through the same ABI: predict, predictCameraMeasurements, update with a match per prediction (prediction + 0.3 px)."""
@@ -292,8 +292,15 @@ def all_matched_line(eng, seq, dtype, updates=8):
     if tm.p_update_launches > 0:
         ms = tm.p_update_kernel_ms / tm.p_update_launches
         ach = float(n) * n * m_rows / (ms * 1e-3) / 1e12
-        out["p_update"] = {"avg_launch_ms": ms, "achieved_tflops": ach, "frac": ach / PEAK_TFLOPS[dtype],
-                           "algorithmic_flops_per_launch": float(n) * n * m_rows}
+        if exact:  # the int8 kernel is priced like `roofline`: the int8 ops it executes against the int8 peak
+            tops = PX_PRODUCTS * ach
+            out["p_update"] = {"avg_launch_ms": ms, "achieved": tops, "peak": PEAK_I8_TOPS, "unit": "TOP/s (int8)",
+                               "frac": tops / PEAK_I8_TOPS, "fp32_equivalent_tflops": ach,
+                               "algorithmic_flops_per_launch": float(n) * n * m_rows,
+                               "int8_ops_per_launch": PX_PRODUCTS * float(n) * n * m_rows}
+        else:
+            out["p_update"] = {"avg_launch_ms": ms, "achieved": ach, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                               "frac": ach / PEAK_TFLOPS[dtype], "algorithmic_flops_per_launch": float(n) * n * m_rows}
     return out
 
 
@@ -521,7 +528,9 @@ def main():
                     if tr_mb:  # which roof this class sits under: PMC bytes per launch / launch time against 8 TB/s
                         by_class[name]["hbm_GBps"] = tr_mb * 1e6 / (tt / int(sel.sum())) / 1e9
                         by_class[name]["hbm_frac"] = by_class[name]["hbm_GBps"] / 8000.0
-                        by_class[name]["bound"] = "hbm" if by_class[name]["hbm_frac"] > by_class[name]["frac"] else "mfma"
+                        # neither roof above half: the class is bound by neither, it is fixed cost (ring fill, epilogue, unit list)
+                        hf, mf = by_class[name]["hbm_frac"], by_class[name]["frac"]
+                        by_class[name]["bound"] = "fixed-cost" if max(hf, mf) < 0.5 else ("hbm" if hf > mf else "mfma")
             roof["by_launch_class"] = by_class
         if roof is not None and hasattr(eng, "sweep_timing"):
             sw = eng.sweep_timing()
@@ -626,7 +635,7 @@ def main():
     if single_ref is not None:
         out["single_gpu_same_workload"] = single_ref
     if world == 1 and not group and not ncc and args.workload.startswith("n1000") and not args.no_all_matched:
-        out["all_matched"] = all_matched_line(eng, seq, dtype)
+        out["all_matched"] = all_matched_line(eng, seq, dtype, exact=exact)
     if exact and world == 1 and not group and not ncc and not args.no_fast_line:
         # the fast fp32 MFMA configuration on the same frames, labelled: NOT the parity configuration (its component-wise figure
         # is reported by `--workload n1000_f32`, ungated)

@@ -305,7 +305,9 @@ int ekf_comm_init(EkfEngine *e, const uint8_t id[EKF_COMM_ID_BYTES]);
 int ekf_shard_info(const EkfEngine *e, int *rank, int *world, int *row_begin, int *row_end);
 /* EKF_PRECISION_F32_EXACT on a sharded engine: a rank forms the rows of B = inv(L) H P for its own column blocks only and receives
  * the others' int8 digit planes (5 bytes per element of B).  plane_bytes_received: total since creation; [own_columns_begin,
- * own_columns_end): the columns (multiples of 32) whose rows of B this rank forms.  Tests compare both with the cost model. */
+ * own_columns_end): the columns whose rows of B this rank formed in its LAST update -- they end exactly at the ownership boundaries
+ * on the by-symmetry route (updates of <= 2048 rows) and at multiples of 32 on the inverse + GEMM route; before the first update:
+ * the ownership boundaries rounded to 32.  Tests compare both with the cost model. */
 int ekf_shard_counters(EkfEngine *e, int64_t *plane_bytes_received, int32_t *own_columns_begin, int32_t *own_columns_end);
 /* device-to-device copy on the engine's device, synchronous: the exchange primitive when ranks share a GPU */
 int ekf_device_copy(EkfEngine *e, void *dst, const void *src, size_t bytes);

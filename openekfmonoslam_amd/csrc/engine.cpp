@@ -186,6 +186,12 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     e->cap = cfg->max_features;
     e->ncap = 13 + 6 * e->cap;
     e->mcap = round_up(2 * e->cap, NB);
+    // the exact downdate accumulates digit products in int32: five products of |d d'| <= 2^14 per level and row of k, so the sums
+    // are exact only while 5 * 2^14 * m < 2^31 (kernels_pexact.hip); refuse maps whose updates could exceed that
+    if (e->exact && e->mcap > PX_MAX_ROWS) {
+        delete e;
+        return EKF_ERR_INVALID_ARG;
+    }
     e->kcap = cfg->max_keypoints > 0 ? cfg->max_keypoints : 4 * e->cap;
     e->ldP = round_up(e->ncap, LD_ALIGN);
     e->ldS = round_up(e->mcap, 128) + 128;
@@ -451,7 +457,12 @@ int ekf_shard_counters(EkfEngine *e, int64_t *plane_bytes_received, int32_t *own
     if (!e) return EKF_ERR_INVALID_ARG;
     if (plane_bytes_received) *plane_bytes_received = e->xchg_bytes_planes;
     const int n_pad = round_up(e->n, LD_ALIGN), W = e->shard_world, r = e->shard_rank;
-    auto col = [&](int k) { return k <= 0 ? 0 : (k >= W ? n_pad : std::min(n_pad, round_up(e->shard_row_begin.size() > (size_t)k ? e->shard_row_begin[k] : e->n, NB))); };
+    // the shares the last update actually used (they end at the ownership boundaries on the by-symmetry route, at multiples of
+    // 32 on the inverse + GEMM route); before the first update: the rounded convention
+    auto col = [&](int k) {
+        if ((int)e->last_col_rb.size() == W + 1) return (int)e->last_col_rb[k];
+        return k <= 0 ? 0 : (k >= W ? n_pad : std::min(n_pad, round_up(e->shard_row_begin.size() > (size_t)k ? e->shard_row_begin[k] : e->n, NB)));
+    };
     if (own_columns_begin) *own_columns_begin = col(r);
     if (own_columns_end) *own_columns_end = col(r + 1);
     return EKF_OK;

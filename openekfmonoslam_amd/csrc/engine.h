@@ -20,6 +20,8 @@ constexpr int DX_SPLIT = 16;    // k-splits of the dx = B' z reduction
 #define PX_S_VALUE 5
 #endif
 constexpr int PX_S = PX_S_VALUE; // EKF_PRECISION_F32_EXACT: balanced base-256 digits per element of B (kernels_pexact.hip)
+// rows of B up to which the int32 level sums of the exact downdate cannot wrap: PX_S products of |d d'| <= 2^14 per level and row
+constexpr int PX_MAX_ROWS = ((1 << 17) / PX_S) / 32 * 32; // 26208 at PX_S = 5
 
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -197,6 +199,7 @@ struct EkfEngine {
     long long xchg_bytes_planes = 0;      // bytes of digit planes this rank received (tests assert them against the model)
     int hook_rc = 0;                     // its status (launch_update returns nothing)
     std::vector<int32_t> shard_rb;       // row boundaries of the gathered rows by owner (from CNT_SHARD0..)
+    std::vector<int32_t> last_col_rb;    // column shares of the planes of B used by the last sharded update (ekf_shard_counters)
     void *xchg_user = nullptr;
     int n_cus = 256;           // compute units of the device (launch-shape decisions)
     int b_path = 0;            // ekf_set_update_path: 0 by size (B_SWEEP_MAX), 1 B in the sweep, 2 inverse + GEMM

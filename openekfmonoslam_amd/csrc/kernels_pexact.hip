@@ -13,7 +13,8 @@
 //     bytes in HBM and in LDS (global_load_lds_dwordx4, no staging registers).
 //   * k_p_update_i8: X_i . X_j = sum_L 256^(8 - L) sum_{s + t = L} d_s(i) . d_t(j).  The levels L = 0 .. 4 (15 digit
 //     products per 32 rows of k, each ONE v_mfma_i32_32x32x32_i8 per 32 x 32 block: 32 cycles where the fp32 MFMA needs
-//     1024 for the same 32 rows) are accumulated in int32 -- exact: |d d'| <= 2^14, 5 products, m <= 2^13 rows => < 2^30 --
+//     1024 for the same 32 rows) are accumulated in int32 -- exact while 5 * 2^14 * m < 2^31, i.e. m <= PX_MAX_ROWS = 26208 rows
+//     (|d d'| <= 2^14, at most 5 products per level and row of k; ekf_engine_create refuses larger maps in this configuration) --
 //     and combined once in fp64; the dropped levels are below 2^-35 of max_i max_j per term.  P_new = fl32(P_old - v): ONE
 //     rounding per entry and update, i.e. what fp32 storage of an fp64 update costs.
 //   * integer sums are exactly symmetric (level L of (i, j) and of (j, i) are the same multiset of products), so diagonal
@@ -1133,7 +1134,12 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bo
     e->pu_slots = slots_saved;
     const int grid = e->pu_per_xcd * 8;
     const int4 *tm = (const int4 *)e->d.pu_tilemap;
-    if (grid == 0 || !tm) return; // build_units failed (e->hook_rc is set)
+    if (grid == 0 || !tm) { // build_units failed (e->hook_rc is set): nothing was launched, the timing events go back
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (e2) (void)hipEventDestroy(e2);
+        return;
+    }
     if (e->timing) (void)hipEventRecord(e0, s);
     if (!e->p_exact_sym && !rect) k_p_update_i8<true><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
     else if (g_px_variant == 1 || PX_S != 5) k_p_update_i8<false><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
@@ -1145,9 +1151,11 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bo
     else if (rect) k_p_update_i8p<true><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
     else k_p_update_i8p<false><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
 #endif
+    bool launched = true;
     {   // a launch that the runtime refuses (resources) would leave P silently un-downdated
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) {
+            launched = false;
             e->err = std::string("exact downdate launch: ") + hipGetErrorString(le);
             std::fprintf(stderr, "ekf: %s\n", e->err.c_str());
             e->hook_rc = EKF_ERR_HIP;
@@ -1160,7 +1168,7 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bo
         e->pu_m.push_back(m);
         e->px_events.emplace_back(e2, e0); // sweep end (or this call's start) -> downdate start
     }
-    e->p_exact_sym = true;
+    if (launched) e->p_exact_sym = true; // (a refused launch leaves P as uploaded: the next downdate still symmetrises it)
 }
 
 } // namespace ekf

@@ -1303,6 +1303,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             // boundaries and the 32-column block that straddles one is formed by both neighbours, each valid in its own columns)
             for (int r = 1; r < W; ++r) col_rb[r] = std::min(n_pad, sym_g ? e->shard_row_begin[r] : round_up(e->shard_row_begin[r], NB));
             col_rb[W] = n_pad;
+            e->last_col_rb = col_rb;
             if (planes_b) {
                 cb0 = col_rb[e->shard_rank] / NB;
                 cb1 = (col_rb[e->shard_rank + 1] + NB - 1) / NB;
@@ -1342,10 +1343,11 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             k_g_cols<<<dim3((c_hi - c_lo + 63) / 64, (m_pad + 63) / 64), 256, 0, s>>>((const float *)e->d.P, ld, e->rm, n, M, e->d.mHs, e->d.mHf,
                                                                                e->d.mpos, e->d.mdim, (double *)G, ld, c_lo, c_hi, m_pad);
             k_assemble_S<TB><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim, e->cfg.cam.pixelErrorX, e->d.S, ldS, V,
-                                                 nullptr, nullptr, ldw, e->d.counts, e->d.Lexp, nullptr, b_lo, b_hi, e->d.W, ldw, 0);
-            e->hook_rc = e->exchange_hook(e, EKF_XCHG_SCOLS, e->d.W, (size_t)ldw * sizeof(double), e->shard_rb, "the columns of S");
+                                                 nullptr, nullptr, ldw, e->d.counts, e->d.Lexp, nullptr, b_lo, b_hi, e->d.W, m_pad, 0);
+            // (rows of the image are m_pad doubles: only the live columns of S travel, not the capacity-strided ldW)
+            e->hook_rc = e->exchange_hook(e, EKF_XCHG_SCOLS, e->d.W, (size_t)m_pad * sizeof(double), e->shard_rb, "the columns of S");
             if (e->hook_rc) return;
-            k_s_unpack<<<dim3((m + 255) / 256, m), 256, 0, s>>>(e->d.W, ldw, e->d.S, ldS, m, 2 * b_lo, 2 * b_hi, e->d.Lexp);
+            k_s_unpack<<<dim3((m + 255) / 256, m), 256, 0, s>>>(e->d.W, m_pad, e->d.S, ldS, m, 2 * b_lo, 2 * b_hi, e->d.Lexp);
             k_assemble_S<TB><<<dim3(1, 1), 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim, e->cfg.cam.pixelErrorX, e->d.S, ldS, V,
                                                        nullptr, nullptr, ldw, e->d.counts, nullptr, nullptr, 0, 0, nullptr, 0, 1);
         } else

@@ -46,6 +46,45 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["parity_ok"] is True
 
 
+def _walk(node, path=""):
+    if isinstance(node, dict):
+        for k, v in node.items():
+            yield from _walk(v, f"{path}.{k}" if path else k)
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            yield from _walk(v, f"{path}[{i}]")
+    else:
+        yield path, node
+
+
+def test_default_line_the_driver_runs_has_no_fraction_above_one():
+    """The line `python bench.py` prints with no workload flag (n1000_f32x: int8 units, fast_fp32_configuration, all_matched):
+    every `frac` anywhere in the JSON is a fraction of a peak the timed kernel actually runs against, so none exceeds 1;
+    roofline, cpu_baseline and parity_ok are present; the bound labels come from the three-way rule."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["config"]["name"] == "n1000_f32x" and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2
+    assert d["roofline"] is not None and d["cpu_baseline"] is not None and d["parity_ok"] is True
+    fracs = [(p, v) for p, v in _walk(d) if p.split(".")[-1].endswith("frac")]
+    assert fracs, "no frac on the line"
+    for p, v in fracs:
+        assert v is None or 0.0 <= v <= 1.0, (p, v)
+    roof = d["roofline"]
+    assert roof["unit"] == "TOP/s (int8)" and roof["peak"] == 5033.0 and roof["bound"] in ("hbm", "mfma")
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) <= 1e-12
+    for name, c in roof["by_launch_class"].items():
+        assert c.get("bound", "mfma") in ("mfma", "hbm", "fixed-cost"), (name, c.get("bound"))
+    am = d["all_matched"]["p_update"]
+    assert am["unit"] == "TOP/s (int8)" and abs(am["frac"] - am["achieved"] / am["peak"]) <= 1e-12
+    assert d["fast_fp32_configuration"]["value"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["parity_vs_oracle"]["parity_ok"] is True
+
+
 def test_sweep_timing_through_the_abi():
     """ekf_timing_sweep: HIP-event time, panels and flops of the Cholesky sweep of every update since the last reset."""
     import numpy as np  # noqa: F401

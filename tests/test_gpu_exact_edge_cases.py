@@ -225,3 +225,13 @@ def test_concurrent_exact_engines_give_the_sequential_result(eng_mod):
     for k in (1, 2):
         for a, b in zip(ref[0], got[k]):
             assert np.array_equal(np.asarray(a), np.asarray(b)), k
+
+
+def test_exact_configuration_refuses_maps_whose_int32_level_sums_could_wrap(eng_mod):
+    """kernels_pexact.hip: the int32 level sums of the exact downdate are exact while 5 * 2^14 * m < 2^31, i.e. up to 26208 rows of
+    B (round-4 ADVICE): ekf_engine_create returns EKF_ERR_INVALID_ARG for EKF_PRECISION_F32_EXACT with 2 * max_features above that,
+    before anything is allocated; the largest admissible capacity is accepted by the argument check (13104 features)."""
+    seq = SyntheticSequence(8, 1)
+    with pytest.raises(eng_mod.EkfError) as ei:
+        eng_mod.EkfEngine(seq.cam, seq.par, 13105, max_keypoints=64, precision=EXACT)
+    assert ei.value.code == 1  # EKF_ERR_INVALID_ARG

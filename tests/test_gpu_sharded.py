@@ -48,9 +48,9 @@ def test_sharded_steps_match_unsharded(eng_mod, oracle_lib, nfeat, world, precis
     x, fp, P = grp.get_state()
     xr, fpr, Pr = ref.get_state()
     assert not np.isnan(P).any(), "some rows of P were returned by no rank"
-    # precision 2: the unsharded engine forms the rows of B from int8 digit planes with a-priori column scales (chol_bplanes.h), a
-    # rank of the sharded one in fp64 with the columns' true maxima -- two roundings of the same fp32-stored filter, 1.3e-6 apart
-    # component-wise after three frames (measured); held to the north-star 1e-5
+    # precision 2: both engines form the rows of B from int8 digit planes with a-priori column scales (chol_bplanes.h); the sharded
+    # one from G formed by symmetry out of its own rows of P (k_g_cols) where the unsharded one reads the cached H P rows -- two
+    # roundings of the same fp32-stored filter, ~1e-6 apart component-wise after three frames (measured); held to the north-star 1e-5
     tol = 1e-12 if precision == 0 else (1e-6 if precision == 1 else 1e-5)
     assert state_err(x, fp, xr, fpr) <= tol
     assert rel_max(P, Pr) <= tol
@@ -287,13 +287,16 @@ def test_n2000_exact_ranks_two_frames_vs_oracle_and_model(eng_mod, oracle_lib, w
     assert any(mk <= 2048 for mk in planes_rows) and any(mk > 2048 for mk in planes_rows), planes_rows  # both paths exercised
     cols = []
     for r, e in enumerate(grp.engines):
-        got, c0, c1 = e.shard_counters()
+        got, c0, c1 = e.shard_counters()  # the shares of the LAST update (ekf_shard_counters)
         cols.append((c0, c1))
         # rows of B in the sweep (<= 2048 rows): G by symmetry, so a rank's columns are exactly the state rows it holds (the last
-        # rank's run to n_pad); inverse + GEMM above: its share rounded to 32 columns (ekf_shard_counters)
+        # rank's run to n_pad); inverse + GEMM above: its share rounded to 32 columns
         _, _, lo, hi = e.shard_info()
         own_exact = (n_pad if r == world - 1 else hi) - lo
-        want = sum((n_pad - (own_exact if mk <= 2048 else c1 - c0)) * 5 * mk for mk in planes_rows)
+        r32 = lambda v: (v + 31) // 32 * 32  # noqa: E731
+        own_rounded = (n_pad if r == world - 1 else min(n_pad, r32(hi))) - (0 if r == 0 else min(n_pad, r32(lo)))
+        assert c1 - c0 == (own_exact if planes_rows[-1] <= 2048 else own_rounded), (r, c0, c1, own_exact, own_rounded)
+        want = sum((n_pad - (own_exact if mk <= 2048 else own_rounded)) * 5 * mk for mk in planes_rows)
         assert got == want, (r, got, want)
     assert cols[0][0] == 0 and cols[-1][1] == n_pad and all(cols[r][1] == cols[r + 1][0] for r in range(world - 1)), cols
     share = [(c1 - c0) / n_pad for c0, c1 in cols]
