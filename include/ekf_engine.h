@@ -204,10 +204,13 @@ int ekf_set_async_errors(EkfEngine *e, int on);
 enum { EKF_UPDATE_PATH_AUTO = 0, EKF_UPDATE_PATH_SWEEP = 1, EKF_UPDATE_PATH_GEMM = 2 };
 int ekf_set_update_path(EkfEngine *e, int path);
 /* How the blocked Cholesky sweep of S (replaces S.inv(), EKF/Update.cpp:108) is launched: EKF_SWEEP_SINGLE one 32-row panel per
- * launch, EKF_SWEEP_PAIRS two panels per launch with a 64 x 64 look-ahead inverse, EKF_SWEEP_AUTO (the default) single launches
- * while a launch is bound by its look-ahead factorisation and pairs once the rows of B = inv(L) H P are the longest role
- * (large maps).  Same result to rounding; a tuning / test knob. */
-enum { EKF_SWEEP_PAIRS = 0, EKF_SWEEP_SINGLE = 1, EKF_SWEEP_AUTO = 2 };
+ * launch, EKF_SWEEP_PAIRS two panels per launch with a 64 x 64 look-ahead inverse, EKF_SWEEP_PERSISTENT ONE launch per update
+ * (a resident critical workgroup factorises panel after panel, tile and row-block workers follow it through flags; updates of at
+ * most 2048 rows on an unsharded engine in the fp64 and the exact configuration, otherwise launches as under AUTO),
+ * EKF_SWEEP_LAUNCHES the round-4 rule (single launches while a launch is bound by its look-ahead factorisation, pairs once the
+ * rows of B = inv(L) H P are the longest role), EKF_SWEEP_AUTO (the default): persistent where it applies, else LAUNCHES
+ * (DESIGN.md 4.3).  Same result to rounding; a tuning / test knob. */
+enum { EKF_SWEEP_PAIRS = 0, EKF_SWEEP_SINGLE = 1, EKF_SWEEP_AUTO = 2, EKF_SWEEP_PERSISTENT = 3, EKF_SWEEP_LAUNCHES = 4 };
 int ekf_set_sweep_mode(EkfEngine *e, int mode);
 
 /* -- matcher mode B: image in, no detector ----------------------------------------------------------------

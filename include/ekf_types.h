@@ -97,7 +97,9 @@ enum {
     EKF_ERR_NON_FINITE = 4,
     EKF_ERR_HIP = 5,
     EKF_ERR_NO_DEVICE = 6,
-    EKF_ERR_COMM = 7
+    EKF_ERR_COMM = 7,
+    EKF_ERR_TIMEOUT = 8 /* a device-side wait of the persistent Cholesky sweep exceeded its bound (its workgroups were not all resident:
+                           another persistent launch of another process on the same GPU?); the update is incomplete */
 };
 
 #ifdef __cplusplus

@@ -410,4 +410,236 @@ __device__ __forceinline__ bool block_chol_inv32_v4(double (*a)[CH_NB + 1], doub
     return ok;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// block_chol_inv32_w2: the same elimination of [A | I] with 4x4 block pivots, WITHOUT a workgroup barrier on the pivot chain.
+// Two free-running wavefronts: wavefront 0 owns the A half (four 16x16 accumulator blocks of the full symmetric matrix),
+// wavefront 1 the identity half (three blocks: X01 stays zero); the other wavefronts of the workgroup wait at the final barrier.
+//   * the 4x4 pivot block reaches every lane of wavefront 0 through v_readlane (20 scalar reads of the lane's own accumulator
+//     registers: no LDS round trip, no barrier);
+//   * the panel column A[r][4J + k] = A[4J + k][r] (symmetry) is gathered across the four 16-lane rows through a private LDS
+//     image written [column][k] (512 contiguous bytes, read back as 32 contiguous bytes per lane): a single wavefront's LDS
+//     operations complete in order, so only s_waitcnt stands between the store and the load, and both run beside the
+//     scalar LDL' chain of the pivot block instead of in front of it;
+//   * the multipliers -W (already in MFMA A-operand layout) go to wavefront 1 through LDS with one flag word per step (eight
+//     distinct slots: nothing is ever reused, so wavefront 0 never waits for wavefront 1), which trails by less than a step and
+//     applies them to its own pivot rows;
+//   * MFMAs that cannot change a live element are not issued (16 for the A half, 13 for the identity half), and the block that
+//     holds the next pivot rows is issued first.
+// v4 above costs ~1270 cycles per pivot step (LDS publish, barrier over four wavefronts, broadcast reads, chain, MFMA); here the
+// step is the chain alone: readlane -> LDL' -> column of inv(D) -> dot with the gathered panel -> MFMA.
+// `a`: lower triangle valid on entry, overwritten (scratch); `x`: inv(L).  256 threads must call it; returns uniformly.
+__device__ __forceinline__ double w2_readlane(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+template <int NEWTON = 2>
+__device__ __forceinline__ double w2_rcp(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+#pragma unroll
+    for (int i = 0; i < NEWTON; ++i) r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+#ifndef W2_STAMP
+#define W2_STAMP(slot) // scripts/micro/chol32_micro.hip defines it: shader-clock stamps of the two wavefronts
+#endif
+struct W2Idle {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+// `other(h)`: what wavefronts 2 and 3 (h = 0, 1) do while wavefronts 0 and 1 factorise -- e.g. the persistent sweep's critical
+// workgroup fetches the next two tiles of S (chol_persist.h); it must not touch `a`, `x` or a workgroup barrier.
+// LDS scratch of block_chol_inv32_w2 (17 KB): the caller owns it (a kernel whose other roles need the space overlays it)
+struct __attribute__((aligned(32))) W2Scratch {
+    double prow[8][CH_NB][4]; // prow[J][c][k] = A[4J + k][c] (= A[c][4J + k])
+    double wbuf[8][2][64];    // -W of step J in A-operand layout, block rows 0 / 1
+    double fac[8][10];
+    int wflag[8];
+    int okflag;
+};
+
+template <int NEWTON = 2, class OTHER = W2Idle>
+__device__ __forceinline__ bool block_chol_inv32_w2(double (*a)[CH_NB + 1], double (*x)[CH_NB + 1], W2Scratch *ws, OTHER &&other = W2Idle())
+{
+    typedef double acc4 __attribute__((ext_vector_type(4)));
+    double(*prow)[CH_NB][4] = ws->prow;
+    double(*wbuf)[2][64] = ws->wbuf;
+    double(*fac)[10] = ws->fac;
+    int *wflag = ws->wflag;
+    int &okflag = ws->okflag;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int lc = lane & 15, lq = lane >> 4;
+    if (t < 8) wflag[t] = 0;
+    if (t == 8) okflag = 1;
+    __syncthreads();
+    if (w == 0) {
+        acc4 m[2][2];
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r = 16 * bi + lq + 4 * v, c = 16 * bj + lc;
+                    m[bi][bj][v] = c <= r ? a[r][c] : a[c][r];
+                }
+        bool ok = true;
+        double nw1_pend = 0.0, bv1_pend = 0.0; // the m[1][1] update of the previous step, issued behind this step's LDL' chain
+#pragma unroll
+        for (int J = 0; J < 8; ++J) {
+            const int j0 = 4 * J, bp = J >> 2, v0 = J & 3, cc = j0 & 15;
+            W2_STAMP(4 * J)
+            const double bv0 = m[bp][0][v0], bv1 = m[bp][1][v0]; // pivot row 4J + lq at columns lc and 16 + lc
+            // panel image for the gather (columns left of the pivot block are dead: J >= 4 needs columns 16.. only), requested back
+            // at once: the LDS round trip runs beside the scalar chain below, not behind it
+            if (J < 4) prow[J][lc][lq] = bv0;
+            prow[J][16 + lc][lq] = bv1;
+            asm volatile("" ::: "memory"); // (one wavefront: its LDS stores and loads complete in order; the compiler must keep that order too)
+            double p0[4] = {0.0, 0.0, 0.0, 0.0}, p1[4];
+            if (J < 7) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) p1[k] = prow[J][16 + lc][k];
+                if (J < 3) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) p0[k] = prow[J][lc][k];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the pivot block, to every lane: D[k][k'] = A[4J + k][4J + k'] sits in lane 16 k + cc + k' of bv_{bp}
+            const double bvp = bp ? bv1 : bv0;
+            const double d00 = w2_readlane(bvp, cc);
+            const double d10 = w2_readlane(bvp, 16 + cc), d11 = w2_readlane(bvp, 16 + cc + 1);
+            const double d20 = w2_readlane(bvp, 32 + cc), d21 = w2_readlane(bvp, 32 + cc + 1), d22 = w2_readlane(bvp, 32 + cc + 2);
+            const double d30 = w2_readlane(bvp, 48 + cc), d31 = w2_readlane(bvp, 48 + cc + 1), d32 = w2_readlane(bvp, 48 + cc + 2),
+                         d33 = w2_readlane(bvp, 48 + cc + 3);
+            const double i0 = w2_rcp<NEWTON>(d00);
+            const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+            const double e11 = d11 - l10 * d10;
+            const double e21 = d21 - l20 * d10, e31 = d31 - l30 * d10;
+            const double i1 = w2_rcp<NEWTON>(e11);
+            const double l21 = e21 * i1, l31 = e31 * i1;
+            const double e22 = d22 - l20 * d20 - l21 * e21;
+            const double e32 = d32 - l30 * d20 - l31 * e21;
+            const double i2 = w2_rcp<NEWTON>(e22);
+            const double l32 = e32 * i2;
+            const double e33 = d33 - l30 * d30 - l31 * e31 - l32 * e32;
+            const double i3 = w2_rcp<NEWTON>(e33);
+            W2_STAMP(4 * J + 1)
+            ok = ok && d00 > 0.0 && e11 > 0.0 && e22 > 0.0 && e33 > 0.0;
+            if (lane == 0) {
+                double *f = fac[J];
+                f[0] = l10; f[1] = l20; f[2] = l30; f[3] = l21; f[4] = l31; f[5] = l32;
+                f[6] = i0; f[7] = i1; f[8] = i2; f[9] = i3;
+            }
+            if (J == 7) break;
+            // the previous step's update of block (1, 1) -- nobody needs it before the fifth pivot step -- goes into the matrix
+            // pipe here, behind the chain that only needed blocks (0, 0) and (0, 1)
+            if (J >= 1 && J <= 3) {
+                __builtin_amdgcn_sched_barrier(0);
+                m[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(nw1_pend, bv1_pend, m[1][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // column lq of inv(D): solve D e = unit(lq)
+            const double u1 = lq == 1 ? 1.0 : 0.0, u2 = lq == 2 ? 1.0 : 0.0, u3 = lq == 3 ? 1.0 : 0.0;
+            const double y0 = lq == 0 ? 1.0 : 0.0;
+            const double y1 = u1 - l10 * y0;
+            const double y2 = u2 - l20 * y0 - l21 * y1;
+            const double y3 = u3 - l30 * y0 - l31 * y1 - l32 * y2;
+            const double q3 = y3 * i3;
+            const double q2 = y2 * i2 - l32 * q3;
+            const double q1 = y1 * i1 - l21 * q2 - l31 * q3;
+            const double q0 = y0 * i0 - l10 * q1 - l20 * q2 - l30 * q3;
+            // W[r][lq] = sum_k' A[r][4J + k'] inv(D)[k'][lq] for the lane's rows lc (block row 0, live while J < 3) and 16 + lc
+            double nw0 = 0.0;
+            double nw1 = -((p1[0] * q0 + p1[1] * q1) + (p1[2] * q2 + p1[3] * q3));
+            if (16 + lc < j0 + 4) nw1 = 0.0;
+            if (J < 3) {
+                nw0 = -((p0[0] * q0 + p0[1] * q1) + (p0[2] * q2 + p0[3] * q3));
+                if (lc < j0 + 4) nw0 = 0.0;
+            }
+            W2_STAMP(4 * J + 2)
+            wbuf[J][0][lane] = nw0;
+            wbuf[J][1][lane] = nw1;
+            // data, then flag: a wavefront's LDS operations are processed in issue order, so no wait is needed between them (a
+            // workgroup-scope release fence would also drain this wavefront's global-memory counter)
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&wflag[J], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+            // the blocks with the next pivot rows now; block (1, 1) of the steps before the fourth waits (see above)
+            if (J < 3) {
+                m[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(nw0, bv0, m[0][0], 0, 0, 0);
+                m[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(nw0, bv1, m[0][1], 0, 0, 0);
+                nw1_pend = nw1;
+                bv1_pend = bv1;
+            } else {
+                m[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(nw1, bv1, m[1][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            W2_STAMP(4 * J + 3)
+        }
+        if (!ok && lane == 0) okflag = 0;
+    } else if (w == 1) {
+        acc4 x00, x10, x11;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = lq + 4 * v;
+            x00[v] = r == lc ? 1.0 : 0.0;
+            x10[v] = 0.0;
+            x11[v] = r == lc ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int J = 0; J < 7; ++J) {
+            const int v0 = J & 3;
+            while (__hip_atomic_load(&wflag[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            W2_STAMP(32 + J)
+            const double nw0 = wbuf[J][0][lane], nw1 = wbuf[J][1][lane];
+            if (J < 3) {
+                const double b0 = x00[v0];
+                x00 = __builtin_amdgcn_mfma_f64_16x16x4f64(nw0, b0, x00, 0, 0, 0);
+                x10 = __builtin_amdgcn_mfma_f64_16x16x4f64(nw1, b0, x10, 0, 0, 0);
+            } else if (J == 3) {
+                x10 = __builtin_amdgcn_mfma_f64_16x16x4f64(nw1, x00[v0], x10, 0, 0, 0);
+            } else {
+                const double b0 = x10[v0], b1 = x11[v0];
+                x10 = __builtin_amdgcn_mfma_f64_16x16x4f64(nw1, b0, x10, 0, 0, 0);
+                x11 = __builtin_amdgcn_mfma_f64_16x16x4f64(nw1, b1, x11, 0, 0, 0);
+            }
+        }
+        // X to LDS (into `a`, which wavefront 0 has read completely before its first flag: this wavefront passed flag 6)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            a[lq + 4 * v][lc] = x00[v];
+            a[lq + 4 * v][16 + lc] = 0.0;
+            a[16 + lq + 4 * v][lc] = x10[v];
+            a[16 + lq + 4 * v][16 + lc] = x11[v];
+        }
+    } else {
+        other(w - 2);
+    }
+    W2_STAMP(40 + w)
+    __syncthreads();
+    W2_STAMP(44)
+    // inv(L) = blockdiag(inv(chol(D_J))) X : unit-lower solve inside each 4-row group, then sqrt of the pivots
+    const int r = t >> 3, c0 = (t & 7) * 4;
+    const int base = r & ~3, q = r & 3;
+    const double *f = fac[r >> 2];
+    const double sr = sqrt(f[6 + q]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e;
+        const double u0 = a[base][c];
+        const double u1 = a[base + 1][c] - f[0] * u0;
+        const double u2 = a[base + 2][c] - f[1] * u0 - f[3] * u1;
+        const double u3 = a[base + 3][c] - f[2] * u0 - f[4] * u1 - f[5] * u2;
+        const double res = q == 0 ? u0 : (q == 1 ? u1 : (q == 2 ? u2 : u3));
+        x[r][c] = (c <= r) ? res * sr : 0.0;
+    }
+    const bool okr = okflag != 0;
+    __syncthreads();
+    W2_STAMP(45)
+    return okr;
+}
+
 } // namespace ekf

@@ -116,6 +116,7 @@ const char *ekf_last_error(const EkfEngine *e) { return e ? e->err.c_str() : "nu
 void ekf_engine_destroy(EkfEngine *e)
 {
     if (!e) return;
+    if (e->counted_alive) --g_engines_alive;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     DeviceArrays &d = e->d;
@@ -125,7 +126,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
                     d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.W, d.Wf, d.G, d.LL, d.LLf, d.Tbuf, d.gates, d.cell_resp, d.cell_xy,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.sq_part, d.diag_save, d.cam_part, d.cam_save, d.HPc, d.Gc, d.Bc, d.zvec, d.yvec,
-                    e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq, d.Bq, d.Bexp, d.Lq, d.Lexp, d.Grow, d.Pdiag, d.Bstage, d.Wq, d.Gq, d.Wexp, d.Gexp};
+                    e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq, d.sweep_ctl, d.Bq, d.Bexp, d.Lq, d.Lexp, d.Grow, d.Pdiag, d.Bstage, d.Wq, d.Gq, d.Wexp, d.Gexp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &kv : e->pu_tables)
@@ -311,6 +312,11 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     ALLOC(d.Dinv, mw * e->ldW);
     ALLOC(d.W, mw * e->ldW);
     ALLOC(d.Tbuf, mw * e->ldW);
+    {   // flags of the persistent sweep (chol_persist.h): done / lrdy tables of (B_SWEEP_MAX / 32 + 2)^2 words each, zeroed here once
+        uint8_t *raw = nullptr;
+        if ((st = dalloc(&raw, (size_t)256 + sizeof(unsigned) * 2 * (B_SWEEP_MAX / NB + 2) * (B_SWEEP_MAX / NB + 2))) != hipSuccess) return fail(st, "hipMalloc sweep_ctl");
+        d.sweep_ctl = raw;
+    }
     if (e->f32 && !e->exact) ALLOC(d.Wf, mw * e->ldW);
     ALLOC(d.mHs, 14 * cap);
     ALLOC(d.mHf, 12 * cap);
@@ -347,6 +353,8 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     }
     e->shard_feat_begin.assign(world + 1, 0);
     e->exchange_hook = exchange_rows;
+    ++g_engines_alive;
+    e->counted_alive = true;
     *out = e;
     return EKF_OK;
 }
@@ -1535,7 +1543,7 @@ int ekf_set_update_path(EkfEngine *e, int path)
 
 int ekf_set_sweep_mode(EkfEngine *e, int mode)
 {
-    if (!e || mode < EKF_SWEEP_PAIRS || mode > EKF_SWEEP_AUTO) return EKF_ERR_INVALID_ARG;
+    if (!e || mode < EKF_SWEEP_PAIRS || mode > EKF_SWEEP_LAUNCHES) return EKF_ERR_INVALID_ARG;
     e->sweep_mode = mode;
     return EKF_OK;
 }

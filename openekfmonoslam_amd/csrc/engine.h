@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <map>
 #include <string>
@@ -138,6 +139,7 @@ struct DeviceArrays {
     double *yvec = nullptr;      // [mcap + slack]: y = inv(L)' z = inv(S) nu (fp32 configuration: dx = (H P)' y)
     uint8_t *mask = nullptr;   // generic byte mask output (rescue)
     void *pu_tilemap = nullptr; // int2 (ti, tj) per upper-triangle tile, XCD-friendly order
+    void *sweep_ctl = nullptr;  // flags of the persistent Cholesky sweep (chol_persist.h), zeroed once
     int8_t *Bq = nullptr;       // EKF_PRECISION_F32_EXACT: PX_S digit planes of B, each [bq_rows / 16][ldP][16] bytes (kernels_pexact.hip)
     int *Bexp = nullptr;        // its column scales (biased exponents), ldP ints
     int8_t *Lq = nullptr;       // digit planes of L for the rows of B formed from planes (chol_bplanes.h): PX_S x lq_nbk^2 KB
@@ -203,7 +205,10 @@ struct EkfEngine {
     void *xchg_user = nullptr;
     int n_cus = 256;           // compute units of the device (launch-shape decisions)
     int b_path = 0;            // ekf_set_update_path: 0 by size (B_SWEEP_MAX), 1 B in the sweep, 2 inverse + GEMM
-    int sweep_mode = 2;        // ekf_set_sweep_mode: 2 by size (default), 1 one panel per launch (k_chol_step), 0 two panels per launch (chol_pair.h)
+    int sweep_mode = 2;        // ekf_set_sweep_mode: EKF_SWEEP_* (2 AUTO: one persistent launch per update where it applies, chol_persist.h)
+    unsigned ps_epoch = 0, ps_arrive = 0; // persistent sweep: epoch of its flags, tickets handed out so far
+    bool counted_alive = false; // this engine is in g_engines_alive (set at the end of a successful create)
+    int ps_cap[2] = {0, 0};    // resident workgroups of k_chol_persist<false / true> on this device (0: not asked yet, -1: unusable)
     bool async_errors = false; // ekf_set_async_errors: no read-back at the end of a step
     bool p_exact_sym = false; // P known to be bitwise symmetric (engine-maintained invariant)
     int n_pred = 0;           // predictions of the last full prediction
@@ -250,6 +255,8 @@ struct EkfEngine {
 };
 
 namespace ekf {
+
+extern std::atomic<int> g_engines_alive; // engines of this process (kernels_update.hip: persistent sweeps of different engines are chained)
 
 // C[i][j] = alpha sum_k X[k][i] Y[k][j] (kernels_gemm.hip); batch element b adds b * (xb, yb, cb, ctb) elements
 struct XtyArgs {

@@ -17,6 +17,9 @@
 #include "engine.h"
 #include <vector>
 #include <cstdio>
+#include <mutex>
+#include <cstdlib>
+#include <atomic>
 #include "chol32.h"
 #include "mma_tile.h"
 #include "digit_planes.h"
@@ -251,6 +254,7 @@ k_s_unpack(const double *St, int ldst, double *S, int ldS, int m, int own_lo, in
 
 #include "chol_pair.h" // the two-panels-per-launch variant of the sweep below, and the 32^3 product helpers both use
 #include "chol_bplanes.h" // EKF_PRECISION_F32_EXACT: the rows of B from int8 digit planes
+#include "chol_persist.h" // the whole sweep as one persistent launch
 
 // -------------------------------------------------------------------------------------- blocked Cholesky sweep
 // Right-looking sweep over [ S | nu ], panel width NB = 32, ONE launch per panel (k_chol_step).  The only serial
@@ -1249,6 +1253,105 @@ k_fix_normalize(T *P, int ld, int n, RowMap rm, const double *dsave, const doubl
 // P-update launcher lives in kernels_pupdate.hip
 void launch_p_update(EkfEngine *e, int m_pad, int m);
 
+// ---------------------------------------------------------------------------------------------- persistent sweep launcher
+// Two persistent launches that are each only partly resident would wait for each other's workgroups until the watchdog ends
+// them: sweeps of different engines of this process on one device are chained by an event (the second waits for the first).
+static std::mutex g_ps_mu;
+static hipEvent_t g_ps_last[16] = {};
+static const EkfEngine *g_ps_owner[16] = {};
+std::atomic<int> g_engines_alive{0}; // engines of this process (engine.cpp counts them)
+
+#ifdef EKF_SWEEP_TRACE // debug builds only (scripts/persist_trace.py): the stamps of the LAST persistent sweep launched while enabled
+constexpr int PS_TRACE_WORDS = 4096;
+static unsigned long long *g_ps_trace = nullptr;
+static int g_ps_trace_on = 0, g_ps_trace_m = 0;
+extern "C" int ekf_debug_persist_trace(int enable, unsigned long long *out, int *m)
+{
+    g_ps_trace_on = enable;
+    if (out && g_ps_trace) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(out, g_ps_trace, sizeof(unsigned long long) * PS_TRACE_WORDS, hipMemcpyDeviceToHost);
+        if (m) *m = g_ps_trace_m;
+    }
+    return 0;
+}
+#endif
+
+// resident workgroups of k_chol_persist<PL> on the engine's device (two per CU at most), -1 if the query fails
+template <bool PL>
+static int persist_capacity(EkfEngine *e)
+{
+    int &cap = e->ps_cap[PL ? 1 : 0];
+    if (cap == 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chol_persist<PL>, 256, 0) != hipSuccess || per_cu < 1) cap = -1;
+        else cap = std::min(per_cu, 2) * e->n_cus;
+    }
+    return cap;
+}
+
+// one launch for the whole sweep of an update of m rows; false: not launched (the caller runs the launch-per-panel sweep)
+template <bool PL>
+static bool launch_persistent_sweep(EkfEngine *e, int m, const double *G, double *Bout, int n_bcols, const BPlanes &bp)
+{
+    const int cap = persist_capacity<PL>(e);
+    const int nbk = (m + NB - 1) / NB;
+    if (cap < 64 || nbk > B_SWEEP_MAX / NB || !e->d.sweep_ctl) return false;
+    const int ntiles = (nbk + 1) * (nbk + 2) / 2 - 1;
+    // Block order (chol_persist.h, PsArgs::n_cus): [chain][B workers][tile workers up to block n_cus - 1], then -- in-order dispatch
+    // deals the blocks n_cus, n_cus + 1, ... to the CUs a second time -- empty spacers on the chain's and the B workers' CUs and a
+    // second batch of tile workers beside the first: the rows of B (int8 MFMA, the longest role) and the chain share their CU with
+    // nobody.  One B worker per 32-column block while at least 32 CUs are left for tiles; a tile worker owns at most 64 tiles.
+    const int C = e->n_cus;
+    const int n_b = std::max(1, std::min(n_bcols, C - 1 - 32));
+    const int first = C - 1 - n_b;
+    int n_t = std::min(ntiles, cap >= 2 * C ? 2 * first : first);
+#ifdef EKF_SWEEP_TRACE // tuning runs of the debug build only
+    if (const char *ev = std::getenv("EKF_PS_NT")) n_t = std::max(1, std::min(n_t, atoi(ev)));
+#endif
+    n_t = std::max(n_t, (ntiles + 63) / 64);
+    if (n_t > (cap >= 2 * C ? 2 * first : first)) return false;
+    const int workers = 1 + n_b + n_t;
+    const int grid = n_t <= first ? workers : C + n_b + 1 + (n_t - first);
+    if (e->ps_epoch >= (1u << 22) || e->ps_epoch == 0) { // (re)start the epochs of the flags well before they can wrap
+        if (hipMemsetAsync(e->d.sweep_ctl, 0, sweep_ctl_bytes(), e->stream) != hipSuccess) return false;
+        e->ps_epoch = 0;
+        e->ps_arrive = 0;
+    }
+    ++e->ps_epoch;
+    PsArgs a{};
+    a.S = e->d.S; a.LL = e->d.LL; a.ldS = e->ldS; a.m = m; a.nbk = nbk;
+    a.V = e->d.Dinv; a.ldw = e->ldW; a.nu = e->d.nu; a.zvec = e->d.zvec; a.counts = e->d.counts;
+    a.G = G; a.Bout = Bout; a.ld = e->ldP; a.bp = bp;
+    a.ctl = (SweepCtl *)e->d.sweep_ctl; a.eb = e->ps_epoch * PS_EPOCH_STEP; a.arrive_base = e->ps_arrive;
+    a.n_b = n_b; a.n_bcols = n_bcols; a.n_t = n_t; a.n_cus = C;
+    a.trace = nullptr;
+#ifdef EKF_SWEEP_TRACE
+    if (g_ps_trace_on) {
+        if (!g_ps_trace && hipMalloc(&g_ps_trace, sizeof(unsigned long long) * PS_TRACE_WORDS) != hipSuccess) g_ps_trace = nullptr;
+        if (g_ps_trace) {
+            (void)hipMemsetAsync(g_ps_trace, 0, sizeof(unsigned long long) * PS_TRACE_WORDS, e->stream);
+            a.trace = g_ps_trace;
+            g_ps_trace_m = m;
+        }
+    }
+#endif
+    e->ps_arrive += (unsigned)workers;
+    const int dev = e->device >= 0 && e->device < 16 ? e->device : 0;
+    if (g_engines_alive.load() > 1) {
+        // more than one engine in this process: order this sweep behind the last persistent sweep of any other engine on the device
+        std::lock_guard<std::mutex> lk(g_ps_mu);
+        if (!g_ps_last[dev] && hipEventCreateWithFlags(&g_ps_last[dev], hipEventDisableTiming) != hipSuccess) g_ps_last[dev] = nullptr;
+        if (g_ps_last[dev] && g_ps_owner[dev] && g_ps_owner[dev] != e) (void)hipStreamWaitEvent(e->stream, g_ps_last[dev], 0);
+        k_chol_persist<PL><<<grid, 256, 0, e->stream>>>(a);
+        if (g_ps_last[dev]) (void)hipEventRecord(g_ps_last[dev], e->stream);
+        g_ps_owner[dev] = e;
+    } else {
+        k_chol_persist<PL><<<grid, 256, 0, e->stream>>>(a);
+    }
+    return true;
+}
+
 // T: storage type of P; TB: type of H P, of its gathered rows G, of B = inv(L) G and of the arithmetic that forms it
 // (TB = T except EKF_PRECISION_F32_EXACT: T = float, TB = double, the downdate by kernels_pexact.hip)
 template <typename T, typename TB>
@@ -1316,6 +1419,12 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             if (e->hook_rc) return;
         }
     }
+    // ONE persistent launch for the whole sweep (chol_persist.h) where it applies: B inside the sweep, at most B_SWEEP_MAX rows, one
+    // GPU, fp64 arithmetic of B (the fp64 and the exact configuration); otherwise the launch-per-panel sweep below
+    const int lmode = (e->sweep_mode == EKF_SWEEP_PERSISTENT || e->sweep_mode == EKF_SWEEP_LAUNCHES) ? EKF_SWEEP_AUTO : e->sweep_mode;
+    bool persist = (e->sweep_mode == EKF_SWEEP_AUTO || e->sweep_mode == EKF_SWEEP_PERSISTENT) && b_in_sweep && m_pad <= B_SWEEP_MAX &&
+                   !sharded && sizeof(TB) == 8 && e->d.sweep_ctl != nullptr;
+    if (persist && (planes_b ? persist_capacity<true>(e) : persist_capacity<false>(e)) < 64) persist = false;
     double *V = e->d.Dinv, *W = b_in_sweep ? nullptr : e->d.W; // W = inv(L)' (and L row-major in LL): the GEMM path's
     float *Wf = sizeof(TB) == 4 && !b_in_sweep ? e->d.Wf : nullptr;
     {
@@ -1353,7 +1462,8 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         } else
         k_assemble_S<TB><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts,
-                                             planes_b ? e->d.Lexp : nullptr, planes_b && !sharded ? e->d.Grow : nullptr, 0, M, nullptr, 0, 1);
+                                             planes_b ? e->d.Lexp : nullptr, planes_b && !sharded ? e->d.Grow : nullptr, 0, M, nullptr, 0,
+                                             persist ? 0 : 1); // (the persistent sweep's chain workgroup factorises the first block itself)
     }
     const int n_bblocks = b_in_sweep ? cb1 - cb0 : 0; // row block k of B = inv(L) G rides in the launch of panel k (sharded planes: own column blocks)
     hipEvent_t sw0 = nullptr, sw1 = nullptr;
@@ -1376,17 +1486,30 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     constexpr int PAIR_ROWS = 3072; // rows of the trailing matrix from which a sweep without the B role starts in pairs
     bool have_pair = false;
     int n_sweep_launches = 0;
-    for (int k0 = 0; k0 < m;) {
+    if (persist) {
+        bool launched = false;
+        if constexpr (sizeof(TB) == 8) {
+            if (planes_b) launched = launch_persistent_sweep<true>(e, m, (const double *)G, nullptr, cb1 - cb0, bp);
+            else launched = launch_persistent_sweep<false>(e, m, (const double *)G, (double *)A, n_pad / NB, BPlanes{});
+        }
+        if (!launched) { // cannot happen after the capacity check above; the first block still wants its factorisation
+            e->err = "persistent sweep could not be launched";
+            e->hook_rc = EKF_ERR_HIP;
+            return;
+        }
+        n_sweep_launches = 1;
+    }
+    for (int k0 = 0; k0 < m && !persist;) {
         ++n_sweep_launches;
         // (without the rows of B -- inverse + GEMM path -- a big sweep is bound by streaming the fp64 trailing matrix once per
         // launch: 2 x 8 m^2 bytes; pairs stream it once per two panels: N = 5000, m = 3000-4500: 16.6 -> 15.4 us per panel)
-        const bool want_pairs = e->sweep_mode == EKF_SWEEP_PAIRS ||
-                                (e->sweep_mode == EKF_SWEEP_AUTO &&
+        const bool want_pairs = lmode == EKF_SWEEP_PAIRS ||
+                                (lmode == EKF_SWEEP_AUTO &&
                                  (b_in_sweep ? (long long)(k0 / NB) * n_pad >= PAIR_FROM : m - k0 >= PAIR_ROWS));
         // rows of B from digit planes (chol_bplanes.h b_pair_rows_planes): two panels per launch halve the re-reads of the finished
         // planes and the rounds of workgroups of a wide map -- N = 2000: 15.4 -> 13.3 us per panel; N = 1000: 9.9 either way, so
         // AUTO takes pairs from 8192 state columns on (profiles/r04_sweep_pairs_planes.txt)
-        const bool want_pairs_pl = e->sweep_mode == EKF_SWEEP_PAIRS || (e->sweep_mode == EKF_SWEEP_AUTO && n_pad >= 8192);
+        const bool want_pairs_pl = lmode == EKF_SWEEP_PAIRS || (lmode == EKF_SWEEP_AUTO && n_pad >= 8192);
         const bool pair_launch = planes_b ? (have_pair || want_pairs_pl) : (have_pair || want_pairs);
         const int kbA = min(NB, m - k0);
         const int kbB = have_pair ? max(0, min(NB, m - k0 - NB)) : 0;

@@ -82,6 +82,7 @@ STATUS_NAMES = {
     5: "EKF_ERR_HIP",
     6: "EKF_ERR_NO_DEVICE",
     7: "EKF_ERR_COMM",
+    8: "EKF_ERR_TIMEOUT",
 }
 
 

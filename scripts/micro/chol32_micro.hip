@@ -7,6 +7,10 @@
 #include <cstdio>
 #include <vector>
 
+#ifdef W2_TRACE // -DW2_TRACE: shader-clock stamps inside block_chol_inv32_w2 (lane 0 of each wavefront), printed for the last call
+__device__ long long g_w2_stamps[64];
+#define W2_STAMP(slot) if ((threadIdx.x & 63) == 0) g_w2_stamps[(slot)] = clock64();
+#endif
 #include "../../openekfmonoslam_amd/csrc/chol32.h"
 
 using namespace ekf;
@@ -157,6 +161,7 @@ template <int V>
 __global__ void __launch_bounds__(256) k_run(const double *A, double *Linv, long long *ticks, int reps)
 {
     __shared__ double sa[CH_NB][CH_NB + 1], sx[CH_NB][CH_NB + 1], srs[CH_NB];
+    __shared__ W2Scratch w2s;
     long long c_acc = 0, w_acc = 0;
     bool ok = true;
     for (int it = 0; it < reps; ++it) {
@@ -169,7 +174,9 @@ __global__ void __launch_bounds__(256) k_run(const double *A, double *Linv, long
         if (V == 0) ok = block_chol_inv32(sa, sx, srs) && ok;
         else if (V == 1) ok = block_chol_inv32_bp(sa, sx) && ok;
         else if (V == 2) ok = block_chol_inv32_mf(sa, sx) && ok;
-        else ok = block_chol_inv32_v4(sa, sx) && ok;
+        else if (V == 3) ok = block_chol_inv32_v4(sa, sx) && ok;
+        else if (V == 4) ok = block_chol_inv32_w2<2>(sa, sx, &w2s) && ok;
+        else ok = block_chol_inv32_w2<1>(sa, sx, &w2s) && ok;
         c_acc += clock64() - c0;
         w_acc += wall_clock64() - w0;
     }
@@ -177,8 +184,37 @@ __global__ void __launch_bounds__(256) k_run(const double *A, double *Linv, long
     if (threadIdx.x == 0) { ticks[0] = c_acc; ticks[1] = w_acc; ticks[2] = ok; }
 }
 
+// accuracy of the hardware reciprocal estimate and of its Newton refinements (relative error, max over 64 K random arguments)
+__global__ void k_rcp_err(double *out)
+{
+    double e0 = 0, e1 = 0, e2 = 0;
+    unsigned s = 1234567u + threadIdx.x * 7919u;
+    for (int i = 0; i < 256; ++i) {
+        s = s * 1664525u + 1013904223u;
+        const double d = ldexp(1.0 + (double)(s >> 8) / (1 << 24), (int)(s & 63) - 20);
+        const double ex = 1.0 / d;
+        double r = __builtin_amdgcn_rcp(d);
+        e0 = fmax(e0, fabs(r - ex) / ex);
+        r = fma(fma(-d, r, 1.0), r, r);
+        e1 = fmax(e1, fabs(r - ex) / ex);
+        r = fma(fma(-d, r, 1.0), r, r);
+        e2 = fmax(e2, fabs(r - ex) / ex);
+    }
+    out[threadIdx.x * 3] = e0; out[threadIdx.x * 3 + 1] = e1; out[threadIdx.x * 3 + 2] = e2;
+}
+
 int main()
 {
+    {
+        double *dE;
+        hipMalloc(&dE, 256 * 3 * 8);
+        k_rcp_err<<<1, 256>>>(dE);
+        std::vector<double> hE(256 * 3);
+        hipMemcpy(hE.data(), dE, hE.size() * 8, hipMemcpyDeviceToHost);
+        double m[3] = {0, 0, 0};
+        for (int i = 0; i < 256; ++i) for (int k = 0; k < 3; ++k) m[k] = std::fmax(m[k], hE[i * 3 + k]);
+        std::printf("v_rcp_f64 relative error: raw %.2e, one Newton step %.2e, two %.2e\n", m[0], m[1], m[2]);
+    }
     const int n = CH_NB;
     std::vector<double> M(n * n), A(n * n, 0.0);
     unsigned s = 12345;
@@ -193,7 +229,7 @@ int main()
     long long *dT;
     hipMalloc(&dA, n * n * 8); hipMalloc(&dL, n * n * 8); hipMalloc(&dT, 64);
     hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < 6; ++v) {
         const int reps = 50;
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
@@ -202,7 +238,9 @@ int main()
             if (v == 0) k_run<0><<<1, 256>>>(dA, dL, dT, reps);
             else if (v == 1) k_run<1><<<1, 256>>>(dA, dL, dT, reps);
             else if (v == 2) k_run<2><<<1, 256>>>(dA, dL, dT, reps);
-            else k_run<3><<<1, 256>>>(dA, dL, dT, reps);
+            else if (v == 3) k_run<3><<<1, 256>>>(dA, dL, dT, reps);
+            else if (v == 4) k_run<4><<<1, 256>>>(dA, dL, dT, reps);
+            else k_run<5><<<1, 256>>>(dA, dL, dT, reps);
             hipEventRecord(e1);
             hipDeviceSynchronize();
         }
@@ -233,6 +271,18 @@ int main()
         std::printf("variant %d: ok=%lld  cycles/call %.0f  wall us/call %.2f  (kernel %.1f us / %d reps = %.2f us)  |LinvALinv'-I| %.2e  upper %.1e\n",
                     v, t[2], (double)t[0] / reps, (double)t[1] / reps / 100.0, ms * 1e3, reps, ms * 1e3 / reps, err, upper);
     }
+#ifdef W2_TRACE
+    {
+        long long st[64];
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(g_w2_stamps), sizeof(st));
+        std::printf("w2 stamps (cycles after step 0 start): per step J: start, LDL done, W ready, MFMAs issued | wavefront 1: flag seen\n");
+        for (int J = 0; J < 8; ++J)
+            std::printf("  J=%d  %6lld %6lld %6lld %6lld | %6lld\n", J, st[4 * J] - st[0], st[4 * J + 1] - st[0], st[4 * J + 2] - st[0],
+                        st[4 * J + 3] - st[0], J < 7 ? st[32 + J] - st[0] : 0ll);
+        std::printf("  wavefronts 0..3 at the barrier: %lld %lld %lld %lld, after it %lld, end %lld\n", st[40] - st[0], st[41] - st[0], st[42] - st[0],
+                    st[43] - st[0], st[44] - st[0], st[45] - st[0]);
+    }
+#endif
     {
         const int reps = 50;
         long long t[1];

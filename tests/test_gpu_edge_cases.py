@@ -232,7 +232,7 @@ def test_abi_error_paths(eng_mod, seq12):
         e.set_update_path(3)
     assert ei.value.code == 1
     with pytest.raises(eng_mod.EkfError) as ei:   # a sweep launch scheme that does not exist
-        e.set_sweep_mode(3)
+        e.set_sweep_mode(5)
     assert ei.value.code == 1
     # still healthy: a normal prediction + update on a subset of the keypoints
     kps, desc = seq12.frames[0]
