@@ -346,8 +346,9 @@ def main():
                     help="descriptors: matcher mode A, keypoints + 32-byte descriptors per frame (the reference's "
                          "matcher downstream of its detector); ncc: mode B, rendered frames staged in HBM, gray "
                          "pyramid + template NCC per frame (BASELINE configs[3-4])")
-    ap.add_argument("--sweep-mode", type=int, default=2, choices=[0, 1, 2],
-                    help="ekf_set_sweep_mode: 2 by size (default), 1 one panel of the Cholesky sweep per launch, 0 two panels per launch")
+    ap.add_argument("--sweep-mode", type=int, default=2, choices=[0, 1, 2, 3, 4],
+                    help="ekf_set_sweep_mode: 2 AUTO (default: one persistent launch per update where it applies), 3 persistent, "
+                         "4 launches by size (the round-4 rule), 1 one panel of the Cholesky sweep per launch, 0 two panels per launch")
     ap.add_argument("--update-path", type=int, default=0, choices=[0, 1, 2],
                     help="ekf_set_update_path: 0 by size (default), 1 B inside the Cholesky sweep, 2 inverse + GEMM")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -22,8 +22,8 @@
 // one relaxed agent-scope flag; consumers poll the flag from one lane (s_sleep between polls) and read the payload with sc1 loads.
 // Flags are monotone and carry an epoch (no clearing between sweeps).  Every wait is on work of an earlier level (or, for the tile
 // workers, no wait at all: they pick the most urgent RUNNABLE task of their tiles), so the launch needs all its workgroups resident
-// (the host sizes the grid by the occupancy query) but no particular placement; the block order only tries to give the chain and
-// the B workers a CU of their own (empty spacer blocks where in-order dispatch would double up).  EVERY spin is bounded by wall time: a wait that exceeds PS_TIMEOUT_TICKS sets the
+// (the host sizes the grid by the occupancy query) but no particular placement; the block order only tries to give the chain
+// workgroup a CU of its own (an empty spacer block where in-order dispatch would double up).  EVERY spin is bounded by wall time: a wait that exceeds PS_TIMEOUT_TICKS sets the
 // sticky error EKF_ERR_TIMEOUT, wakes every other waiter and ends the launch -- never a hung stream.
 #pragma once
 
@@ -37,6 +37,7 @@ struct SweepCtl {
 constexpr int PS_NBC = B_SWEEP_MAX / NB + 2;        // block rows of the flag tables: 64 panels + the nu row + 1
 constexpr unsigned PS_EPOCH_STEP = 128;             // flag values of one sweep stay below this
 constexpr long long PS_TIMEOUT_TICKS = 3000000ll;   // 30 ms of the 100 MHz constant clock
+constexpr int PS_BATCH = 4;                         // panels a tile worker applies to one tile per task in the L form
 constexpr int PS_CACHE = 4;                         // tiles a tile worker keeps in LDS between their panels (the rest live in S)
 inline size_t sweep_ctl_bytes() { return sizeof(SweepCtl) + sizeof(unsigned) * 2 * PS_NBC * PS_NBC; }
 
@@ -56,14 +57,14 @@ struct PsArgs {
     unsigned eb;          // epoch base of this sweep's flag values
     unsigned arrive_base; // tickets handed out before this launch
     int n_b, n_bcols, n_t;
-    int n_cus;  // block order: [chain][B workers][tile workers .. n_cus - 1][spacers: n_cus .. n_cus + n_b][the other tile workers]
+    int n_cus;  // > 0: block n_cus is an empty spacer (in-order dispatch would put it on the chain workgroup's CU)
     unsigned long long *trace; // debug builds (-DEKF_SWEEP_TRACE): per-panel time stamps of the roles, see PS_TRACE
 };
 
 // debug aid (scripts/persist_trace.py): 10 ns stamps per panel k -- chain [k][0..4], first B worker 1024 + [k][0..4], last B worker
 // 2048 + ..., tile workers 3072 + [k]: 0 latest end of a tile of column k + 1, 1 latest end of a panel block L(i,k), 2 latest end of any tile
 #ifdef EKF_SWEEP_TRACE
-#define PS_TRACE(base, k, slot) if (a.trace && threadIdx.x == 0) a.trace[(base) + 8 * (k) + (slot)] = wall_clock64();
+#define PS_TRACE(base, k, slot) if (a.trace && threadIdx.x == 0 && (base) != 2048) a.trace[(base) + 8 * (k) + (slot)] = wall_clock64();
 #define PS_TRACE_MAX(base, k, slot) if (a.trace && threadIdx.x == 0) atomicMax(&a.trace[(base) + 8 * (k) + (slot)], (unsigned long long)wall_clock64());
 #else
 #define PS_TRACE(base, k, slot)
@@ -260,7 +261,7 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
     const int k0 = k * NB, c0 = bcol * NB, kp = k;
     const int m = a.m, ld = a.ld;
     unsigned *lrdy = a.ctl->flags + PS_NBC * PS_NBC;
-    const int tb = bcol == a.bp.bcol0 ? 1024 : 2048;
+    const int tb = 1024;
     (void)tb;
     // this thread's four elements of G_k (cold, needed at the end)
     const int r4 = tid >> 3, cg = (tid & 7) * 4;
@@ -338,18 +339,45 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
 #endif
         }
     }
-    PS_TRACE(tb, k, 1)
-    // phase B: the last block, j = kp - 1, by the wavefront whose turn it is
-    if (ok && kp > 0 && ((kp - 1) & 3) == wv) {
-        ok = ps_wwait(lrdy + (size_t)kp * PS_NBC + kp - 1, a.eb + 1, a.ctl, a.counts, a.eb, 0x5100u + k);
-        if (ok) {
-            PSB_LOAD(0, kp - 1)
-            PSB_MMA(0)
+    if (bcol == a.bp.bcol0) { PS_TRACE(tb, k, 1) }
+    // phase B: the last block, j = kp - 1, by the wavefront whose turn it is.  Its planes of B are this workgroup's own stores of the
+    // previous panel, which ended without draining them: every wavefront's stores are older than the loads it has just waited for
+    // (the memory counter is in order), so one barrier makes them visible.  A worker that trails the chain finds L(k, k-1) published
+    // already and requests its planes BEFORE that barrier.
+    if (kp > 0) {
+        const bool mine = ((kp - 1) & 3) == wv;
+        bool early = false;
+        if (ok && mine) {
+            early = ps_reached(ps_flag(lrdy + (size_t)kp * PS_NBC + kp - 1), a.eb + 1);
+            early = __builtin_amdgcn_readfirstlane(early ? 1 : 0) != 0;
+            if (early) {
+#pragma unroll
+                for (int s = 0; s < PX_S; ++s)
+                    la[0][s] = __builtin_amdgcn_raw_buffer_load_b128(lq, pl_off + (unsigned)(kp - 1) * 1024u + (unsigned)(s * bp.l_stride), 0, 16);
+            }
+        }
+        if (early) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PX_S) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ok && mine) {
+            if (!early) {
+                ok = ps_wwait(lrdy + (size_t)kp * PS_NBC + kp - 1, a.eb + 1, a.ctl, a.counts, a.eb, 0x5100u + k);
+                if (ok) {
+#pragma unroll
+                    for (int s = 0; s < PX_S; ++s)
+                        la[0][s] = __builtin_amdgcn_raw_buffer_load_b128(lq, pl_off + (unsigned)(kp - 1) * 1024u + (unsigned)(s * bp.l_stride), 0, 16);
+                }
+            }
+            if (ok) {
+#pragma unroll
+                for (int s = 0; s < PX_S; ++s) lb[0][s] = *(const bp_v4i *)(pb + (size_t)(kp - 1) * bstep + (size_t)s * bp.b_stride);
+                PSB_MMA(0)
+            }
         }
     }
 #undef PSB_LOAD
 #undef PSB_MMA
-    PS_TRACE(tb, k, 2)
+    if (bcol == a.bp.bcol0) { PS_TRACE(tb, k, 2) }
     // inv(L_kk), unless it travelled with the sums: every wavefront waits for itself, every thread fetches its four elements
     if (ok && !have_inv) {
         ok = ps_wwait(&a.ctl->inv_ready, a.eb + k + 1, a.ctl, a.counts, a.eb, 0x5200u + k);
@@ -361,7 +389,7 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
             }
         }
     }
-    PS_TRACE(tb, k, 3)
+    if (bcol == a.bp.bcol0) { PS_TRACE(tb, k, 3) }
     if (ok) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) sLi[(tid + q * 256) / NB][(tid + q * 256) % NB] = gv[q];
@@ -411,7 +439,9 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
 #pragma unroll
         for (int s = 0; s < PX_S; ++s) *(unsigned *)(dst + (size_t)s * bp.b_stride) = w[s];
     }
-    __syncthreads(); // (drains every wavefront's stores: the next panel of this column block reads them back; frees the LDS blocks)
+    // (frees the LDS blocks; the stores of the planes drain beside the next panel's sums and are waited for there)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     return true;
 }
 
@@ -524,14 +554,11 @@ __global__ void __launch_bounds__(256, 2) k_chol_persist(PsArgs a)
     unsigned *done = ctl->flags;
     unsigned *lrdy = ctl->flags + PS_NBC * PS_NBC;
     const int m = a.m, nbk = a.nbk, ldS = a.ldS;
-    // role of this block (see PsArgs::n_cus): 0 chain, 1 .. n_b B workers, then tile workers
+    // role of this block: 0 chain, 1 .. n_b B workers, then tile workers; block n_cus (if any) is the chain's empty neighbour
     int role = (int)blockIdx.x;
-    {
-        const int first = a.n_cus - 1 - a.n_b; // tile workers among the first n_cus blocks
-        if ((int)blockIdx.x >= a.n_cus) {
-            if ((int)blockIdx.x <= a.n_cus + a.n_b) return; // spacer: the chain's and the B workers' CUs stay theirs
-            role = 1 + a.n_b + first + ((int)blockIdx.x - a.n_cus - a.n_b - 1);
-        }
+    if (a.n_cus > 0) {
+        if ((int)blockIdx.x == a.n_cus) return;
+        if ((int)blockIdx.x > a.n_cus) role = (int)blockIdx.x - 1;
     }
     if (tid == 0) hfail_s = 0;
     __syncthreads();
@@ -696,101 +723,141 @@ __global__ void __launch_bounds__(256, 2) k_chol_persist(PsArgs a)
     }
     if (ticket > a.n_b) {
         // ------------------------------------------------------------------------------------------------------ tile workers
-        // A worker owns the tiles me, me + n_t, ... of the column-major enumeration and applies the panels to each of them in order,
-        // but across its tiles it always takes the most URGENT task that can run now: task (p, tile (i, j)) = "apply panel p" needs
-        // inv(L_pp) and the panel blocks S(i,p), S(j,p) with the panels < p applied; its urgency is j - p (1: a tile of the next
-        // column -- the chain and every next-level task wait for those; 0: a block of panel p itself, whose official L(i,p) the rows
-        // of B wait for; then the rest).  A worker never blocks on one task while another of its tasks could run, so a slow far tile
-        // cannot delay the column the chain needs next.
+        // A worker owns the tiles me, me + n_t, ... of the column-major enumeration.  Its tasks, per tile (i, j):
+        //   * apply the panels 0 .. upd - 1 (upd = j; the chain workgroup takes the last panel of the tile left of the diagonal and
+        //     the last two of a diagonal tile itself).  Panel p can be applied in two forms:
+        //       L form     S(i,j) -= L(i,p) L(j,p)'  from the official fp64 blocks of L (flags lrdy): a streaming product straight
+        //                  from L2 into the MFMA operand layout, no LDS, no barrier, any number of consecutive panels per task;
+        //       S form     from the panel blocks S(i,p), S(j,p) and inv(L_pp) (two more 32^3 products): available one hand-off
+        //                  EARLIER than the L form -- what the last panel of a tile needs, which the next column waits for;
+        //   * (off the diagonal) the panel-block step at level j: L(i,j) = S(i,j) inv(L_jj)' is final -- stored as fp64 (row-major
+        //     for the L form, mirrored for the fp64 rows of B) and as digit planes (exact configuration), flag lrdy(i, j); the extra
+        //     block row carries nu' and yields z'.
+        // Across its tiles a worker takes panel-block steps and last panels first (they unblock others), then the runnable task with
+        // the least slack (key 5 j + 7 p: deadline ~ j cycles of the chain, remaining work ~ j - p tasks), and never blocks on one
+        // task while another could run.
         const int me = ticket - 1 - a.n_b;
         if (me >= a.n_t) return;
         double(*sP)[NB + 1] = pool[0];
         double(*sQ)[NB + 1] = pool[1];
         double(*sLi)[NB + 1] = pool[2];
         double(*sLj)[NB + 1] = pool[3];
-        __shared__ int s_ti[64], s_tj[64], s_prog[64], s_end[64], s_choice;
+        __shared__ int s_ti[64], s_tj[64], s_prog[64], s_upd[64], s_choice, s_kind, s_cnt;
         const int ntiles = (nbk + 1) * (nbk + 2) / 2 - 1; // columns j = 0 .. nbk - 1, rows j .. nbk
         const int ntl = me < ntiles ? min(64, (ntiles - me + a.n_t - 1) / a.n_t) : 0;
         if (tid < 64) {
-            int i = 0, j = 0, end = 0;
+            int i = 0, j = 0, upd = 0;
             if (tid < ntl) {
                 ps_tile(me + tid * a.n_t, nbk, i, j);
-                // tasks of a tile: panels 0 .. j - 1, then (off the diagonal) its own panel-block step at level j.  The chain
-                // workgroup applies the last two panels (j - 2, j - 1) to a diagonal tile and the last one (j - 1) to the tile left
-                // of it itself (see there): those levels are not the owner's.
-                end = (i == j) ? max(j - 2, 0) : j + 1;
+                const bool sub = i == j + 1 && i < nbk;
+                upd = (i == j) ? max(j - 2, 0) : (sub ? max(j - 1, 0) : j);
             }
-            const bool sub = i == j + 1 && i < nbk;
-            s_ti[tid] = i; s_tj[tid] = j; s_prog[tid] = (sub && j == 1) ? 1 : 0; s_end[tid] = end;
+            // s_prog: panels applied (0 .. upd), upd + 1 once the panel-block step is done too (diagonal tiles have none)
+            s_ti[tid] = i; s_tj[tid] = j; s_prog[tid] = 0; s_upd[tid] = upd;
         }
         __syncthreads();
         int inv_k = -1; // the panel whose inverse sits in sX
-        for (;;) {
-            if (w == 0) {
-                // scan: lane t looks at its tile's next task
-                const long long t0 = wall_clock64();
-                unsigned n = 0;
-                int choice = -2;
-                for (;;) {
-                    const unsigned inv = ps_flag(&ctl->inv_ready);
-                    int key = 1 << 30;
-                    bool pending = false;
-                    if (lane < ntl) {
-                        const int p = s_prog[lane], i = s_ti[lane], j = s_tj[lane];
-                        if (p < s_end[lane]) {
-                            pending = true;
-                            bool r = ps_reached(inv, a.eb + p + 1);
-                            if (r && p > 0 && p < j) {
+        __shared__ int s_nchoice, s_nkind, s_ncnt; // the task picked while the current one's operands travel (-3: none)
+        if (tid == 0) s_nchoice = -3;
+        // the scan (wavefront 0): lane t looks at its tile's next task; `exclude`: the tile of the task in flight; a non-blocking
+        // scan returns -3 when nothing else can run now
+        auto scan = [&](int exclude, bool blocking, int &choice, int &kind, int &cnt) {
+            const long long t0 = wall_clock64();
+            unsigned n = 0;
+            choice = -2; kind = 0; cnt = 1;
+            for (;;) {
+                const unsigned inv = ps_flag(&ctl->inv_ready);
+                int key = 1 << 30, lfc = 0;
+                bool pending = false;
+                if (lane < ntl && lane != exclude) {
+                    const int p = s_prog[lane], i = s_ti[lane], j = s_tj[lane], upd = s_upd[lane];
+                    const bool sub = i == j + 1 && i < nbk;
+                    int kd = -1;
+                    if (p < upd) {
+                        pending = true;
+                        // L form first (cheap; as many consecutive panels as are published, PS_BATCH at most: their operands
+                        // travel together), S form if that is what is there
+                        bool run = true;
+#pragma unroll
+                        for (int q = 0; q < PS_BATCH; ++q) {
+                            bool lf = run && p + q < upd && ps_reached(ps_flag(&lrdy[(size_t)i * PS_NBC + min(p + q, PS_NBC - 1)]), a.eb + 1);
+                            if (lf && j != i) lf = ps_reached(ps_flag(&lrdy[(size_t)j * PS_NBC + min(p + q, PS_NBC - 1)]), a.eb + 1);
+                            run = lf;
+                            lfc += lf ? 1 : 0;
+                        }
+                        if (lfc > 0) kd = 2;
+                        else if (ps_reached(inv, a.eb + p + 1)) {
+                            bool r = true;
+                            if (p > 0) {
                                 r = ps_reached(ps_flag(&done[(size_t)i * PS_NBC + p]), a.eb + p);
                                 if (r && j != i) r = ps_reached(ps_flag(&done[(size_t)j * PS_NBC + p]), a.eb + p);
                             }
-                            // the block left of the diagonal gets its last panel from the chain workgroup, which hands it back
-                            if (r && p == j && j > 0 && i == j + 1 && i < nbk) r = ps_reached(ps_flag(&done[(size_t)i * PS_NBC + j]), a.eb + j);
-                            if (r) {
-                                const int u = j - p;
-                                key = (u == 1 ? 0 : (u == 0 ? 1 : u)) * 64 + lane;
-                            }
+                            if (r) kd = 0;
                         }
+                    } else if (i != j && p == upd) {
+                        pending = true;
+                        bool r = ps_reached(inv, a.eb + j + 1);
+                        // the block left of the diagonal gets its last panel from the chain workgroup, which hands it back
+                        if (r && sub && j > 0) r = ps_reached(ps_flag(&done[(size_t)i * PS_NBC + j]), a.eb + j);
+                        if (r) kd = 1;
                     }
+                    // what unblocks others first: the panel-block steps (every L-form update of that panel waits for them) and a
+                    // tile's last panel (the next column waits for it); then the least slack
+                    if (kd >= 0) key = ((kd == 1 || p == upd - 1) ? 0 : (1 << 20)) | ((5 * j + 7 * min(p, j)) << 8) | (kd << 6) | lane;
+                }
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o, 64));
-                    if (key < (1 << 30)) { choice = key & 63; break; }
-                    if (__builtin_amdgcn_ballot_w64(pending) == 0ull) { choice = -1; break; } // every tile of this worker is finished
-                    if (n < 8) __builtin_amdgcn_s_sleep(2);
-                    else __builtin_amdgcn_s_sleep(8);
-                    if ((++n & 31u) == 0) {
-                        if (ps_failing(ctl, a.eb)) break;
-                        if (wall_clock64() - t0 > PS_TIMEOUT_TICKS) {
-                            if (lane == 0) ps_fail(ctl, a.counts, a.eb, 0x3000u);
-                            break;
-                        }
+                for (int o = 32; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o, 64));
+                if (key < (1 << 30)) {
+                    choice = key & 63;
+                    kind = (key >> 6) & 3;
+                    cnt = max(1, __shfl(lfc, choice, 64));
+                    return;
+                }
+                if (!blocking) { choice = -3; return; }
+                if (__builtin_amdgcn_ballot_w64(pending) == 0ull) { choice = -1; return; } // every tile of this worker is finished
+                if (n < 8) __builtin_amdgcn_s_sleep(2);
+                else __builtin_amdgcn_s_sleep(8);
+                if ((++n & 31u) == 0) {
+                    if (ps_failing(ctl, a.eb)) return;
+                    if (wall_clock64() - t0 > PS_TIMEOUT_TICKS) {
+                        if (lane == 0) ps_fail(ctl, a.counts, a.eb, 0x3000u);
+                        return;
                     }
                 }
-                if (lane == 0) s_choice = choice;
+            }
+        };
+        __syncthreads();
+        for (;;) {
+            if (w == 0) {
+                int choice = s_nchoice, kind = s_nkind, cnt = s_ncnt;
+                if (choice == -3) scan(-1, true, choice, kind, cnt);
+                if (lane == 0) { s_choice = choice; s_kind = kind; s_cnt = cnt; s_nchoice = -3; }
             }
             __syncthreads();
             const int ch = s_choice;
             if (ch < 0) return; // -1 finished, -2 failing
-            const int i = s_ti[ch], j = s_tj[ch], k = s_prog[ch];
+            const int kind = s_kind, nb = s_cnt;
+#ifdef EKF_SWEEP_TRACE
+            int tlog = -1;
+            if (a.trace && me == a.n_t / 3 && tid == 0) { // the task log of one worker: [scan done, end, kind | panel | count | tile]
+                tlog = (int)a.trace[2048];
+                if (tlog < 250) { a.trace[2048] = tlog + 1; a.trace[2052 + 4 * tlog] = wall_clock64(); }
+            }
+#endif
+            const int i = s_ti[ch], j = s_tj[ch], upd = s_upd[ch];
+            const int k = kind == 1 ? j : s_prog[ch]; // the panel of this task (the first one of a batch)
             const int k0 = k * NB;
             const bool is_nu = i == nbk; // the right-hand-side row: one live row (nu' / z')
+            const bool sub = i == j + 1 && i < nbk;
             const int i0 = i * NB, j0 = j * NB;
-            // every flag this task needs has been seen: its operands are final (sc1 loads).  A worker's first PS_CACHE tiles live in
-            // LDS between their panels: S gets them back (and the `done` flag its only meaningful value) when their last panel is on.
             const bool cached = ch < PS_CACHE;
-            const bool sub = i == j + 1 && i < nbk; // the block left of the diagonal: its last panel (j - 1) is the chain's
             double(*sC)[NB + 1] = pool[4 + (cached ? ch : 0)];
-            const bool in_lds = cached && k > 0 && !(sub && j == k); // (panel 0 finds the tile as k_assemble_S / k_gather wrote it)
-            double pa[4], pb[4], v[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = tid + 256 * q, r = e >> 5, c = e & 31;
-                if (j == k && in_lds) pa[q] = sC[r][c]; // its own tile has become a block of panel k
-                else if (is_nu) pa[q] = (r == 0 && k0 + c < m) ? ps_ld(a.nu + k0 + c) : 0.0;
-                else pa[q] = (i0 + r < m) ? ps_ld(a.S + (size_t)(i0 + r) * ldS + k0 + c) : 0.0;
-                pb[q] = (j != k && j != i && j0 + r < m) ? ps_ld(a.S + (size_t)(j0 + r) * ldS + k0 + c) : 0.0;
-            }
-            if (j != k) {
+            // (panel 0 finds the tile as k_assemble_S / k_gather wrote it; the block left of the diagonal comes back from the chain)
+            const bool in_lds = cached && s_prog[ch] > 0 && !(sub && kind == 1);
+            int done_to = 0; // panels applied after this task (update tasks)
+            if (kind == 2) {
+                // ---- L form: nb consecutive panels, streaming, per wavefront (its quadrant (bi, bj) of the tile)
+                double v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int r = 16 * bi + lk + 4 * q, c = 16 * bj + lr;
@@ -799,65 +866,42 @@ __global__ void __launch_bounds__(256, 2) k_chol_persist(PsArgs a)
                     else if (in_lds) v[q] = sC[r][c];
                     else v[q] = is_nu ? ps_ld(a.nu + j0 + c) : ps_ld(a.S + (size_t)(i0 + r) * ldS + j0 + c);
                 }
-            }
-            if (inv_k != k) {
-                double gv[4];
+                // operands in MFMA layout: a[row 16 bi + lr][k = 4 st + lk] = L(i0 + 16 bi + lr, 32 q + 4 st + lk), b likewise from row block j
+                const bool arow = is_nu ? (bi == 0 && lr == 0) : (i0 + 16 * bi + lr < m);
+                const bool brow = j0 + 16 * bj + lr < m;
+                const double *pa_ = is_nu ? a.zvec + lk : a.LL + (size_t)(i0 + 16 * bi + lr) * ldS + lk;
+                const double *pb_ = a.LL + (size_t)(j0 + 16 * bj + lr) * ldS + lk;
+                // all nb <= PS_BATCH panels are requested at once: ONE round trip to L2 / the memory-side cache, then 8 MFMAs per panel
+                acc4_t acc = {0, 0, 0, 0};
+                double la[PS_BATCH][8], lb[PS_BATCH][8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int e = tid + 256 * q;
-                    gv[q] = ps_ld(a.V + (size_t)(k0 + (e >> 5)) * a.ldw + k0 + (e & 31));
-                }
+                for (int q = 0; q < PS_BATCH; ++q) {
+                    if (q < nb) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) sX[(tid + 256 * q) >> 5][(tid + 256 * q) & 31] = gv[q];
-                inv_k = k;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = tid + 256 * q;
-                sP[e >> 5][e & 31] = pa[q];
-                sQ[e >> 5][e & 31] = pb[q];
-            }
-            __syncthreads();
-            const acc4_t li = ps_prod_abt(sP, sX);
-            if (j == k) {
-                // a block of panel k: L(i,k) is final -- the official copy for the rows of B (digit planes or mirrored fp64), z' for
-                // the right-hand-side row
-                if (is_nu) {
-                    if (bi == 0 && lk == 0) {
-                        const int c = 16 * bj + lr;
-                        if (k0 + c < m) a.zvec[k0 + c] = li[0];
-                    }
-                    __syncthreads();
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) sLi[16 * bi + lk + 4 * q][16 * bj + lr] = li[q];
-                    __syncthreads();
-                    if (PL) ps_store_l_planes(a.bp, m, i0, sLi, k0);
-                    else {
-                        for (int e = tid; e < NB * NB; e += 256) { // mirrored: LL[k0 + c][i0 + r] = L(i0 + r, k0 + c)
-                            const int c = e / NB, r = e % NB;
-                            ps_st(a.LL + (size_t)(k0 + c) * ldS + i0 + r, (i0 + r < m) ? sLi[r][c] : 0.0);
+                        for (int st = 0; st < 8; ++st) {
+                            la[q][st] = arow ? ps_ld(pa_ + (size_t)(k + q) * NB + 4 * st) : 0.0;
+                            lb[q][st] = brow ? ps_ld(pb_ + (size_t)(k + q) * NB + 4 * st) : 0.0;
                         }
                     }
-                    ps_publish(&lrdy[(size_t)i * PS_NBC + k], a.eb + 1);
-                    PS_TRACE_MAX(3072, k, 1)
                 }
-            } else {
-                const acc4_t lj = (i == j) ? li : ps_prod_abt(sQ, sX);
+                if (w == 0) { // while they travel: the next task (non-blocking; this tile is busy)
+                    int c2, k2, n2;
+                    scan(ch, false, c2, k2, n2);
+                    if (lane == 0) { s_nchoice = c2; s_nkind = k2; s_ncnt = n2; }
+                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    sLi[16 * bi + lk + 4 * q][16 * bj + lr] = li[q];
-                    sLj[16 * bi + lk + 4 * q][16 * bj + lr] = lj[q];
+                for (int q = 0; q < PS_BATCH; ++q) {
+                    if (q < nb) {
+#pragma unroll
+                        for (int st = 0; st < 8; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q][st], lb[q][st], acc, 0, 0, 0);
+                    }
                 }
-                __syncthreads();
-                const acc4_t u = ps_prod_abt(sLi, sLj);
-                // the owner's last panel of this tile: k + 1 = j off the diagonal (the tile is then a block of panel j), j - 1 left of
-                // the diagonal, j - 2 on it (the chain workgroup takes over)
-                const bool last = k + 1 == (i == j ? j - 2 : (sub ? j - 1 : j));
+                done_to = k + nb;
+                const bool last = done_to == upd;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int r = 16 * bi + lk + 4 * q, c = 16 * bj + lr;
-                    const double nv = v[q] - u[q];
+                    const double nv = v[q] - acc[q];
                     if (cached) sC[r][c] = nv;
                     if (!cached || last) {
                         if (is_nu) {
@@ -865,12 +909,115 @@ __global__ void __launch_bounds__(256, 2) k_chol_persist(PsArgs a)
                         } else if (i0 + r < m && j0 + c < m && (i != j || c <= r)) ps_st(a.S + (size_t)(i0 + r) * ldS + j0 + c, nv);
                     }
                 }
-                if (!cached || last) ps_publish(&done[(size_t)i * PS_NBC + j], a.eb + k + 1);
+                if (!cached || last) ps_publish(&done[(size_t)i * PS_NBC + j], a.eb + done_to);
                 else __syncthreads();
-                if (j == k + 1) { PS_TRACE_MAX(3072, k, 0) }
-                PS_TRACE_MAX(3072, k, 2)
+                PS_TRACE_MAX(3072, done_to - 1, 2)
+            } else {
+                // ---- S form of one panel, or the panel-block step: operands through LDS
+                double pa[4], pb[4], v[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = tid + 256 * q, r = e >> 5, c = e & 31;
+                    if (kind == 1 && in_lds) pa[q] = sC[r][c]; // its own tile has become a block of panel k
+                    else if (is_nu) pa[q] = (r == 0 && k0 + c < m) ? ps_ld(a.nu + k0 + c) : 0.0;
+                    else pa[q] = (i0 + r < m) ? ps_ld(a.S + (size_t)(i0 + r) * ldS + k0 + c) : 0.0;
+                    pb[q] = (kind == 0 && j != i && j0 + r < m) ? ps_ld(a.S + (size_t)(j0 + r) * ldS + k0 + c) : 0.0;
+                }
+                if (kind == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = 16 * bi + lk + 4 * q, c = 16 * bj + lr;
+                        const bool live = is_nu ? (r == 0 && j0 + c < m) : (i0 + r < m && j0 + c < m && (i != j || c <= r));
+                        if (!live) v[q] = 0.0;
+                        else if (in_lds) v[q] = sC[r][c];
+                        else v[q] = is_nu ? ps_ld(a.nu + j0 + c) : ps_ld(a.S + (size_t)(i0 + r) * ldS + j0 + c);
+                    }
+                }
+                if (inv_k != k) {
+                    double gv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int e = tid + 256 * q;
+                        gv[q] = ps_ld(a.V + (size_t)(k0 + (e >> 5)) * a.ldw + k0 + (e & 31));
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sX[(tid + 256 * q) >> 5][(tid + 256 * q) & 31] = gv[q];
+                    inv_k = k;
+                }
+                if (w == 0) { // while the operands travel: the next task (non-blocking; this tile is busy)
+                    int c2, k2, n2;
+                    scan(ch, false, c2, k2, n2);
+                    if (lane == 0) { s_nchoice = c2; s_nkind = k2; s_ncnt = n2; }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = tid + 256 * q;
+                    sP[e >> 5][e & 31] = pa[q];
+                    sQ[e >> 5][e & 31] = pb[q];
+                }
+                __syncthreads();
+                const acc4_t li = ps_prod_abt(sP, sX);
+                if (kind == 1) {
+                    // a block of panel k: L(i,k) is final
+                    if (is_nu) {
+                        if (bi == 0 && lk == 0) {
+                            const int c = 16 * bj + lr;
+                            if (k0 + c < m) ps_st(a.zvec + k0 + c, li[0]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int r = 16 * bi + lk + 4 * q, c = 16 * bj + lr;
+                            sLi[r][c] = li[q];
+                            if (i0 + r < m) ps_st(a.LL + (size_t)(i0 + r) * ldS + k0 + c, li[q]); // row-major: the L form of the tile updates
+                        }
+                        __syncthreads();
+                        if (PL) ps_store_l_planes(a.bp, m, i0, sLi, k0);
+                        else {
+                            for (int e = tid; e < NB * NB; e += 256) { // mirrored: LL[k0 + c][i0 + r] = L(i0 + r, k0 + c)
+                                const int c = e / NB, r = e % NB;
+                                ps_st(a.LL + (size_t)(k0 + c) * ldS + i0 + r, (i0 + r < m) ? sLi[r][c] : 0.0);
+                            }
+                        }
+                    }
+                    ps_publish(&lrdy[(size_t)i * PS_NBC + k], a.eb + 1);
+                    PS_TRACE_MAX(3072, k, 1)
+                    done_to = upd + 1;
+                } else {
+                    const acc4_t lj = (i == j) ? li : ps_prod_abt(sQ, sX);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        sLi[16 * bi + lk + 4 * q][16 * bj + lr] = li[q];
+                        sLj[16 * bi + lk + 4 * q][16 * bj + lr] = lj[q];
+                    }
+                    __syncthreads();
+                    const acc4_t u = ps_prod_abt(sLi, sLj);
+                    done_to = k + 1;
+                    const bool last = done_to == upd;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = 16 * bi + lk + 4 * q, c = 16 * bj + lr;
+                        const double nv = v[q] - u[q];
+                        if (cached) sC[r][c] = nv;
+                        if (!cached || last) {
+                            if (is_nu) {
+                                if (r == 0 && j0 + c < m) ps_st(a.nu + j0 + c, nv);
+                            } else if (i0 + r < m && j0 + c < m && (i != j || c <= r)) ps_st(a.S + (size_t)(i0 + r) * ldS + j0 + c, nv);
+                        }
+                    }
+                    if (!cached || last) ps_publish(&done[(size_t)i * PS_NBC + j], a.eb + done_to);
+                    else __syncthreads();
+                    if (j == k + 1) { PS_TRACE_MAX(3072, k, 0) }
+                    PS_TRACE_MAX(3072, k, 2)
+                }
             }
-            if (tid == 0) s_prog[ch] = (sub && k + 1 == j - 1) ? j : k + 1; // (level j - 1 of the block left of the diagonal is not the owner's)
+#ifdef EKF_SWEEP_TRACE
+            if (tlog >= 0 && tlog < 250) {
+                a.trace[2052 + 4 * tlog + 1] = wall_clock64();
+                a.trace[2052 + 4 * tlog + 2] = (unsigned long long)kind | ((unsigned long long)k << 8) | ((unsigned long long)nb << 16) | ((unsigned long long)i << 24) | ((unsigned long long)j << 32);
+            }
+#endif
+            if (tid == 0) s_prog[ch] = done_to;
             // (the next scan is wavefront 0's, in program order behind this store; the LDS blocks are free: every product above
             // was followed by a barrier)
         }

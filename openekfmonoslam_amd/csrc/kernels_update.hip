@@ -1298,21 +1298,22 @@ static bool launch_persistent_sweep(EkfEngine *e, int m, const double *G, double
     const int nbk = (m + NB - 1) / NB;
     if (cap < 64 || nbk > B_SWEEP_MAX / NB || !e->d.sweep_ctl) return false;
     const int ntiles = (nbk + 1) * (nbk + 2) / 2 - 1;
-    // Block order (chol_persist.h, PsArgs::n_cus): [chain][B workers][tile workers up to block n_cus - 1], then -- in-order dispatch
-    // deals the blocks n_cus, n_cus + 1, ... to the CUs a second time -- empty spacers on the chain's and the B workers' CUs and a
-    // second batch of tile workers beside the first: the rows of B (int8 MFMA, the longest role) and the chain share their CU with
-    // nobody.  One B worker per 32-column block while at least 32 CUs are left for tiles; a tile worker owns at most 64 tiles.
+    // Block order: [chain][B workers][tile workers]; block n_cus -- which in-order dispatch would put on the chain workgroup's CU --
+    // is an empty spacer.  One B worker per 32-column block (at most 3/5 of the slots), the rest tile workers: with one or two
+    // tiles each they react to a published inverse within ~3 us, which the chain needs in its first panels (the band of two tiles
+    // it applies itself covers the rest).  Measured at N = 1000 (profiles/r05_persist_layout.txt): 134 tile workers beside B workers
+    // with CUs of their own 10.4 us per panel, 200 / 322 tile workers sharing the B workers' CUs 9.4 / 9.0.
     const int C = e->n_cus;
-    const int n_b = std::max(1, std::min(n_bcols, C - 1 - 32));
-    const int first = C - 1 - n_b;
-    int n_t = std::min(ntiles, cap >= 2 * C ? 2 * first : first);
+    const int n_b = std::max(1, std::min(n_bcols, (cap - 2) * 3 / 5));
+    int n_t = std::min(ntiles, cap - 2 - n_b);
 #ifdef EKF_SWEEP_TRACE // tuning runs of the debug build only
     if (const char *ev = std::getenv("EKF_PS_NT")) n_t = std::max(1, std::min(n_t, atoi(ev)));
 #endif
     n_t = std::max(n_t, (ntiles + 63) / 64);
-    if (n_t > (cap >= 2 * C ? 2 * first : first)) return false;
-    const int workers = 1 + n_b + n_t;
-    const int grid = n_t <= first ? workers : C + n_b + 1 + (n_t - first);
+    if (1 + n_b + n_t + 1 > cap) return false;
+    const bool spacer = 1 + n_b + n_t > C;
+    const int grid = 1 + n_b + n_t + (spacer ? 1 : 0);
+    const int layout_cus = spacer ? C : 0;
     if (e->ps_epoch >= (1u << 22) || e->ps_epoch == 0) { // (re)start the epochs of the flags well before they can wrap
         if (hipMemsetAsync(e->d.sweep_ctl, 0, sweep_ctl_bytes(), e->stream) != hipSuccess) return false;
         e->ps_epoch = 0;
@@ -1324,7 +1325,7 @@ static bool launch_persistent_sweep(EkfEngine *e, int m, const double *G, double
     a.V = e->d.Dinv; a.ldw = e->ldW; a.nu = e->d.nu; a.zvec = e->d.zvec; a.counts = e->d.counts;
     a.G = G; a.Bout = Bout; a.ld = e->ldP; a.bp = bp;
     a.ctl = (SweepCtl *)e->d.sweep_ctl; a.eb = e->ps_epoch * PS_EPOCH_STEP; a.arrive_base = e->ps_arrive;
-    a.n_b = n_b; a.n_bcols = n_bcols; a.n_t = n_t; a.n_cus = C;
+    a.n_b = n_b; a.n_bcols = n_bcols; a.n_t = n_t; a.n_cus = layout_cus;
     a.trace = nullptr;
 #ifdef EKF_SWEEP_TRACE
     if (g_ps_trace_on) {
@@ -1336,7 +1337,7 @@ static bool launch_persistent_sweep(EkfEngine *e, int m, const double *G, double
         }
     }
 #endif
-    e->ps_arrive += (unsigned)workers;
+    e->ps_arrive += (unsigned)(1 + n_b + n_t);
     const int dev = e->device >= 0 && e->device < 16 ? e->device : 0;
     if (g_engines_alive.load() > 1) {
         // more than one engine in this process: order this sweep behind the last persistent sweep of any other engine on the device

@@ -53,7 +53,8 @@ fn(0, buf.ctypes.data_as(C.c_void_p), C.byref(m))
 nbk = (m.value + 31) // 32
 ch = buf[:1024].reshape(-1, 8)
 b0 = buf[1024:2048].reshape(-1, 8)
-b1 = buf[2048:3072].reshape(-1, 8)
+b1 = np.zeros((128, 8), dtype=np.uint64)
+tlog = buf[2048:3072]
 tl = buf[3072:4096].reshape(-1, 8)
 t0 = int(ch[0][0])
 us = lambda x: (int(x) - t0) / 100.0 if int(x) else float("nan")  # noqa: E731
@@ -64,3 +65,13 @@ for k in range(nbk):
     print(f"{k:3d} | {us(c[0]):8.2f} {us(c[1]):8.2f} {us(c[2]):8.2f} {us(c[3]):8.2f} | {us(c[4]):8.2f} | "
           f"{us(x[0]):8.2f} {us(x[1]):8.2f} {us(x[2]):8.2f} {us(x[3]):8.2f} {us(x[4]):8.2f} | {us(y[0]):8.2f} {us(y[4]):8.2f} | "
           f"{us(z[0]):8.2f} {us(z[1]):8.2f} {us(z[2]):8.2f}")
+
+nlog = int(tlog[0])
+print(f"task log of tile worker n_t/3: {nlog} tasks (kind 0 S-form update, 1 panel-block step, 2 L-form batch)")
+prev = None
+for n in range(min(nlog, 250)):
+    t_s, t_e, info = int(tlog[4 + 4 * n]), int(tlog[4 + 4 * n + 1]), int(tlog[4 + 4 * n + 2])
+    kind, k, nb, i, j = info & 255, (info >> 8) & 255, (info >> 16) & 255, (info >> 24) & 255, (info >> 32) & 255
+    gap = (t_s - prev) / 100.0 if prev else 0.0
+    print(f"  {n:3d}: tile ({i:2d},{j:2d}) kind {kind} panel {k:2d} x{nb}  picked at {us(t_s):8.2f} (idle/scan {gap:5.2f})  took {(t_e - t_s) / 100.0:5.2f} us")
+    prev = t_e
