@@ -34,6 +34,9 @@ WORKLOADS = {
     "n1000_f32x": (1000, 640, 480, 2, "f32"),   # fp32 storage, exact downdate (EKF_PRECISION_F32_EXACT)
     "n2000_f32x": (2000, 1280, 720, 2, "f32"),
     "n5000_f32x": (5000, 1920, 1080, 2, "f32"),
+    "n2000_auto": (2000, 1280, 720, 4, "f64"),   # EKF_PRECISION_AUTO: above 1024 features the exact update on an fp64-stored covariance
+    "n5000_auto": (5000, 1920, 1080, 4, "f64"),  # (all-fp64 at this capacity)
+    "n5000_f64x": (5000, 1920, 1080, 3, "f64"),  # EKF_PRECISION_F64_EXACT: the exact int8 update on an fp64-stored covariance
     "n1000_f64": (1000, 640, 480, 0, "f64"),
     "n2000_f32": (2000, 1280, 720, 1, "f32"),
     "n5000_f32": (5000, 1920, 1080, 1, "f32"),
@@ -377,7 +380,7 @@ def main():
     if args.transport is None:  # ranks that share one GPU (gloo, functional checks) cannot form an RCCL communicator
         args.transport = "rccl" if (ranks.dist is None or ranks.dist.get_backend() == "nccl") else "callback"
     N, W, H, precision, dtype = WORKLOADS[args.workload]
-    exact = precision == 2
+    exact = precision in (2, 3, 4)  # the exact int8 update (fp32- or fp64-stored covariance)
     n_frames = args.warmup + args.steps
     seq = SyntheticSequence(N, n_frames, width=W, height=H)
     sharded = args.mode == "sharded" and world > 1
@@ -420,6 +423,7 @@ def main():
 
             eng.set_exchange(DistributedExchange(ranks.dist, ranks.device))
         eng.upload_frames(seq.frames)
+    exact = eng.precision in (2, 3)  # (what EKF_PRECISION_AUTO resolved to)
     for e in (group.engines if group else [eng]):
         e.set_update_path(args.update_path)
         e.set_sweep_mode(args.sweep_mode)
@@ -517,7 +521,7 @@ def main():
                     tt = float(mss[sel].sum()) * 1e-3
                     by_class[name] = {"launches": int(sel.sum()), "mean_m": float(mm[sel].mean()),
                                       "avg_ms": 1e3 * tt / int(sel.sum()), "tflops": fl / tt / 1e12,
-                                      "algorithmic_GBps": 2.0 * n_state * n_state * (4 if precision else 8)
+                                      "algorithmic_GBps": 2.0 * n_state * n_state * (4 if eng.precision in (1, 2) else 8)
                                       * int(sel.sum()) / tt / 1e9,
                                       "frac": (PX_PRODUCTS * fl / tt / 1e12 / PEAK_I8_TOPS) if exact else fl / tt / 1e12 / PEAK_TFLOPS[dtype],
                                       **({"int8_tops": PX_PRODUCTS * fl / tt / 1e12} if exact else {}),
@@ -613,11 +617,12 @@ def main():
         "higher_is_better": True,
         "scaling": "strong" if sharded else "weak",
         "vs_baseline": None,
-        "dtype": "f32 storage; i8 MFMA with exact i32 sums (downdate) + f64 (B, S, state)" if exact else dtype,
+        "dtype": (("f32" if eng.precision == 2 else "f64") + " storage; i8 MFMA with exact i32 sums (downdate) + f64 (B, S, state)") if exact else dtype,
         "data": "synthetic",
         "config": {
             "workload": f"synthetic {W}x{H} sequence, N={N} inverse-depth features (n={13 + 6 * N}), "
-                        + ("fp32-stored covariance, B in fp64 + exact int8-digit downdate (EKF_PRECISION_F32_EXACT), " if exact else
+                        + ((("fp32" if eng.precision == 2 else "fp64") + "-stored covariance, B in fp64 + exact int8-digit downdate ("
+                            + ("EKF_PRECISION_F32_EXACT" if eng.precision == 2 else "EKF_PRECISION_F64_EXACT") + "), ") if exact else
                            f"{'fp32' if precision else 'fp64'} covariance, ")
                         + (f"{len(seq.frames[0][0])} keypoints/frame (matcher mode A)" if not ncc else
                            "rendered frames staged in HBM, 3-level pyramid + 11x11 NCC templates (matcher mode B)")

@@ -34,11 +34,20 @@ enum {
     EKF_PRECISION_F64 = 0, /* covariance and work matrices in fp64 (reference arithmetic)                   */
     EKF_PRECISION_F32 = 1, /* covariance, H*P and the rank-m downdate in fp32 (MFMA f32); S, its Cholesky     */
                            /* factor, the state and all Jacobians stay fp64                                   */
-    EKF_PRECISION_F32_EXACT = 2 /* fp32 STORAGE of the covariance and of H*P, reference-class arithmetic: B = inv(L) H P in
+    EKF_PRECISION_F32_EXACT = 2, /* fp32 STORAGE of the covariance and of H*P, reference-class arithmetic: B = inv(L) H P in
                                  * fp64 and the rank-m downdate P - B'B accumulated EXACTLY (int8 digit planes of B on the
                                  * int8 MFMA, int32 sums), rounded to fp32 once per entry and update.  The reference computes
                                  * in double throughout (Core/Base.h:67; Update.cpp:105-108, 214-218). */
+    EKF_PRECISION_F64_EXACT = 3, /* fp64 STORAGE of the covariance with the same exact int8 update: the sums are subtracted from an
+                                 * fp64-stored P, no rounding to fp32 -- for maps on which fp32 storage alone leaves the reference's
+                                 * 1e-5 (fresh maps of >= ~1400 features); about 2.5 x the speed of EKF_PRECISION_F64 there. */
+    EKF_PRECISION_AUTO = 4      /* the fastest configuration that holds every feature parameter within 1e-5 of the fp64 reference
+                                 * at this capacity (measured): EKF_PRECISION_F32_EXACT up to
+                                 * EKF_AUTO_F32_MAX_FEATURES features, EKF_PRECISION_F64_EXACT up to EKF_AUTO_EXACT_MAX_FEATURES,
+                                 * EKF_PRECISION_F64 above; ekf_get_precision reports the choice */
 };
+#define EKF_AUTO_F32_MAX_FEATURES 1024
+#define EKF_AUTO_EXACT_MAX_FEATURES 2048
 
 typedef struct EkfEngineConfig {
     EkfCamera cam;
@@ -112,6 +121,7 @@ int ekf_get_state(EkfEngine *e, double x13[13], double *feature_pos, double *P);
 int ekf_get_map_features(EkfEngine *e, uint8_t *desc32, uint32_t *times_predicted, uint32_t *times_matched);
 int ekf_state_dim(const EkfEngine *e);
 int ekf_descriptor_bytes(const EkfEngine *e); /* bytes per descriptor row (32, or 4 * cols for CV_32F) */
+int ekf_get_precision(const EkfEngine *e);    /* the EKF_PRECISION_* in use (what EKF_PRECISION_AUTO resolved to) */
 int ekf_num_features(const EkfEngine *e);
 
 /* -- map management: the state dimension changes, P is edited in place on the device ------ */

@@ -170,12 +170,20 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     const EkfParams &p = cfg->par;
     e->par = ParD{p.linearAccelSD, p.angularAccelSD, p.matchingCompCoefSecondBestVSFirst,
                   p.ransacThresholdPredictDistance, p.ransacAllInliersProbability, p.ransacChi2Threshold};
-    if (cfg->precision != EKF_PRECISION_F64 && cfg->precision != EKF_PRECISION_F32 && cfg->precision != EKF_PRECISION_F32_EXACT) {
+    if (cfg->precision < EKF_PRECISION_F64 || cfg->precision > EKF_PRECISION_AUTO) {
         delete e;
         return EKF_ERR_INVALID_ARG;
     }
-    e->exact = cfg->precision == EKF_PRECISION_F32_EXACT;
-    e->f32 = cfg->precision == EKF_PRECISION_F32 || e->exact;
+    // EKF_PRECISION_AUTO: the fastest configuration that holds EVERY feature parameter within 1e-5 of the fp64 reference on the
+    // maps it was measured on: the exact int8 update on an fp32-stored covariance up to
+    // EKF_AUTO_F32_MAX_FEATURES features; on an fp64-stored one up to EKF_AUTO_EXACT_MAX_FEATURES (fp32 storage alone leaves 1e-5
+    // on fresh maps of >= 1400 features); all-fp64 above (at N = 5000 the 38-bit digits of the exact update themselves leave
+    // 2.5e-5 ... 3.4e-5 on one far feature in the third frame of a fresh map)
+    if (cfg->precision == EKF_PRECISION_AUTO)
+        e->cfg.precision = cfg->max_features <= EKF_AUTO_F32_MAX_FEATURES ? EKF_PRECISION_F32_EXACT
+                           : (cfg->max_features <= EKF_AUTO_EXACT_MAX_FEATURES ? EKF_PRECISION_F64_EXACT : EKF_PRECISION_F64);
+    e->exact = e->cfg.precision == EKF_PRECISION_F32_EXACT || e->cfg.precision == EKF_PRECISION_F64_EXACT;
+    e->f32 = e->cfg.precision == EKF_PRECISION_F32 || e->cfg.precision == EKF_PRECISION_F32_EXACT;
     if ((cfg->flags & 0xff) == 1) { // EKF_DESCRIPTOR_F32_L2(cols)
         const int cols = (cfg->flags >> 8) & 0xffff;
         if (cols < 1 || cols > 1024) { delete e; return EKF_ERR_INVALID_ARG; }
@@ -527,6 +535,7 @@ int ekf_get_map_features(EkfEngine *e, uint8_t *desc32, uint32_t *times_predicte
 
 int ekf_state_dim(const EkfEngine *e) { return e ? e->n : 0; }
 int ekf_descriptor_bytes(const EkfEngine *e) { return e ? e->desc_bytes : 0; }
+int ekf_get_precision(const EkfEngine *e) { return e ? e->cfg.precision : -1; }
 int ekf_num_features(const EkfEngine *e) { return e ? e->N : 0; }
 
 static int finish_update(EkfEngine *e);

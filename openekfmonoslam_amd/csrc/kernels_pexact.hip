@@ -114,10 +114,22 @@ k_slice_B(const double *B, int ld, int m, int m_k, const double *Bc, const int *
 //                    is one contiguous run of "rows" of PX_S m / 16 x 16 bytes, which is what the engine's row-block exchange moves
 //   k_planes_unpack  the other ranks' columns back into [plane][k / 16][column][16]
 //   k_dx_planes      dx = B'z from the planes, every column (the fp64 rows of B exist only for the own columns)
-__global__ void __launch_bounds__(256) k_diag_extract(const float *P, int ld, RowMap rm, int n, float *diag)
+template <typename TP>
+__global__ void __launch_bounds__(256) k_diag_extract(const TP *P, int ld, RowMap rm, int n, float *diag)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j < n && owns_row(rm, j)) diag[j] = P[(size_t)local_row(rm, j) * ld + j];
+    if (j < n && owns_row(rm, j)) diag[j] = (float)P[(size_t)local_row(rm, j) * ld + j]; // (only its exponent is used, rounded up)
+}
+
+// P <- 0.5 (P + P') in place, upper triangle mirrored (fp64-stored exact configuration: the first downdate after an arbitrary
+// upload; the fp32-stored one has the AVG variant of its downdate kernel for that).  One thread per (i, j), j > i.
+__global__ void __launch_bounds__(256) k_symmetrize_P(double *P, int ld, int n)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= n || j <= i) return;
+    const double v = 0.5 * P[(size_t)i * ld + j] + 0.5 * P[(size_t)j * ld + i];
+    P[(size_t)i * ld + j] = v;
+    P[(size_t)j * ld + i] = v;
 }
 
 template <bool PACK>
@@ -174,7 +186,8 @@ void launch_slice_columns(EkfEngine *e, int m, int c_lo, int c_hi)
 
 void launch_diag_extract(EkfEngine *e, float *diag)
 {
-    k_diag_extract<<<(e->n + 255) / 256, 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->rm, e->n, diag);
+    if (e->f32) k_diag_extract<float><<<(e->n + 255) / 256, 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->rm, e->n, diag);
+    else k_diag_extract<double><<<(e->n + 255) / 256, 256, 0, e->stream>>>((const double *)e->d.P, e->ldP, e->rm, e->n, diag);
 }
 
 void launch_planes_move(EkfEngine *e, bool pack, int m_k, int c_lo, int c_hi, int skip_lo, int skip_hi)
@@ -410,9 +423,13 @@ constexpr int PX_RING = 3;
 // camera block (13 live rows), tile row t >= 1 holds the owned global rows rm.r0 + (t - 1) TM ..., stored from local row
 // rm.base on; every (row tile, column tile) pair is computed and written in place, nothing is mirrored.  The integer sums of
 // (i, j) and (j, i) are the same number, so P[i][j] here is bit for bit P[j][i] on the rank that owns row j.
-template <bool RECT>
+// TP: storage type of P.  float: one rounding to fp32 per entry and update (EKF_PRECISION_F32_EXACT).  double
+// (EKF_PRECISION_F64_EXACT): the same exact sums subtracted from an fp64-stored P -- the arithmetic of the update is unchanged
+// (38-bit digits of B under a-priori column scales), the storage no longer rounds; the epilogue stages half a block at a time
+// (the staging area keeps its size) and requests a block's old values only when the block before has left its accumulators.
+template <bool RECT, typename TP = float>
 __global__ void __launch_bounds__(512, 2)
-k_p_update_i8p(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq, int ldq, size_t plane_stride, int m_k,
+k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq, int ldq, size_t plane_stride, int m_k,
                const int *__restrict__ bexp, int per_xcd, const int4 *__restrict__ units, int slots, RowMap rm)
 {
     constexpr int TM = 128, MB = 32, SLAB = PX_S * 8192;
@@ -529,13 +546,14 @@ k_p_update_i8p(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__
                 for (int L = 0; L < PX_S; ++L)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) h ^= acc[x][L][r];
-            if (h == 0x12345677) P[0] = 0.f;
+            if (h == 0x12345677) P[0] = (TP)0;
             continue;
         }
         // epilogue: v = 2^(e_i + e_j - 12) sum_L acc_L 256^-L, P <- fl32(P - v); off-diagonal tiles also write the mirror image
         // (the epilogue's addresses are formed from a copy of ldp the compiler cannot see through -- read back from LDS --:
         // otherwise it computes all 64 store addresses BEFORE the k-loop and spills them, 190 registers, around it)
-        float *Pe = P;
+        if constexpr (sizeof(TP) == 4) {
+        float *Pe = reinterpret_cast<float *>(P);
         const int lde = __builtin_amdgcn_readfirstlane(sMeta[0]); // = ldp, read back from LDS after the loop
         float *sTe = sT + __builtin_amdgcn_readfirstlane(sMeta[1]); // + 0
         const int *se = sExp[ui & 1];
@@ -610,6 +628,80 @@ k_p_update_i8p(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
+        }
+        } else {
+            // ---- fp64-stored P
+            double *Pe = reinterpret_cast<double *>(P);
+            const int lde = __builtin_amdgcn_readfirstlane(sMeta[0]); // = ldp, read back from LDS after the loop
+            double *sTe = reinterpret_cast<double *>(sT) + __builtin_amdgcn_readfirstlane(sMeta[1]); // + 0
+            const int *se = sExp[ui & 1];
+            const int ej = se[TM + wc * MB + idx];
+            double *pe = Pe + (size_t)(I0 + p_off + rbase) * lde + J0 + wc * MB;
+            const int le = 4 * kg * lde + idx;
+            double *pm = Pe + (size_t)(J0 + wc * MB) * lde + I0 + rbase; // mirror image of block (0, .) (never used when RECT)
+            // staging per HALF block (16 rows): direct image [row][column] with rows of ST2 doubles, read back as 16 bytes = two
+            // columns per lane (lane = (row q, column pair c2), four rows per pass); mirror image [column][row] with rows of ST2T
+            constexpr int ST2 = MB + 2, ST2T = 16 + 2;
+            static_assert(16 * ST2 * 8 <= MB * ST * 4 && MB * ST2T * 8 <= MB * ST * 4, "the staging area holds half a block in fp64");
+            const int qd = lane >> 4, c2 = lane & 15;   // direct read-back: row 4 i4 + qd, columns 2 c2, 2 c2 + 1
+            const int qm = lane >> 3, c2m = lane & 7;   // mirror read-back: mirror row 8 i4 + qm, columns 2 c2m, 2 c2m + 1
+            // half a block (eight registers = sixteen rows) at a time: its old values were requested while the half before left
+            double pvn[8];
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) pvn[r8] = (pe + ((r8 & 3) + 8 * (r8 >> 2)) * lde)[le];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                if (x == 1 && !full) continue;
+                const int bi = I0 + rbase + x * MB;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { // registers 8 h .. 8 h + 7 = rows 16 h .. 16 h + 15 of the block
+                    double out[8];
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = 8 * h + r8;
+                        const int li = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                        double tsum = (double)acc[x][PX_S - 1][r];
+#pragma unroll
+                        for (int L = PX_S - 2; L >= 0; --L) tsum = fma(tsum, 1.0 / 256.0, (double)acc[x][L][r]);
+                        out[r8] = pvn[r8] - ldexp(tsum, se[rbase + x * MB + li] + ej - 12);
+                    }
+                    if (h == 0 || (x == 0 && full)) { // the next half's old values
+                        const int xn = h == 0 ? x : 1, hn = h ^ 1;
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) pvn[r8] = (pe + (xn * MB + 16 * hn + (r8 & 3) + 8 * (r8 >> 2)) * lde)[le];
+                    }
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) sTe[((r8 & 3) + 8 * (r8 >> 2) + 4 * kg) * ST2 + idx] = out[r8];
+                    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        const double2 v = *reinterpret_cast<const double2 *>(sTe + (4 * i4 + qd) * ST2 + 2 * c2);
+                        const int gi = bi + 16 * h + 4 * i4 + qd, gj0 = J0 + wc * MB + 2 * c2;
+                        double *dst = pe + (size_t)(x * MB + 16 * h + 4 * i4 + qd) * lde + 2 * c2;
+                        if (gi < ilim) {
+                            if (gj0 + 1 < n) *reinterpret_cast<double2 *>(dst) = v;
+                            else if (gj0 < n) dst[0] = v.x; // (n is odd: the padding stays untouched)
+                        }
+                    }
+                    if (!diag) { // rows of an off-diagonal tile are all < n (its row range ends before its column range starts)
+                        __builtin_amdgcn_s_waitcnt(0xc07f);
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) sTe[idx * ST2T + (r8 & 3) + 8 * (r8 >> 2) + 4 * kg] = out[r8];
+                        __builtin_amdgcn_s_waitcnt(0xc07f);
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int i4 = 0; i4 < 4; ++i4) {
+                            const double2 v = *reinterpret_cast<const double2 *>(sTe + (8 * i4 + qm) * ST2T + 2 * c2m);
+                            const int mj = J0 + wc * MB + 8 * i4 + qm; // row of the mirror = column of the block
+                            if (mj < n) *reinterpret_cast<double2 *>(pm + (size_t)(8 * i4 + qm) * lde + x * MB + 16 * h + 2 * c2m) = v;
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
         }
     }
 #undef PXP_ISSUE
@@ -839,7 +931,7 @@ k_p_update_i8q(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__
                     for (int L = 0; L < PX_S; ++L)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) h ^= acc[x][c][L][r];
-            if (h == 0x12345677) P[0] = 0.f;
+            if (h == 0x12345677) P[0] = (TP)0;
             continue;
         }
         // epilogue: as k_p_update_i8p, four blocks per wavefront
@@ -1141,6 +1233,12 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bo
         return;
     }
     if (e->timing) (void)hipEventRecord(e0, s);
+    if (!e->f32) { // fp64-stored P (EKF_PRECISION_F64_EXACT): the persistent kernel with the fp64 epilogue; an arbitrary upload is
+                   // symmetrised first (0.5 (P + P') - B'B = 0.5 ((P - B'B) + (P - B'B)'): B'B is symmetric)
+        if (!e->p_exact_sym && !rect) k_symmetrize_P<<<dim3((n + 255) / 256, n), 256, 0, s>>>((double *)e->d.P, ld, n);
+        if (rect) k_p_update_i8p<true, double><<<e->n_cus, 512, 0, s>>>((double *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
+        else k_p_update_i8p<false, double><<<e->n_cus, 512, 0, s>>>((double *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
+    } else
     if (!e->p_exact_sym && !rect) k_p_update_i8<true><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
     else if (g_px_variant == 1 || PX_S != 5) k_p_update_i8<false><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
 #if PX_S_VALUE == 5

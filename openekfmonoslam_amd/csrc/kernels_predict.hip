@@ -366,7 +366,7 @@ void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_pred
     unsigned *tp = count_predicted ? e->d.feat_times_predicted : nullptr;
     if (n_list <= 0) return;
     const int chunks_f = (e->n + 256 * 4 - 1) / (256 * 4), chunks_d = (e->n + 256 * 2 - 1) / (256 * 2);
-    if (e->exact)
+    if (e->exact && e->f32)
         k_hp_rows<float, double><<<dim3(n_list, chunks_f), 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
                                                         e->d.feat_covpos, e->d.Hs, e->d.Hf, (double *)e->d.HP,
                                                         e->d.pred_S, e->rm, e->d.HPc, tp, d_count);

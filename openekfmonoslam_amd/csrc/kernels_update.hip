@@ -29,11 +29,11 @@ namespace ekf {
 // ---------------------------------------------------------------------------------------------------- gather
 // Per selected match i: A[2i..2i+1, :] = HP[2f..2f+1, :], its Jacobian blocks, position/dimension and the
 // dead-banded innovation nu (Update.cpp:125-135).  Rows m..m_pad of A are zero-filled for the k-tiled kernels.
-template <typename T>
+template <typename T, typename TP = float> // TP: type of the diagonal table (the covariance itself on one GPU, the float table of a sharded engine)
 __global__ void __launch_bounds__(256)
 k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
          const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
-         double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, int *bexp, const float *Pdiag, int ldpd,
+         double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, int *bexp, const TP *Pdiag, int ldpd,
          int n, int *grow)
 {
     // grow != nullptr (exact configuration, rows of B from digit planes): the rows are NOT copied -- their consumers (k_assemble_S,
@@ -46,8 +46,8 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
         if (blockIdx.x == 0) {
             const int per = (n_pad + m_pad - 1) / m_pad;
             for (int j = row * per + threadIdx.x; j < min((row + 1) * per, n_pad); j += 256) {
-                const float pjj = j < n ? Pdiag[(size_t)j * ldpd + j] : 0.f;
-                bexp[j] = pjj > 0.f ? ilogb(sqrt((double)pjj) * 1.001) + 1 + 1022 : 1022;
+                const double pjj = j < n ? (double)Pdiag[(size_t)j * ldpd + j] : 0.0;
+                bexp[j] = pjj > 0.0 ? ilogb(sqrt(pjj) * 1.001) + 1 + 1022 : 1022;
             }
         }
     } else if (bexp && row == 0) {
@@ -209,15 +209,16 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
 // the replicated camera rows); columns in that range the rank does not own are written as zeros (the 32-column blocks of the rows
 // of B straddle the ownership boundaries; their owner's digit planes replace them after the exchange).
 // Block: 64 columns x 4 row lanes, 64 rows per block.y.
+template <typename TP>
 __global__ void __launch_bounds__(256)
-k_g_cols(const float *P, int ldp, RowMap rm, int n, int M, const double *mHs, const double *mHf, const int *mpos, const int *mdim,
+k_g_cols(const TP *P, int ldp, RowMap rm, int n, int M, const double *mHs, const double *mHf, const int *mpos, const int *mdim,
          double *G, int ld, int c_lo, int c_hi, int m_pad)
 {
     const int c = c_lo + blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
     if (c >= c_hi) return;
     const bool valid = c < n && owns_row(rm, c);
-    const float *pr = P + (size_t)(valid ? local_row(rm, c) : 0) * ldp;
+    const TP *pr = P + (size_t)(valid ? local_row(rm, c) : 0) * ldp;
     double pc[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) pc[k] = valid ? (double)pr[k] : 0.0;
@@ -1354,11 +1355,10 @@ static bool launch_persistent_sweep(EkfEngine *e, int m, const double *G, double
 }
 
 // T: storage type of P; TB: type of H P, of its gathered rows G, of B = inv(L) G and of the arithmetic that forms it
-// (TB = T except EKF_PRECISION_F32_EXACT: T = float, TB = double, the downdate by kernels_pexact.hip)
-template <typename T, typename TB>
+// (EXACT: EKF_PRECISION_F32_EXACT, T = float, and EKF_PRECISION_F64_EXACT, T = double -- TB = double, the downdate by kernels_pexact.hip)
+template <typename T, typename TB, bool EXACT = false>
 static void update_impl(EkfEngine *e, int M, bool update_cov)
 {
-    constexpr bool EXACT = sizeof(T) != sizeof(TB);
     hipStream_t s = e->stream;
     const int m = 2 * M, n = e->n, ld = e->ldP, ldS = e->ldS, ldw = e->ldW;
     const int m_pad = round_up(m, NB);
@@ -1431,11 +1431,14 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     {
         dim3 grid((n_pad / (int)(16 / sizeof(TB)) + 255) / 256, m_pad);
         if ((planes_b && !sharded) || sym_g) grid.x = 1; // no copy: one workgroup per row (bookkeeping, row map, its share of the column scales)
-        k_gather<TB><<<grid, 256, 0, s>>>(e->d.matches, M, m_pad, (const TB *)e->d.HP, G, ld, n_pad, e->d.pred_uv,
-                                         e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, e->d.mHs,
-                                         e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc, EXACT ? e->d.Bexp : nullptr,
-                                         apriori ? (sharded ? e->d.Pdiag : (const float *)e->d.P) : nullptr, sharded ? 0 : ld, n,
-                                         (planes_b && !sharded) || sym_g ? e->d.Grow : nullptr);
+#define GATHER_ARGS e->d.matches, M, m_pad, (const TB *)e->d.HP, G, ld, n_pad, e->d.pred_uv, e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, \
+                    e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc, EXACT ? e->d.Bexp : nullptr
+        if (apriori && !sharded) // a-priori column scales from the diagonal of the covariance itself
+            k_gather<TB, T><<<grid, 256, 0, s>>>(GATHER_ARGS, (const T *)e->d.P, ld, n, planes_b || sym_g ? e->d.Grow : nullptr);
+        else
+            k_gather<TB, float><<<grid, 256, 0, s>>>(GATHER_ARGS, apriori ? e->d.Pdiag : nullptr, 0, n,
+                                                    (planes_b && !sharded) || sym_g ? e->d.Grow : nullptr);
+#undef GATHER_ARGS
         if (planes_b && !sharded) G = (TB *)e->d.HP; // the consumers read H P through the row map (sym_g: G is formed by k_g_cols below)
     }
     // sharded step: every rank gathered the rows of the matches it owns; the others arrive here (engine.cpp)
@@ -1448,10 +1451,10 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             // all-gather of those columns (transposed image in W, which the sweep path does not use), the rest of S's duties after it
             const int c_lo = cb0 * NB, c_hi = cb1 * NB;
             const int b_lo = e->shard_rb[e->shard_rank] / 2, b_hi = e->shard_rb[e->shard_rank + 1] / 2;
-            if (c_lo > 0) k_g_cols<<<dim3(1, (m_pad + 63) / 64), 256, 0, s>>>((const float *)e->d.P, ld, e->rm, n, M, e->d.mHs, e->d.mHf, e->d.mpos,
-                                                                       e->d.mdim, (double *)G, ld, 0, NB, m_pad);
-            k_g_cols<<<dim3((c_hi - c_lo + 63) / 64, (m_pad + 63) / 64), 256, 0, s>>>((const float *)e->d.P, ld, e->rm, n, M, e->d.mHs, e->d.mHf,
-                                                                               e->d.mpos, e->d.mdim, (double *)G, ld, c_lo, c_hi, m_pad);
+            if (c_lo > 0) k_g_cols<T><<<dim3(1, (m_pad + 63) / 64), 256, 0, s>>>((const T *)e->d.P, ld, e->rm, n, M, e->d.mHs, e->d.mHf, e->d.mpos,
+                                                                          e->d.mdim, (double *)G, ld, 0, NB, m_pad);
+            k_g_cols<T><<<dim3((c_hi - c_lo + 63) / 64, (m_pad + 63) / 64), 256, 0, s>>>((const T *)e->d.P, ld, e->rm, n, M, e->d.mHs, e->d.mHf,
+                                                                                  e->d.mpos, e->d.mdim, (double *)G, ld, c_lo, c_hi, m_pad);
             k_assemble_S<TB><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim, e->cfg.cam.pixelErrorX, e->d.S, ldS, V,
                                                  nullptr, nullptr, ldw, e->d.counts, e->d.Lexp, nullptr, b_lo, b_hi, e->d.W, m_pad, 0);
             // (rows of the image are m_pad doubles: only the live columns of S travel, not the capacity-strided ldW)
@@ -1586,7 +1589,10 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         }
     }
     // exact configuration above B_SWEEP_MAX rows: the GEMM on the int8 MFMA, straight into the digit planes of B (kernels_pexact.hip)
-    const bool gemm_planes = EXACT && !b_in_sweep && update_cov && e->d.Wq != nullptr && (!sharded || shard_cols);
+    bool gemm_planes = EXACT && !b_in_sweep && update_cov && e->d.Wq != nullptr && (!sharded || shard_cols);
+#ifdef EKF_SWEEP_TRACE // accuracy experiments of the debug build: B = inv(L) G above 2048 rows by the fp64 GEMM, cut into planes afterwards
+    if (std::getenv("EKF_DBG_FP64_GEMM") && !sharded) gemm_planes = false;
+#endif
     if (gemm_planes) {
         const int c_lo = shard_cols ? col_rb[e->shard_rank] : 0, c_hi = shard_cols ? col_rb[e->shard_rank + 1] : n_pad;
         launch_b_gemm_planes(e, m, c_lo, c_hi);
@@ -1664,7 +1670,8 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
 void launch_update(EkfEngine *e, int M, bool update_cov)
 {
     if (M <= 0) return;
-    if (e->exact) update_impl<float, double>(e, M, update_cov);
+    if (e->exact && e->f32) update_impl<float, double, true>(e, M, update_cov);
+    else if (e->exact) update_impl<double, double, true>(e, M, update_cov);
     else if (e->f32) update_impl<float, float>(e, M, update_cov);
     else update_impl<double, double>(e, M, update_cov);
 }

@@ -16,7 +16,7 @@ from .ekftypes import (DESC_BYTES, KEYPOINT_DTYPE, MATCH_DTYPE, PREDICTION_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libekf_engine.so")
-PRECISION_F64, PRECISION_F32, PRECISION_F32_EXACT = 0, 1, 2
+PRECISION_F64, PRECISION_F32, PRECISION_F32_EXACT, PRECISION_F64_EXACT, PRECISION_AUTO = 0, 1, 2, 3, 4
 
 
 class EkfEngineConfig(C.Structure):
@@ -86,6 +86,7 @@ ABI = {
     "ekf_set_async_errors": (_i, [_vp, _i]),
     "ekf_set_update_path": (_i, [_vp, _i]),
     "ekf_set_sweep_mode": (_i, [_vp, _i]),
+    "ekf_get_precision": (_i, [_vp]),
     "ekf_image_upload": (_i, [_vp, _vp, _i, _i, _i, _i]),
     "ekf_get_image_level": (_i, [_vp, _i, _vp, C.POINTER(_i), C.POINTER(_i)]),
     "ekf_capture_templates": (_i, [_vp, _vp, _vp, _i]),
@@ -198,7 +199,7 @@ class EkfEngine:
             raise EkfError(rc, "ekf_engine_create failed (no MI355X visible?)")
         self.h = h
         self.cap = int(max_features)
-        self.precision = precision
+        self.precision = int(self.L.ekf_get_precision(self.h))  # (what PRECISION_AUTO resolved to)
         self.desc_bytes = self.L.ekf_descriptor_bytes(self.h)
         self.desc_dtype = np.float32 if descriptor_cols_f32 else np.uint8
 

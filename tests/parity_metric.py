@@ -5,11 +5,14 @@ import numpy as np
 F64_TOL = 1e-9   # fp64 engine vs fp64 oracle (different summation orders / FMA only)
 F32_TOL = 1e-5   # the north-star tolerance for the fp32-covariance configuration
 # Every gate below is the north-star figure, UN-widened: each block AND every single feature parameter (against
-# max(|own value|, 1e-4): SURVEY.md 8(d), "abs floor 1e-9").  The configuration that meets it with fp32 storage is
-# EKF_PRECISION_F32_EXACT (fp64 B, exact int8-digit downdate: worst component 2.5e-6 at N = 1000 over five scenes x four frames,
-# profiles/r04_componentwise_n1000.txt).  The fast fp32 MFMA configuration (EKF_PRECISION_F32) does NOT meet the component-wise
-# reading at N >= 1000 (measured up to 7.6e-5; cause: profiles/r03_parity_attribution.txt): callers that run it pass
-# componentwise=False and get the figure reported, not gated -- there is no second, wider tolerance.
+# max(|own value|, 1e-4): SURVEY.md 8(d), "abs floor 1e-9").  The configuration that meets it is EKF_PRECISION_AUTO: the exact
+# update (fp64 B, exact int8-digit downdate) on an fp32-stored covariance up to 1024 features (EKF_PRECISION_F32_EXACT: worst
+# component 2.5e-6 at N = 1000 over five scenes x four frames) and on an fp64-stored one above (EKF_PRECISION_F64_EXACT; fp32 storage
+# alone leaves 1e-5 on fresh maps of >= 1400 features).  The fast fp32 MFMA configuration (EKF_PRECISION_F32) does NOT meet the
+# component-wise reading at N >= 1000 (measured up to 7.6e-5; cause: profiles/r03_parity_attribution.txt): callers that run it pass
+# componentwise=False and get the figure held to FAST_COMPONENT_CEILING only -- a REGRESSION guard of a shipped secondary
+# configuration, not a parity claim.
+FAST_COMPONENT_CEILING = 2e-4
 ASSERTED_BLOCKS = ("r", "q", "v", "w", "feat_xyz", "feat_theta", "feat_phi", "feat_rho", "P_max", "P_fro")
 
 
@@ -61,8 +64,11 @@ def parity_report(x, fp, P, xo, fpo, Po):
 
 
 def over_tolerance(be, tol, n_features=0, componentwise=True):
-    """Blocks (and, unless componentwise=False, the worst single feature parameter) above `tol`."""
+    """Blocks (and, unless componentwise=False, the worst single feature parameter) above `tol`; with componentwise=False (the
+    fast fp32 configuration) the worst feature parameter is held to FAST_COMPONENT_CEILING, a regression guard."""
     bad = {k: v for k, v in be.items() if k in ASSERTED_BLOCKS and not v <= tol}
     if componentwise and not be.get("features_componentwise", 0.0) <= tol:
         bad["features_componentwise"] = be["features_componentwise"]
+    if not componentwise and not be.get("features_componentwise", 0.0) <= max(tol, FAST_COMPONENT_CEILING):
+        bad["features_componentwise (regression ceiling of the fast configuration)"] = be["features_componentwise"]
     return bad

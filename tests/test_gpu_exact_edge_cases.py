@@ -235,3 +235,50 @@ def test_exact_configuration_refuses_maps_whose_int32_level_sums_could_wrap(eng_
     with pytest.raises(eng_mod.EkfError) as ei:
         eng_mod.EkfEngine(seq.cam, seq.par, 13105, max_keypoints=64, precision=EXACT)
     assert ei.value.code == 1  # EKF_ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("M", [1, 17, 33, 64, 129, 160])
+def test_update_sizes_fp64_stored_exact(eng_mod, oracle_lib, M):
+    """EKF_PRECISION_F64_EXACT (what EKF_PRECISION_AUTO selects above 1024 features): the same exact int8 update on an fp64-stored
+    covariance -- the downdate kernel's fp64 epilogue (half a block staged at a time, both images as 16-byte stores) across the
+    blocking boundaries; P stays bitwise symmetric; held to 1e-7 (38-bit digits of B under a-priori column scales; no storage rounding)"""
+    seq = SyntheticSequence(170, 1, outlier_fraction=0.0, distractors_per_feature=0.0, max_bit_flips=0)
+    e, o = make_pair(eng_mod, oracle_lib, seq, precision=3)
+    assert e.precision == 3
+    e.predict()
+    o.predict()
+    e.predict_measurements()
+    preds, Hs, Hf = o.predict_measurements()
+    mo = _matches_from_predictions(preds, M)
+    mp, mHs, mHf = align_to_matches(preds, Hs, Hf, mo)
+    assert o.update(mo, mp, mHs, mHf, ALGORITHMIC) == 0
+    e.update(mo)
+    x, fp, P = e.get_state()
+    be = parity_report(x, fp, P, o.x13(), o.feature_pos(), o.P())
+    assert not over_tolerance(be, 1e-7, 170, componentwise=True), be
+    assert np.array_equal(P, P.T)
+
+
+def test_auto_precision_resolves_by_capacity_and_steps_fp64_stored(eng_mod, oracle_lib):
+    """EKF_PRECISION_AUTO: fp32 storage up to 1024 features, fp64 storage above (ekf_get_precision reports the choice); three frames
+    of an fp64-stored exact engine (the seeded P0 is symmetric to rounding only: the first downdate symmetrises) against the oracle at 1e-7"""
+    seq = SyntheticSequence(150, 3)
+    small = eng_mod.EkfEngine(seq.cam, seq.par, 1024, max_keypoints=64, precision=4)
+    assert small.precision == 2
+    small.close()
+    big = eng_mod.EkfEngine(seq.cam, seq.par, 1025, max_keypoints=len(seq.frames[0][0]) + 64, precision=4)
+    huge = eng_mod.EkfEngine(seq.cam, seq.par, 2049, max_keypoints=64, precision=4)
+    assert huge.precision == 0  # all fp64 above 2048 features
+    huge.close()
+    assert big.precision == 3
+    o = oracle_lib.Oracle(seq.cam, seq.par, 160)
+    P0 = seq.P0
+    big.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, P0)
+    o.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, P0)
+    for t in range(3):
+        _same_info(big.step(*seq.frames[t]), o.step(*seq.frames[t], ALGORITHMIC), f"frame {t}")
+    x, fp, P = big.get_state()
+    be = parity_report(x, fp, P, o.x13(), o.feature_pos(), o.P())
+    assert not over_tolerance(be, 1e-7, 150, componentwise=True), be
+    assert np.array_equal(P, P.T)
+    big.close()
