@@ -34,15 +34,24 @@ def test_mode_b_steps_n2000_1280x720_vs_oracle(eng_mod, oracle_lib, precision):
     N = 2000
     seq = SyntheticSequence(N, 2, width=1280, height=720)
     e, o = _with_templates(eng_mod, oracle_lib, seq, precision=precision)
+
+    def oracle_steps():  # the oracle's two image steps, shared by the two precisions
+        out = []
+        for t in (1, 2):
+            oi = o.step_image(seq.render_image(t), ALGORITHMIC)
+            out.append((oi, np.array(o.x13(), copy=True), np.array(o.feature_pos(), copy=True), np.array(o.P(), copy=True)))
+        return out
+
+    ref = oracle_lib.cached_oracle_run("n2000_1280x720_modeB_2f", oracle_steps)
     for t in (1, 2):
         img = seq.render_image(t)
         gi = e.step_image(img)
-        oi = o.step_image(img, ALGORITHMIC)
+        oi, xo, fpo, Po = ref[t - 1]
         for f in COUNTERS:
             assert getattr(gi, f) == getattr(oi, f), (t, f, getattr(gi, f), getattr(oi, f))
         assert gi.n_matches > 0.6 * N, gi.n_matches
         x, fp, P = e.get_state()
-        be = parity_report(x, fp, P, o.x13(), o.feature_pos(), o.P())
+        be = parity_report(x, fp, P, xo, fpo, Po)
         bad = over_tolerance(be, F32_TOL, N, componentwise=precision == 2)
         print(f"mode B N=2000 1280x720 precision {precision} frame {t}: matches {gi.n_matches} inliers {gi.n_inliers} rescued {gi.n_rescued}",
               {k: f"{v:.2e}" for k, v in be.items()})

@@ -39,22 +39,29 @@ def eng_mod():
     return engine
 
 
-def run_pair(eng_mod, ol, seq, frames, precision=EXACT, path=0):
+def run_pair(eng_mod, ol, seq, frames, precision=EXACT, path=0, key=None):
+    """`key`: the oracle's frames are shared with the other tests that pass the same key (same sequence, same start)"""
     N = seq.n_features
     e = eng_mod.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=precision)
     e.set_update_path(path)
-    o = ol.Oracle(seq.cam, seq.par, N + 8)
     e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
-    o.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    if key is None:
+        o = ol.Oracle(seq.cam, seq.par, N + 8)
+        o.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    else:
+        ref = ol.oracle_frames(seq, frames, seq.P0, key)
     worst = {}
     for t in range(frames):
         ie = e.step(*seq.frames[t])
-        io = o.step(*seq.frames[t], ol.ALGORITHMIC)
+        if key is None:
+            io = o.step(*seq.frames[t], ol.ALGORITHMIC)
+            xo, fpo, Po = o.x13(), o.feature_pos(), o.P()
+        else:
+            io, xo, fpo, Po = ref[t]
         for f in COUNTERS:
             assert getattr(ie, f) == getattr(io, f), (t, f, getattr(ie, f), getattr(io, f))
         x, fp, P = e.get_state()
-        Po = o.P()
-        be = parity_report(x, fp, P, o.x13(), o.feature_pos(), Po)
+        be = parity_report(x, fp, P, xo, fpo, Po)
         for k, v in be.items():
             worst[k] = max(worst.get(k, 0.0), v)
         bad = over_tolerance(be, F32_TOL, N, componentwise=precision != FAST)
@@ -68,14 +75,14 @@ BOTH = pytest.mark.parametrize("precision", [EXACT, FAST], ids=["exact", "fast"]
 
 # the scene of the round-1 driver run (25 frames asked for), the round-1 builder runs (70) and the current generator's
 # (fixed 100-frame horizon), plus two more seeds
+@BOTH  # (the top decorator varies fastest: the two precisions of a scene are adjacent and share the oracle's frames)
 @pytest.mark.parametrize("kw", [dict(horizon=25), dict(horizon=70), dict(), dict(seed=0xC0FFEE), dict(seed=20260102)],
                          ids=["scene25", "scene70", "scene100", "seedA", "seedB"])
-@BOTH
 def test_n1000_fp32_four_frames_vs_oracle(eng_mod, oracle_lib, kw, precision):
     """BASELINE configs[2]: N = 1000, fp32 covariance, four frames: every block and (exact configuration) every feature
     parameter <= 1e-5."""
     seq = SyntheticSequence(1000, 4, **kw)
-    worst = run_pair(eng_mod, oracle_lib, seq, 4, precision=precision)
+    worst = run_pair(eng_mod, oracle_lib, seq, 4, precision=precision, key=("n1000_4f", tuple(sorted(kw.items()))))
     print(f"N=1000 precision {precision} worst errors over 4 frames:", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
@@ -84,7 +91,7 @@ def test_n1000_fp32_inverse_and_gemm_path_vs_oracle(eng_mod, oracle_lib, precisi
     """The same bar with B = inv(L) H P forced onto the explicit inverse + GEMM (the path of updates with more than 2048
     measurement rows; at N = 1000 the sweep path is the default and the five scenes above run it)."""
     seq = SyntheticSequence(1000, 3)
-    worst = run_pair(eng_mod, oracle_lib, seq, 3, precision=precision, path=2)
+    worst = run_pair(eng_mod, oracle_lib, seq, 3, precision=precision, path=2, key="n1000_3f")
     print(f"N=1000 precision {precision} (inverse + GEMM) worst errors over 3 frames:", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
@@ -92,7 +99,7 @@ def test_n1000_fp32_inverse_and_gemm_path_vs_oracle(eng_mod, oracle_lib, precisi
 def test_n2000_fp32_two_frames_vs_oracle(eng_mod, oracle_lib, precision):
     """BASELINE configs[3] map size (N = 2000, 1280x720), fp32 covariance, unsharded engine, two frames."""
     seq = SyntheticSequence(2000, 2, width=1280, height=720)
-    worst = run_pair(eng_mod, oracle_lib, seq, 2, precision=precision)
+    worst = run_pair(eng_mod, oracle_lib, seq, 2, precision=precision, key="n2000_1280x720_2f")
     print(f"N=2000 precision {precision} worst errors over 2 frames:", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
@@ -102,7 +109,7 @@ def test_n1400_two_frames_vs_oracle(eng_mod, oracle_lib, precision):
     and leaves 3e-5 component-wise (round 4).  EKF_PRECISION_AUTO stores such a map in fp64 (EKF_PRECISION_F64_EXACT: same exact
     int8 update): every block and every feature parameter within the plain 1e-5 over two frames, decisions identical."""
     seq = SyntheticSequence(1400, 2, width=1280, height=720)
-    w = run_pair(eng_mod, oracle_lib, seq, 2, precision=precision)
+    w = run_pair(eng_mod, oracle_lib, seq, 2, precision=precision, key="n1400_1280x720_2f")
     print(f"N=1400 precision {precision} worst errors:", {k: f"{v:.2e}" for k, v in w.items()})
 
 

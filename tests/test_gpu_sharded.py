@@ -233,14 +233,16 @@ def test_n2000_four_ranks_against_the_oracle(eng_mod, oracle_lib, precision):
     N = 2000
     seq = SyntheticSequence(N, 1, width=1280, height=720)
     grp, infos = _run_group(seq, 4, precision, 1)
-    o = oracle_lib.Oracle(seq.cam, seq.par, N + 8)
-    o.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, _sym(seq.P0))
-    oi = o.step(*seq.frames[0], ALGORITHMIC)
+    # (the oracle's frames of this sequence are shared with the two-frame tests below: the generator's frame 0 does not depend on
+    # how many frames are asked for)
+    seq2 = SyntheticSequence(N, 2, width=1280, height=720)
+    np.testing.assert_array_equal(seq2.frames[0][0], seq.frames[0][0])
+    oi, xo, fpo, Po = oracle_lib.oracle_frames(seq2, 2, _sym(seq2.P0), "n2000_1280x720_2f_sym")[0]
     for f in INFO_FIELDS:
         assert getattr(infos[0][0], f) == getattr(oi, f), f
     x, fp, P = grp.get_state()
     assert not np.isnan(P).any()
-    be = parity_report(x, fp, P, o.x13(), o.feature_pos(), o.P())
+    be = parity_report(x, fp, P, xo, fpo, Po)
     print(f"N=2000, 4 emulated ranks, precision {precision} vs oracle:", {k: f"{v:.2e}" for k, v in be.items()})
     assert not over_tolerance(be, F32_TOL, N, componentwise=precision == 2), be
     np.testing.assert_array_equal(P, P.T)
@@ -263,16 +265,15 @@ def test_n2000_exact_ranks_two_frames_vs_oracle_and_model(eng_mod, oracle_lib, w
     N, F = 2000, 2
     seq = SyntheticSequence(N, F, width=1280, height=720)
     grp, infos = _run_group(seq, world, 2, F)
-    o = oracle_lib.Oracle(seq.cam, seq.par, N + 8)
-    o.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, _sym(seq.P0))
+    ref = oracle_lib.oracle_frames(seq, F, _sym(seq.P0), "n2000_1280x720_2f_sym")
     for t in range(F):
-        oi = o.step(*seq.frames[t], ALGORITHMIC)
+        oi = ref[t][0]
         for r in range(world):
             for f in INFO_FIELDS:
                 assert getattr(infos[r][t], f) == getattr(oi, f), (r, t, f)
     x, fp, P = grp.get_state()
     assert not np.isnan(P).any()
-    be = parity_report(x, fp, P, o.x13(), o.feature_pos(), o.P())
+    be = parity_report(x, fp, P, ref[F - 1][1], ref[F - 1][2], ref[F - 1][3])
     print(f"N=2000 exact, {world} emulated ranks, 2 frames vs oracle:", {k: f"{v:.2e}" for k, v in be.items()})
     assert not over_tolerance(be, F32_TOL, N), be
     np.testing.assert_array_equal(P, P.T)
