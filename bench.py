@@ -543,15 +543,19 @@ def main():
                 # the #2 kernel of the frame: the blocked Cholesky sweep of S (one launch per 32-row panel; the launches also
                 # form B = inv(L) (H P)).  Latency-bound: the figure to watch is us per panel, the flop rate is for scale.
                 fl = sw["flops_fp64"] + sw["flops_b"]
+                persistent = sw["launches"] == sw["updates"] and sw["panels"] > sw["updates"]
                 roof_sweep = {
-                    "kernel": ("k_chol_step / k_chol_pair (blocked Cholesky of S = H P H' + R, 32-row panels; "
-                               + ("one launch per panel" if sw["launches"] == sw["panels"] else
-                                  f"{sw['launches']} launches for {sw['panels']} panels: part of them two panels per launch (k_chol_pair)")
-                               + ("; rows of B = inv(L) H P in the same launches" if sw["flops_b"] > 0 else "; B by inverse + GEMM afterwards")
+                    "kernel": (("k_chol_persist (blocked Cholesky of S = H P H' + R, 32-row panels, ONE persistent launch per update: a "
+                                "resident chain workgroup factorises panel after panel, tile and row-block workers follow it through flags"
+                                if persistent else
+                                "k_chol_step / k_chol_pair (blocked Cholesky of S = H P H' + R, 32-row panels; "
+                                + ("one launch per panel" if sw["launches"] == sw["panels"] else
+                                   f"{sw['launches']} launches for {sw['panels']} panels: part of them two panels per launch (k_chol_pair)"))
+                               + ("; rows of B = inv(L) H P in the same launch" + ("" if persistent else "es") if sw["flops_b"] > 0 else "; B by inverse + GEMM afterwards")
                                + (", fp64" if exact else "") + ")"),
                     "launches": sw["launches"],
                     "us_per_launch": 1e3 * sw["ms"] / max(sw["launches"], 1),
-                    "bound": "latency (dependent launches)",
+                    "bound": "latency (a chain of dependent 32 x 32 factorisations" + (" and hand-offs inside one launch)" if persistent else ", one launch each)"),
                     "us_per_panel": 1e3 * sw["ms"] / sw["panels"],
                     "panels_per_frame": sw["panels"] / max(int(tm.steps), 1),
                     "ms_per_frame": sw["ms"] / max(int(tm.steps), 1),
@@ -564,8 +568,8 @@ def main():
                         "sweep_end_to_downdate_note": "HIP events: end of the sweep's last launch -> start of the downdate kernel = dx, state "
                                                       "update and, above 2048 rows, the triangular inverse and the int8 GEMM B = inv(L) G"}
                        if exact else {}),
-                    "floor_note": "scripts/micro/persist_chol.hip: a persistent critical workgroup reaches 7.3 us per panel for the "
-                                  "chain alone (profiles/r03_persist_chol_micro.txt); 4.2 us of a panel are the 32x32 factor-and-invert",
+                    "floor_note": "profiles/r05_persist_trace_n1000_f32x.txt: the chain workgroup alone needs 6.5-7 us per panel (4.4-5 us of it the "
+                                  "32 x 32 factor-and-invert under load), the rows of B 8.4-9 us per LATE panel; round 4, one launch per panel: 9.8 us",
                 }
         st = max(int(tm.steps), 1)
         stages = {k: getattr(tm, k) / st for k in ("prediction_ms", "matching_ms", "ransac_ms", "update_li_ms",

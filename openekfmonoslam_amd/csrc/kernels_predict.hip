@@ -8,12 +8,32 @@
 
 namespace ekf {
 
+__device__ void predict_prepare_serial(double *st, double *sG);
+
 // ------------------------------------------------------------------------------------------------ A1 + A2
-// One thread: F (13x13), G Q G' (13x13) from the PRE-prediction state, then the state prediction itself
-// (covariance is predicted before the state, :251-252; dt = 1, :246).
-__global__ void k_predict_prepare(double *st, ParD par)
+// F (13x13), G Q G' (13x13) from the PRE-prediction state, then the state prediction itself (covariance is predicted before
+// the state, :251-252; dt = 1, :246).  One workgroup: thread 0 forms F, G and the predicted state (a chain of a few hundred dependent
+// fp64 operations); the 169 entries of G Q G' -- a thousand multiply-adds, half of the 9 us the kernel took as one thread -- are dealt
+// to the workgroup behind one barrier.
+__global__ void __launch_bounds__(256) k_predict_prepare(double *st, ParD par)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ double sG[13 * 6];
+    const double dt = 1.0;
+    const double ln = par.linearAccelSD * par.linearAccelSD * dt * dt;
+    const double an = par.angularAccelSD * par.angularAccelSD * dt * dt;
+    if (blockIdx.x != 0) return;
+    if (threadIdx.x == 0) predict_prepare_serial(st, sG);
+    __syncthreads();
+    if (threadIdx.x < 169) {
+        const int i = threadIdx.x / 13, j = threadIdx.x % 13;
+        double s = 0.0;
+        for (int k = 0; k < 6; ++k) s += (sG[i * 6 + k] * (k < 3 ? ln : an)) * sG[j * 6 + k];
+        st[ST_GQG + i * 13 + j] = s;
+    }
+}
+
+__device__ void predict_prepare_serial(double *st, double *sG)
+{
     const double dt = 1.0;
     double *x = st + ST_X;
     double *F = st + ST_F, *GQG = st + ST_GQG;
@@ -73,14 +93,8 @@ __global__ void k_predict_prepare(double *st, ParD par)
         G[(i + 10) * 6 + i + 3] = 1.0;
         G[i * 6 + i] = 1.0 * dt;
     }
-    const double ln = par.linearAccelSD * par.linearAccelSD * dt * dt;
-    const double an = par.angularAccelSD * par.angularAccelSD * dt * dt;
-    for (int i = 0; i < 13; ++i)
-        for (int j = 0; j < 13; ++j) {
-            double s = 0.0;
-            for (int k = 0; k < 6; ++k) s += (G[i * 6 + k] * (k < 3 ? ln : an)) * G[j * 6 + k];
-            GQG[i * 13 + j] = s;
-        }
+    for (int i = 0; i < 78; ++i) sG[i] = G[i];
+    (void)GQG;
     // predictState :43-65
     for (int i = 0; i < 3; ++i) x[i] += x[7 + i] * dt;
     {
@@ -155,7 +169,7 @@ __global__ void __launch_bounds__(256) k_predict_cov(T *P, int ld, int n, const 
 
 void launch_predict(EkfEngine *e)
 {
-    k_predict_prepare<<<1, 64, 0, e->stream>>>(e->d.state, e->par);
+    k_predict_prepare<<<1, 256, 0, e->stream>>>(e->d.state, e->par);
     const int nb = 1 + (e->n > 13 ? (e->n - 13 + 255) / 256 : 0);
     if (e->f32)
         k_predict_cov<float><<<nb, 256, 0, e->stream>>>((float *)e->d.P, e->ldP, e->n, e->d.state, e->rm);
