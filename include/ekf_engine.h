@@ -282,6 +282,12 @@ int ekf_timing_sweep_launches(EkfEngine *e, int64_t *launches, double *slice_ms)
  * fp64 arithmetic": the accuracy floor of EKF_PRECISION_F32 / _F32_EXACT on a sequence (scripts/storage_floor_gpu.py).  The
  * reference keeps everything in double (Core/Base.h:67). */
 int ekf_round_covariance_to_f32(EkfEngine *e);
+/* Test aid for the watchdog of the persistent Cholesky sweep (csrc/chol_persist.h): the NEXT persistent sweep of this engine runs
+ * without its chain workgroup -- the situation of a role that never became resident.  Every other role then waits for a hand-off
+ * that cannot come; the bounded waits (30 ms) must end the kernel and the update must return EKF_ERR_TIMEOUT instead of hanging
+ * the stream.  One sweep only; the engine's filter state is undefined afterwards (ekf_set_state / ekf_reset before going on).
+ * No counterpart in the reference. */
+int ekf_debug_stall_next_sweep(EkfEngine *e);
 
 /* -- row-sharded filter (multi-GPU) ----------------------------------------------------------
  * One engine per GPU / rank.  Rank g stores the 13 camera rows of P (replicated, updated identically everywhere)

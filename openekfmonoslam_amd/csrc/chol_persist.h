@@ -58,6 +58,7 @@ struct PsArgs {
     unsigned arrive_base; // tickets handed out before this launch
     int n_b, n_bcols, n_t;
     int n_cus;  // > 0: block n_cus is an empty spacer (in-order dispatch would put it on the chain workgroup's CU)
+    int fault;  // test aid (ekf_debug_stall_next_sweep): the chain workgroup leaves at once, as if it had never become resident
     unsigned long long *trace; // debug builds (-DEKF_SWEEP_TRACE): per-panel time stamps of the roles, see PS_TRACE
 };
 
@@ -565,6 +566,7 @@ __global__ void __launch_bounds__(256, 2) k_chol_persist(PsArgs a)
     const int ticket = role;
     double(*sX)[NB + 1] = lds_blocks[0];
     if (ticket == 0) {
+        if (a.fault) return; // injected stall: every other role now waits for an inverse that never comes -> watchdog
         // ---------------------------------------------------------------------------------------------------- critical chain
         // Panel f: wavefronts 0, 1 factorise A_ff (block_chol_inv32_w2); wavefronts 2, 3 meanwhile prepare row r = f + 1 -- the
         // two tiles the chain needs right after this factorisation:

@@ -1929,6 +1929,13 @@ int ekf_timing_sweep(EkfEngine *e, double *kernel_ms, int64_t *panels, int64_t *
     return EKF_OK;
 }
 
+int ekf_debug_stall_next_sweep(EkfEngine *e)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    e->ps_fault = 1;
+    return EKF_OK;
+}
+
 int ekf_round_covariance_to_f32(EkfEngine *e)
 {
     if (!e) return EKF_ERR_INVALID_ARG;

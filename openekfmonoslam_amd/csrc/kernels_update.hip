@@ -1327,6 +1327,8 @@ static bool launch_persistent_sweep(EkfEngine *e, int m, const double *G, double
     a.G = G; a.Bout = Bout; a.ld = e->ldP; a.bp = bp;
     a.ctl = (SweepCtl *)e->d.sweep_ctl; a.eb = e->ps_epoch * PS_EPOCH_STEP; a.arrive_base = e->ps_arrive;
     a.n_b = n_b; a.n_bcols = n_bcols; a.n_t = n_t; a.n_cus = layout_cus;
+    a.fault = e->ps_fault;
+    e->ps_fault = 0; // one sweep only
     a.trace = nullptr;
 #ifdef EKF_SWEEP_TRACE
     if (g_ps_trace_on) {

@@ -105,6 +105,7 @@ ABI = {
                               C.POINTER(C.c_double)]),
     "ekf_timing_sweep_launches": (_i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ekf_round_covariance_to_f32": (_i, [_vp]),
+    "ekf_debug_stall_next_sweep": (_i, [_vp]),
     "ekf_shard_rows": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "ekf_engine_create_sharded": (_i, [C.POINTER(EkfEngineConfig), _i, _i, C.POINTER(_vp)]),
     "ekf_set_exchange": (_i, [_vp, _vp, _vp]),

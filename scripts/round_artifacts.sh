@@ -13,8 +13,12 @@ $B --workload n1000_f32 > "$out/bench_n1000_f32.json" 2> /dev/null
 $B --workload n200_f64 --steps 60 --warmup 10 > "$out/bench_n200_f64.json" 2> /dev/null
 $B --workload n2000_f32x --steps 20 --warmup 5 > "$out/bench_n2000_f32x.json" 2> /dev/null
 $B --workload n2000_f32 --steps 20 --warmup 5 > "$out/bench_n2000_f32.json" 2> /dev/null
+$B --workload n2000_auto --steps 20 --warmup 5 > "$out/bench_n2000_auto.json" 2> /dev/null
 $B --workload n5000_f32x --steps 3 --warmup 1 > "$out/bench_n5000_f32x.json" 2> /dev/null
+$B --workload n5000_f64x --steps 3 --warmup 1 > "$out/bench_n5000_f64x.json" 2> /dev/null
 $B --workload n5000_f32 --steps 3 --warmup 1 > "$out/bench_n5000_f32.json" 2> /dev/null
+$B --workload n1000_f32x --sweep-mode 4 > "$out/bench_n1000_f32x_launches.json" 2> /dev/null
+$B --workload n200_f64 --sweep-mode 4 --steps 60 --warmup 10 > "$out/bench_n200_f64_launches.json" 2> /dev/null
 $B --matcher ncc --workload n2000_f32x --steps 20 --warmup 5 > "$out/bench_n2000_f32x_ncc.json" 2> /dev/null
 $B --emulate-shards 4 --workload n2000_f32x --steps 6 --warmup 2 --no-cpu-baseline > "$out/bench_n2000_f32x_emulated4.json" 2> /dev/null
 # the downdate kernel alone: variants (0 persistent, 1 first version), bitwise check against the CPU, ablations when built
@@ -22,11 +26,11 @@ for v in 0 1; do timeout 300 scripts/micro/pu_i8_bench 1000 298,1014,2000 15 $v;
 for a in 1 3 7 11 15; do
   [ -x scripts/micro/pu_i8_bench_abl$a ] && { echo "== PX_ABL=$a"; timeout 120 scripts/micro/pu_i8_bench_abl$a 1000 1014 15 0 | tail -3; }
 done >> "$out/pu_i8_bench.txt" 2>&1
-# per-role sweep traces: only when the debug build is there (scripts/build_trace_variant.sh)
+# timelines of the persistent sweep: only when the debug build is there (scripts/build_trace_variant.sh)
 if [ -f variants/libekf_engine_trace.so ]; then
-  EKF_ENGINE_LIB=variants/libekf_engine_trace.so SWEEP_MODE=1 PRECISION=2 timeout 300 python scripts/sweep_trace.py 1000 15 2>/dev/null | grep -v amdgpu.ids > "$out/sweep_trace_n1000_f32x.txt"
-  EKF_ENGINE_LIB=variants/libekf_engine_trace.so SWEEP_MODE=1 PRECISION=1 timeout 300 python scripts/sweep_trace.py 1000 15 2>/dev/null | grep -v amdgpu.ids > "$out/sweep_trace_n1000_f32.txt"
-  EKF_ENGINE_LIB=variants/libekf_engine_trace.so SWEEP_MODE=1 PRECISION=2 timeout 300 python scripts/sweep_trace.py 2000 6 2>/dev/null | grep -v amdgpu.ids > "$out/sweep_trace_n2000_f32x.txt"
+  EKF_ENGINE_LIB=variants/libekf_engine_trace.so timeout 300 python scripts/persist_trace.py 1000 12 0 2>/dev/null | grep -v amdgpu.ids > "$out/persist_trace_n1000_f32x.txt"
+  EKF_ENGINE_LIB=variants/libekf_engine_trace.so timeout 300 python scripts/persist_trace.py 1000 12 1 2>/dev/null | grep -v amdgpu.ids > "$out/persist_trace_n1000_f32x_hi.txt"
+  EKF_ENGINE_LIB=variants/libekf_engine_trace.so PRECISION=0 timeout 300 python scripts/persist_trace.py 200 12 0 2>/dev/null | grep -v amdgpu.ids > "$out/persist_trace_n200_f64.txt"
 fi
 bash scripts/profile_all.sh "$out/prof"
 mv "$out"/prof/kernel_stats_*.csv "$out"/ 2>/dev/null

@@ -237,6 +237,40 @@ def test_exact_configuration_refuses_maps_whose_int32_level_sums_could_wrap(eng_
     assert ei.value.code == 1  # EKF_ERR_INVALID_ARG
 
 
+@pytest.mark.parametrize("precision", [EXACT, 0])
+def test_stalled_persistent_sweep_ends_with_a_timeout_error_not_a_hang(eng_mod, oracle_lib, precision):
+    """Watchdog of the persistent Cholesky sweep (csrc/chol_persist.h; round-4 review: "a bounded spin must end the kernel with an
+    error, never hang"): ekf_debug_stall_next_sweep makes the next sweep run WITHOUT its chain workgroup, so every tile worker and
+    every B worker waits for an inverse that is never published.  The update must come back -- within the 30 ms bound of the waits,
+    asserted here as < 5 s of wall time -- with EKF_ERR_TIMEOUT (8); the error is tagged with the sweep's epoch, so after the state
+    is uploaded again the SAME engine's next update runs and matches the oracle (planes role and fp64 role)."""
+    import time
+    seq = SyntheticSequence(170, 1, outlier_fraction=0.0, distractors_per_feature=0.0, max_bit_flips=0)
+    e, o = make_pair(eng_mod, oracle_lib, seq, precision=precision)
+    e.predict()
+    e.predict_measurements()
+    o.predict()
+    preds, Hs, Hf = o.predict_measurements()
+    mo = _matches_from_predictions(preds, 129)
+    assert e.L.ekf_debug_stall_next_sweep(e.h) == 0
+    t0 = time.time()
+    with pytest.raises(eng_mod.EkfError) as ei:
+        e.update(mo)
+        e.synchronize()
+    assert ei.value.code == 8, ei.value  # EKF_ERR_TIMEOUT
+    assert time.time() - t0 < 5.0
+    # the engine is usable again: same filter state uploaded, same update, this time with its chain
+    e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    e.predict()
+    e.predict_measurements()
+    mp, mHs, mHf = align_to_matches(preds, Hs, Hf, mo)
+    assert o.update(mo, mp, mHs, mHf, ALGORITHMIC) == 0
+    e.update(mo)
+    x, fp, P = e.get_state()
+    be = parity_report(x, fp, P, o.x13(), o.feature_pos(), o.P())
+    assert not over_tolerance(be, F32_TOL if precision == EXACT else 1e-9, 170, componentwise=True), be
+
+
 @pytest.mark.parametrize("M", [1, 17, 33, 64, 129, 160])
 def test_update_sizes_fp64_stored_exact(eng_mod, oracle_lib, M):
     """EKF_PRECISION_F64_EXACT (what EKF_PRECISION_AUTO selects above 1024 features): the same exact int8 update on an fp64-stored
