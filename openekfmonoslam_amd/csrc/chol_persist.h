@@ -409,6 +409,7 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
         }
     }
     __syncthreads();
+    if (bcol == a.bp.bcol0) { PS_TRACE(tb, k, 5) }
     if (*fail_s) return false;
     double(*sR)[NB + 1] = pool[4];
 #pragma unroll
@@ -423,6 +424,7 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
         for (int q = 0; q < 4; ++q) sO[16 * bi + lk + 4 * q][16 * bj + lr] = o[q];
     }
     __syncthreads();
+    if (bcol == a.bp.bcol0) { PS_TRACE(tb, k, 6) }
     {   // the block's digit planes: thread (k half, 4-row quarter, column) cuts four rows of its column: four bytes per plane
         const int col = tid & 31, qr = (tid >> 5) & 3, kh = tid >> 7;
         const int sh = 8 * PX_S - 2 - (bp.bexp[c0 + col] - 1022);
@@ -440,6 +442,7 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
 #pragma unroll
         for (int s = 0; s < PX_S; ++s) *(unsigned *)(dst + (size_t)s * bp.b_stride) = w[s];
     }
+    if (bcol == a.bp.bcol0) { PS_TRACE(tb, k, 7) }
     // (frees the LDS blocks; the stores of the planes drain beside the next panel's sums and are waited for there)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

@@ -330,7 +330,7 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     ALLOC(d.mHf, 12 * cap);
     ALLOC(d.mpos, cap);
     ALLOC(d.mdim, cap);
-    ALLOC(d.dx_part, (size_t)DX_SPLIT * e->ldP);
+    ALLOC(d.dx_part, (size_t)DX_SPLIT * e->ldP + 8); // + the quaternion before the update (k_apply_normalize)
     ALLOC(d.sq_part, (size_t)DX_SPLIT * e->ldP);
     ALLOC(d.diag_save, (size_t)e->ldP);
     ALLOC(d.cam_part, (size_t)DX_SPLIT * 13 * e->ldP);

@@ -127,7 +127,7 @@ struct DeviceArrays {
     double *mHf = nullptr;
     int *mpos = nullptr;
     int *mdim = nullptr;
-    double *dx_part = nullptr; // DX_SPLIT x ldP
+    double *dx_part = nullptr; // DX_SPLIT x ldP (+ 4: the quaternion as it was before the update)
     double *sq_part = nullptr; // DX_SPLIT x ldP: partial sums of squares of the columns of B (fp64 diagonal of B'B)
     double *diag_save = nullptr; // ldP: diagonal of P before a downdate
     double *cam_part = nullptr;  // DX_SPLIT x 13 x ldP: partial sums of the camera rows of B'B (fp64)

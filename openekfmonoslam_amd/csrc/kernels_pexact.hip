@@ -150,9 +150,12 @@ k_planes_move(int8_t *Bq, size_t b_stride, int ldq, int m16, int c_lo, int c_hi,
 }
 
 __global__ void __launch_bounds__(256)
-k_dx_planes(const int8_t *Bq, size_t b_stride, int ldq, int m16, int n, const int *bexp, const double *z, double *part, int ldpart)
+k_dx_planes(const int8_t *Bq, size_t b_stride, int ldq, int m16, int n, const int *bexp, const double *z, double *part, int ldpart,
+            const double *st)
 {
     const int j = blockIdx.x * 256 + threadIdx.x, ks = blockIdx.y;
+    // the quaternion as it is before this update, for k_apply_normalize (whose workgroups each need it while one of them rewrites it)
+    if (blockIdx.x == 0 && ks == 0 && threadIdx.x < 4) part[(size_t)DX_SPLIT * ldpart + threadIdx.x] = st[ST_X + 3 + threadIdx.x];
     if (j >= n) return;
     const int per = (m16 + DX_SPLIT - 1) / DX_SPLIT;
     const int kb0 = ks * per, kb1 = min(m16, kb0 + per);
@@ -205,7 +208,7 @@ void launch_dx_planes(EkfEngine *e, int m_k)
 {
     const size_t b_stride = (size_t)e->bq_rows * e->ldP;
     k_dx_planes<<<dim3((e->n + 255) / 256, DX_SPLIT), 256, 0, e->stream>>>(e->d.Bq, b_stride, e->ldP, m_k / 16, e->n, e->d.Bexp, e->d.zvec,
-                                                                        e->d.dx_part, e->ldP);
+                                                                        e->d.dx_part, e->ldP, e->d.state);
 }
 
 // ------------------------------------------------------------------------------------------------ the downdate

@@ -973,11 +973,14 @@ __global__ void __launch_bounds__(256) k_yvec(const double *W, int ldw, int m, c
 template <typename T, bool USE_G, typename TG = T> // T: type of B and of the gathered rows G; TG: storage type of P
 __global__ void __launch_bounds__(256)
 k_dx_partial(const T *B, int ld, int m, int n, const double *z, double *part, int ldpart, double *sq_part, double *cam_part,
-             const double *Bc, const TG *P, RowMap rm, double *dsave, double *csave, int avg, const T *G, const double *y, int *bexp)
+             const double *Bc, const TG *P, RowMap rm, double *dsave, double *csave, int avg, const T *G, const double *y, int *bexp,
+             const double *st)
 {
     __shared__ double sc[64][13]; // fp64 camera columns of a chunk of rows of B
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int ks = blockIdx.y;
+    // the quaternion as it is before this update, for k_apply_normalize (whose workgroups each need it while one of them rewrites it)
+    if (blockIdx.x == 0 && ks == 0 && threadIdx.x < 4) part[(size_t)DX_SPLIT * ldpart + threadIdx.x] = st[ST_X + 3 + threadIdx.x];
     if (ks == 0 && csave && j < n) {
         // phase 0 of the fp64 fix (k_fix_normalize): keep the diagonal and the camera rows of P as they are before the downdate
         // (avg: the first downdate after an arbitrary upload works on 0.5 (P(a,j) + P(j,a)))
@@ -1163,6 +1166,115 @@ __global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, cons
         }
         P[(size_t)(3 + a) * ld + j] = (T)s;
         if (mine) prow[3 + a] = (T)t;
+    }
+}
+
+// stateUpdate and normalizeCovariance in ONE launch behind the downdate (exact and fp64 configurations, covariance updates):
+// k_state_apply + k_normalize_cov, same arithmetic in the same order.  The downdate reads neither the state nor J, so the state
+// update may follow it; what every workgroup needs for its strip of P is J, i.e. the un-normalised updated quaternion: each
+// recomputes it from the quaternion as it was before the update (saved beside the k-splits of dx by the dx kernel -- workgroup 0
+// rewrites the live one meanwhile) and its four components of dx.  Workgroup 0 owns the camera state and the 7 x 7 corner,
+// workgroup b >= 1 the columns 7 + 256 (b - 1) ... of the strips; thread t of the grid owns feature parameter t.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_apply_normalize(T *P, int ld, int n, double *st, RowMap rm, double *feat_pos, const int *feat_type, const int *feat_covpos, int N,
+                  const double *part, int ldpart)
+{
+    __shared__ double J[16];
+    __shared__ double C[7][7];
+    __shared__ double cam[13];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x * 256 + tid;
+    const bool live = t < N * 6 && (t % 6) < feat_dim(feat_type[t / 6]);
+    const int jf = live ? feat_covpos[t / 6] + t % 6 : 0;
+    double pv[DX_SPLIT];
+#pragma unroll
+    for (int ks = 0; ks < DX_SPLIT; ++ks) pv[ks] = part[(size_t)ks * ldpart + jf];
+    if (tid < 13 && (blockIdx.x == 0 || (tid >= 3 && tid < 7))) {
+        double s = 0.0;
+#pragma unroll
+        for (int ks = 0; ks < DX_SPLIT; ++ks) s += part[(size_t)ks * ldpart + tid];
+        cam[tid] = s;
+    }
+    if (blockIdx.x == 0 && tid < 49) C[tid / 7][tid % 7] = (double)P[(size_t)(tid / 7) * ld + tid % 7];
+    __syncthreads();
+    if (tid == 0) {
+        if (blockIdx.x == 0) {
+            double *x = st + ST_X;
+            for (int i = 0; i < 13; ++i)
+                if (fabs(cam[i]) > EKF_DELTA) x[i] += cam[i];
+            quat_norm_dev(st);
+            for (int i = 0; i < 16; ++i) J[i] = st[ST_JN + i];
+        } else {
+            const double *q0 = part + (size_t)DX_SPLIT * ldpart;
+            double q[4];
+            for (int i = 0; i < 4; ++i) {
+                q[i] = q0[i];
+                if (fabs(cam[3 + i]) > EKF_DELTA) q[i] += cam[3 + i];
+            }
+            const double r = q[0], x = q[1], y = q[2], z = q[3];
+            const double nrm = sqrt(r * r + x * x + y * y + z * z);
+            const double a = 1.0 / (nrm * nrm * nrm);
+            const double M[16] = {x * x + y * y + z * z, -r * x, -r * y, -r * z,
+                                  -x * r, r * r + y * y + z * z, -x * y, -x * z,
+                                  -y * r, -y * x, r * r + x * x + z * z, -y * z,
+                                  -z * r, -z * x, -z * y, r * r + x * x + y * y};
+            for (int i = 0; i < 16; ++i) J[i] = M[i] * a;
+        }
+    }
+    if (live) {
+        double s = 0.0;
+#pragma unroll
+        for (int ks = 0; ks < DX_SPLIT; ++ks) s += pv[ks];
+        if (fabs(s) > EKF_DELTA) feat_pos[6 * (t / 6) + t % 6] += s;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        if (tid < 12) { // P[0:3,3:7] J'
+            const int i = tid / 4, a = tid % 4;
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += C[i][3 + k] * J[a * 4 + k];
+            P[(size_t)i * ld + 3 + a] = (T)s;
+        } else if (tid < 24) { // J P[3:7,0:3]
+            const int u = tid - 12, a = u / 3, j = u % 3;
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += J[a * 4 + k] * C[3 + k][j];
+            P[(size_t)(3 + a) * ld + j] = (T)s;
+        } else if (tid < 40) { // J P[3:7,3:7] J' : upper triangle, mirrored (keeps P bitwise symmetric)
+            const int u = tid - 24, a = u / 4, b = u % 4;
+            if (a <= b) {
+                double s = 0.0;
+                for (int l = 0; l < 4; ++l) {
+                    double v = 0.0;
+                    for (int k = 0; k < 4; ++k) v += J[a * 4 + k] * C[3 + k][3 + l];
+                    s += v * J[b * 4 + l];
+                }
+                P[(size_t)(3 + a) * ld + 3 + b] = (T)s;
+                P[(size_t)(3 + b) * ld + 3 + a] = (T)s;
+            }
+        }
+        return;
+    }
+    const int j = 7 + (blockIdx.x - 1) * 256 + tid;
+    if (j >= n) return;
+    const bool mine = owns_row(rm, j); // sharded storage: the column strip exists only for owned rows
+    T *prow = P + (size_t)local_row(rm, j) * ld;
+    double col[4], row[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        col[k] = (double)P[(size_t)(3 + k) * ld + j];
+        row[k] = mine ? (double)prow[3 + k] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        double s = 0.0, u = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s += J[a * 4 + k] * col[k];
+            u += row[k] * J[a * 4 + k];
+        }
+        P[(size_t)(3 + a) * ld + j] = (T)s;
+        if (mine) prow[3 + a] = (T)u;
     }
 }
 
@@ -1428,6 +1540,10 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     bool persist = (e->sweep_mode == EKF_SWEEP_AUTO || e->sweep_mode == EKF_SWEEP_PERSISTENT) && b_in_sweep && m_pad <= B_SWEEP_MAX &&
                    !sharded && sizeof(TB) == 8 && e->d.sweep_ctl != nullptr;
     if (persist && (planes_b ? persist_capacity<true>(e) : persist_capacity<false>(e)) < 64) persist = false;
+    // by size: one B worker per block of 32 columns is what the persistent sweep is laid out for; on wider maps (from 8192 state columns
+    // on, where the launch-per-panel sweep switches to two panels per launch) its B workers take several blocks each and it loses:
+    // N = 2000, 20.4 against 14.0 us per panel (profiles/r05_bench_n2000_f32x_persistent.json)
+    if (persist && e->sweep_mode == EKF_SWEEP_AUTO && n_pad >= 8192) persist = false;
     double *V = e->d.Dinv, *W = b_in_sweep ? nullptr : e->d.W; // W = inv(L)' (and L row-major in LL): the GEMM path's
     float *Wf = sizeof(TB) == 4 && !b_in_sweep ? e->d.Wf : nullptr;
     {
@@ -1595,6 +1711,9 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
 #ifdef EKF_SWEEP_TRACE // accuracy experiments of the debug build: B = inv(L) G above 2048 rows by the fp64 GEMM, cut into planes afterwards
     if (std::getenv("EKF_DBG_FP64_GEMM") && !sharded) gemm_planes = false;
 #endif
+    // covariance updates of the exact and the fp64 configuration: the state update waits behind the downdate and shares a launch
+    // with the normalisation of the covariance (k_apply_normalize); the fast fp32 configuration keeps its own tail (k_fix_normalize)
+    const bool merged_tail = update_cov && !(sizeof(T) == 4 && !EXACT);
     if (gemm_planes) {
         const int c_lo = shard_cols ? col_rb[e->shard_rank] : 0, c_hi = shard_cols ? col_rb[e->shard_rank + 1] : n_pad;
         launch_b_gemm_planes(e, m, c_lo, c_hi);
@@ -1625,13 +1744,15 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         launch_planes_move(e, false, m_k, 0, n_pad, col_rb[e->shard_rank], col_rb[e->shard_rank + 1]);
         launch_dx_planes(e, m_k);
         const int nt = max(e->N * 6, 1);
-        k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
-                                                       e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
+        if (!merged_tail)
+            k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
+                                                           e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
     } else if (gemm_planes || planes_b) { // B exists as digit planes only
         launch_dx_planes(e, round_up(m, 32));
         const int nt = max(e->N * 6, 1);
-        k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
-                                                       e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
+        if (!merged_tail)
+            k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
+                                                           e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
     } else {
         dim3 grid((n + 255) / 256, DX_SPLIT);
         const bool fix = update_cov && sizeof(T) == 4 && !EXACT; // (the exact downdate needs no fp64 repair of the diagonal / camera rows)
@@ -1648,13 +1769,14 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
 #define DX_LAUNCH(USEG) k_dx_partial<TB, USEG, T><<<grid, 256, 0, s>>>(A, ld, m, n, e->d.zvec, e->d.dx_part, ld, \
                                              fix ? e->d.sq_part : nullptr, fix ? e->d.cam_part : nullptr, Bc, (const T *)e->d.P, \
                                              e->rm, e->d.diag_save, fix ? e->d.cam_save : nullptr, avg, Gy, e->d.yvec, \
-                                             (EXACT && update_cov && !apriori) ? e->d.Bexp : nullptr);
+                                             (EXACT && update_cov && !apriori) ? e->d.Bexp : nullptr, e->d.state);
         if (Gy) { DX_LAUNCH(true) } else { DX_LAUNCH(false) }
 #undef DX_LAUNCH
 
         const int nt = max(e->N * 6, 1);
-        k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
-                                                       e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
+        if (!merged_tail)
+            k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
+                                                           e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
     }
     if (!update_cov) return;
     const bool fix_diag = sizeof(T) == 4 && !EXACT;
@@ -1666,6 +1788,12 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         return;
     }
     const int nb = 1 + (n > 7 ? (n - 7 + 255) / 256 : 0);
+    if (merged_tail) {
+        const int nt = max(e->N * 6, 1);
+        k_apply_normalize<T><<<max(nb, (nt + 255) / 256), 256, 0, s>>>((T *)e->d.P, ld, n, e->d.state, e->rm, e->d.feat_pos, e->d.feat_type,
+                                                                       e->d.feat_covpos, e->N, e->d.dx_part, ld);
+        return;
+    }
     k_normalize_cov<T><<<nb, 256, 0, s>>>((T *)e->d.P, ld, n, e->d.state, e->rm);
 }
 
