@@ -249,12 +249,24 @@ __device__ __forceinline__ void ps_store_l_planes(const BPlanes &bp, int m, int 
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// What a B worker that owns ONE block of columns (CHAINED: its next call is the next panel of the same columns) knows about the next
+// panel when it gets there: the tail of a panel looks once at every flag the next panel waits for (wavefront-uniform answers; a
+// worker that trails the chain finds all of them up).  Only these three bits travel between the calls: operands requested ahead
+// would have to stay in registers across the loop's back edge, and the compiler parks them in scratch (measured: 13.6 us per panel).
+struct PsBNext {
+    bool sums, last, inv; // all L(k+1, j), j < k, published; L(k+1, k) published; inv(L_{k+1,k+1}) published
+};
+
 // Row block k of B from digit planes, persistent form of b_rows_planes (chol_bplanes.h): the planes of L come from other
-// workgroups of this launch (sc1 buffer loads), the planes of the finished rows of B are this workgroup's own (plain loads, ordered
-// behind its stores by the barrier that ends a panel); the blocks j < k - 1 are summed before L(k, k-1) and inv(L_kk) exist.
-// Every wait is per WAVEFRONT (no barrier around a poll): a wavefront whose wait fails raises fail_s and the workgroup leaves
-// together at the next barrier.  pool: [0..3] the wavefronts' partial sums (then [0] the finished block), [4] the right-hand side.
-__device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bcol, double (*pool)[NB][NB + 1], double (*sLi)[NB + 1], int *fail_s)
+// workgroups of this launch (sc1 buffer loads), the planes of the finished rows of B are this workgroup's own (plain loads; the
+// barriers of a panel's tail drain its stores long before anyone reads them).  Every wait is per WAVEFRONT (no barrier around a
+// poll): a wavefront whose wait fails raises fail_s and the workgroup leaves together at the next barrier.
+// pool: [0..3] the wavefronts' partial sums (then [0] the finished block), [4] the right-hand side, [5] CHAINED: the digit planes of
+// the block just finished, for the wavefront that owns it in the next panel (no trip through memory, no barrier for visibility).
+// Fixed cost per panel before this form (profiles/r05_persist_layout.txt): ~7 of 9 us -- flag polls and first operands one round trip
+// after the other, the last block's planes read back from memory behind a barrier, exponents loaded in the conversion.
+__device__ __forceinline__ bool ps_b_rows_planes(const bool CHAINED, const PsArgs &a, int k, int bcol, double (*pool)[NB][NB + 1],
+                                                 double (*sLi)[NB + 1], int *fail_s, PsBNext &nx, const int ec)
 {
     const BPlanes &bp = a.bp;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -264,7 +276,8 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
     unsigned *lrdy = a.ctl->flags + PS_NBC * PS_NBC;
     const int tb = 1024;
     (void)tb;
-    // this thread's four elements of G_k (cold, needed at the end)
+    int8_t *sBq = (int8_t *)pool[5]; // [plane][k half][column][16]
+    // this thread's four elements of G_k and the scale of its row of L (cold, needed at the end)
     const int r4 = tid >> 3, cg = (tid & 7) * 4;
     double g4[4];
     {
@@ -272,6 +285,7 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
 #pragma unroll
         for (int e = 0; e < 4; ++e) g4[e] = gr >= 0 ? a.G[(size_t)gr * ld + c0 + cg + e] : 0.0;
     }
+    const int er4 = k0 + r4 < m ? bp.lexp[k0 + r4] - 1022 : 0;
     bp_v16i acc[PX_S];
 #pragma unroll
     for (int L = 0; L < PX_S; ++L)
@@ -283,8 +297,11 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
     const size_t bstep = (size_t)2 * bp.ldq * 16;
     // inv(L_kk): a B worker that trails the chain finds it published already -- its four elements travel beside the sums
     double gv[4];
-    bool have_inv = ps_reached(ps_flag(&a.ctl->inv_ready), a.eb + k + 1);
-    have_inv = __builtin_amdgcn_readfirstlane(have_inv ? 1 : 0) != 0;
+    bool have_inv = CHAINED && nx.inv;
+    if (!have_inv) {
+        have_inv = ps_reached(ps_flag(&a.ctl->inv_ready), a.eb + k + 1);
+        have_inv = __builtin_amdgcn_readfirstlane(have_inv ? 1 : 0) != 0;
+    }
     if (have_inv) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -295,7 +312,7 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
 #ifndef PS_STAGES
 #define PS_STAGES 2 // operand blocks in flight (a third stage spills 49 registers at two workgroups per CU: 12.0 against 9.5 us per panel)
 #endif
-    bp_v4i la[PS_STAGES][PX_S], lb[PS_STAGES][PX_S];
+    bp_v4i la[2][PX_S], lb[2][PX_S];
 #define PSB_LOAD(S_, J_)                                                                                          \
     _Pragma("unroll") for (int s = 0; s < PX_S; ++s) {                                                            \
         la[S_][s] = __builtin_amdgcn_raw_buffer_load_b128(lq, pl_off + (unsigned)(J_) * 1024u + (unsigned)(s * bp.l_stride), 0, 16); \
@@ -305,29 +322,15 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
     _Pragma("unroll") for (int s = 0; s < PX_S; ++s)                                                              \
         _Pragma("unroll") for (int t = 0; t < PX_S - s; ++t)                                                      \
             acc[s + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(la[S_][s], lb[S_][t], acc[s + t], 0, 0, 0);
-    // phase A: the blocks j < kp - 1 (their L(k, j) were published at least one panel ago), this wavefront's j = wv, wv + 4, ...
+    const bool mine = kp > 0 && ((kp - 1) & 3) == wv;
     bool ok = true;
+    // the blocks j < kp - 1 (their L(k, j) were published at least one panel ago), this wavefront's j = wv, wv + 4, ...
     {
         const int jA = kp - 1;
         const int cnt = jA > wv ? (jA - wv + 3) / 4 : 0;
-        if (cnt > 0) ok = ps_wwait_strided(lrdy + (size_t)kp * PS_NBC, wv, 4, cnt, a.eb + 1, a.ctl, a.counts, a.eb, 0x5000u + k);
+        if (cnt > 0 && !(CHAINED && nx.sums))
+            ok = ps_wwait_strided(lrdy + (size_t)kp * PS_NBC, wv, 4, cnt, a.eb + 1, a.ctl, a.counts, a.eb, 0x5000u + k);
         if (ok) {
-#if PS_STAGES == 3
-            if (cnt > 0) { PSB_LOAD(0, wv) }
-            if (cnt > 1) { PSB_LOAD(1, wv + 4) }
-            for (int i = 0; i < cnt; i += 3) {
-                if (i + 2 < cnt) { PSB_LOAD(2, wv + 4 * (i + 2)) }
-                PSB_MMA(0)
-                if (i + 1 < cnt) {
-                    if (i + 3 < cnt) { PSB_LOAD(0, wv + 4 * (i + 3)) }
-                    PSB_MMA(1)
-                }
-                if (i + 2 < cnt) {
-                    if (i + 4 < cnt) { PSB_LOAD(1, wv + 4 * (i + 4)) }
-                    PSB_MMA(2)
-                }
-            }
-#else
             if (cnt > 0) { PSB_LOAD(0, wv) }
             for (int i = 0; i < cnt; i += 2) {
                 if (i + 1 < cnt) { PSB_LOAD(1, wv + 4 * (i + 1)) }
@@ -337,41 +340,28 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
                     PSB_MMA(1)
                 }
             }
-#endif
         }
     }
     if (bcol == a.bp.bcol0) { PS_TRACE(tb, k, 1) }
-    // phase B: the last block, j = kp - 1, by the wavefront whose turn it is.  Its planes of B are this workgroup's own stores of the
-    // previous panel, which ended without draining them: every wavefront's stores are older than the loads it has just waited for
-    // (the memory counter is in order), so one barrier makes them visible.  A worker that trails the chain finds L(k, k-1) published
-    // already and requests its planes BEFORE that barrier.
+    // the last block, j = kp - 1, by the wavefront whose turn it is.  CHAINED: its planes of B are in LDS since the previous tail (whose
+    // last barrier everyone has passed).  Otherwise (several blocks of columns per worker) they are this workgroup's own stores of an
+    // earlier call: every wavefront's stores are older than the loads it has just waited for, so one barrier makes them visible.
+    // (One copy of the products for both cases: the address is a flat one.)
     if (kp > 0) {
-        const bool mine = ((kp - 1) & 3) == wv;
-        bool early = false;
-        if (ok && mine) {
-            early = ps_reached(ps_flag(lrdy + (size_t)kp * PS_NBC + kp - 1), a.eb + 1);
-            early = __builtin_amdgcn_readfirstlane(early ? 1 : 0) != 0;
-            if (early) {
-#pragma unroll
-                for (int s = 0; s < PX_S; ++s)
-                    la[0][s] = __builtin_amdgcn_raw_buffer_load_b128(lq, pl_off + (unsigned)(kp - 1) * 1024u + (unsigned)(s * bp.l_stride), 0, 16);
-            }
+        if (!CHAINED) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
-        if (early) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PX_S) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
         if (ok && mine) {
-            if (!early) {
-                ok = ps_wwait(lrdy + (size_t)kp * PS_NBC + kp - 1, a.eb + 1, a.ctl, a.counts, a.eb, 0x5100u + k);
-                if (ok) {
-#pragma unroll
-                    for (int s = 0; s < PX_S; ++s)
-                        la[0][s] = __builtin_amdgcn_raw_buffer_load_b128(lq, pl_off + (unsigned)(kp - 1) * 1024u + (unsigned)(s * bp.l_stride), 0, 16);
-                }
-            }
+            if (!(CHAINED && nx.last)) ok = ps_wwait(lrdy + (size_t)kp * PS_NBC + kp - 1, a.eb + 1, a.ctl, a.counts, a.eb, 0x5100u + k);
             if (ok) {
+                const int8_t *own = CHAINED ? (const int8_t *)(sBq + ((size_t)kg * NB + idx) * 16) : pb + (size_t)(kp - 1) * bstep;
+                const size_t own_step = CHAINED ? (size_t)2 * NB * 16 : bp.b_stride;
 #pragma unroll
-                for (int s = 0; s < PX_S; ++s) lb[0][s] = *(const bp_v4i *)(pb + (size_t)(kp - 1) * bstep + (size_t)s * bp.b_stride);
+                for (int s = 0; s < PX_S; ++s) {
+                    la[0][s] = __builtin_amdgcn_raw_buffer_load_b128(lq, pl_off + (unsigned)(kp - 1) * 1024u + (unsigned)(s * bp.l_stride), 0, 16);
+                    lb[0][s] = *(const bp_v4i *)(own + (size_t)s * own_step);
+                }
                 PSB_MMA(0)
             }
         }
@@ -395,26 +385,40 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
 #pragma unroll
         for (int q = 0; q < 4; ++q) sLi[(tid + q * 256) / NB][(tid + q * 256) % NB] = gv[q];
     } else if (lane == 0) *fail_s = 1;
-    // levels -> fp64; the four wavefronts' partial sums meet in LDS (pool[0..3]), one barrier
-    {
-        const int ec = bp.bexp[c0 + idx] - 1022;
+    // one look at everything the NEXT panel waits for (lane j: L(k+1, j) published?  all lanes: how many inverses are out); the
+    // answer is read behind the barrier below
+    const int K = k + 1;
+    const bool look = CHAINED && K < a.nbk;
+    unsigned f_l = 0, f_inv = 0;
+    if (look) {
+        if (lane < K) f_l = ps_flag(lrdy + (size_t)K * PS_NBC + lane);
+        f_inv = ps_flag(&a.ctl->inv_ready);
+    }
+    // levels -> fp64 (no loads here: the column scale came with the call, the row scales of L are applied to the sum below); the four
+    // wavefronts' partial sums meet in LDS (pool[0..3]), one barrier
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
-            double tsum = (double)acc[PX_S - 1][r];
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
+        double tsum = (double)acc[PX_S - 1][r];
 #pragma unroll
-            for (int L = PX_S - 2; L >= 0; --L) tsum = fma(tsum, 1.0 / 256.0, (double)acc[L][r]);
-            const int er = k0 + row < m ? bp.lexp[k0 + row] - 1022 : 0;
-            pool[wv][row][idx] = ldexp(tsum, er + ec - 12);
-        }
+        for (int L = PX_S - 2; L >= 0; --L) tsum = fma(tsum, 1.0 / 256.0, (double)acc[L][r]);
+        pool[wv][row][idx] = ldexp(tsum, ec - 12);
     }
     __syncthreads();
     if (bcol == a.bp.bcol0) { PS_TRACE(tb, k, 5) }
     if (*fail_s) return false;
+    nx.sums = nx.last = nx.inv = false;
+    if (look) {
+        const bool up = lane >= K || ps_reached(f_l, a.eb + 1);
+        const unsigned long long down = __builtin_amdgcn_ballot_w64(!up);
+        nx.sums = K < 2 || (down & ((1ull << (K - 1)) - 1ull)) == 0ull;
+        nx.last = ((down >> (K - 1)) & 1ull) == 0ull;
+        nx.inv = __builtin_amdgcn_readfirstlane(ps_reached(f_inv, a.eb + K + 1) ? 1 : 0) != 0;
+    }
     double(*sR)[NB + 1] = pool[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-        sR[r4][cg + e] = g4[e] - ((pool[0][r4][cg + e] + pool[1][r4][cg + e]) + (pool[2][r4][cg + e] + pool[3][r4][cg + e]));
+        sR[r4][cg + e] = g4[e] - ldexp((pool[0][r4][cg + e] + pool[1][r4][cg + e]) + (pool[2][r4][cg + e] + pool[3][r4][cg + e]), er4);
     __syncthreads();
     double(*sO)[NB + 1] = pool[0];
     {   // B_k = Linv_k R on the fp64 MFMA, one 16 x 16 quadrant per wavefront
@@ -426,8 +430,9 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
     __syncthreads();
     if (bcol == a.bp.bcol0) { PS_TRACE(tb, k, 6) }
     {   // the block's digit planes: thread (k half, 4-row quarter, column) cuts four rows of its column: four bytes per plane
+        // (column = tid & 31 = this thread's lane & 31: the column scale that came with the call is this column's)
         const int col = tid & 31, qr = (tid >> 5) & 3, kh = tid >> 7;
-        const int sh = 8 * PX_S - 2 - (bp.bexp[c0 + col] - 1022);
+        const int sh = 8 * PX_S - 2 - ec;
         unsigned w[PX_S];
 #pragma unroll
         for (int s = 0; s < PX_S; ++s) w[s] = 0u;
@@ -440,10 +445,13 @@ __device__ __forceinline__ bool ps_b_rows_planes(const PsArgs &a, int k, int bco
         }
         int8_t *dst = bp.Bq + ((size_t)(2 * kp + kh) * bp.ldq + c0 + col) * 16 + 4 * qr;
 #pragma unroll
-        for (int s = 0; s < PX_S; ++s) *(unsigned *)(dst + (size_t)s * bp.b_stride) = w[s];
+        for (int s = 0; s < PX_S; ++s) {
+            *(unsigned *)(dst + (size_t)s * bp.b_stride) = w[s];
+            if (CHAINED) *(unsigned *)(sBq + ((size_t)(s * 2 + kh) * NB + col) * 16 + 4 * qr) = w[s];
+        }
     }
     if (bcol == a.bp.bcol0) { PS_TRACE(tb, k, 7) }
-    // (frees the LDS blocks; the stores of the planes drain beside the next panel's sums and are waited for there)
+    // (frees the LDS blocks; the stores of the planes drain beside the next panel's sums: that panel's barriers come before anyone reads them)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     return true;
@@ -615,15 +623,8 @@ __global__ void __launch_bounds__(256, 2) k_chol_persist(PsArgs a)
                 }
                 const int kk = k - 1, kk0 = kk * NB;
                 bool ok = true;
-                if (kk > 0) {
-                    int o = 1;
-                    if (lane == 0) {
-                        o = ps_spin(&done[(size_t)(k + 1) * PS_NBC + kk], a.eb + kk, ctl, a.counts, a.eb, 0x1000u + k) &&
-                            ps_spin(&done[(size_t)(k + 1) * PS_NBC + k], a.eb + kk, ctl, a.counts, a.eb, 0x1100u + k) &&
-                            ps_spin(&done[(size_t)(k + 1) * PS_NBC + k + 1], a.eb + kk, ctl, a.counts, a.eb, 0x2000u + k);
-                    }
-                    ok = __builtin_amdgcn_readfirstlane(o) != 0;
-                }
+                if (kk > 0) // the three tiles (k+1, k-1 .. k+1) with the panels <= k - 2 applied: adjacent flags, one look for all
+                    ok = ps_wwait_strided(done + (size_t)(k + 1) * PS_NBC, kk, 1, 3, a.eb + kk, ctl, a.counts, a.eb, 0x1000u + k);
                 if (!ok) {
                     if (lane == 0) hfail_s = 1;
                     return;
@@ -694,7 +695,15 @@ __global__ void __launch_bounds__(256, 2) k_chol_persist(PsArgs a)
             };
             if (!block_chol_inv32_w2<2>(sA, sX, ws, helpers) && tid == 0) atomicMax(&a.counts[CNT_ERR], (int)EKF_ERR_NOT_POSITIVE_DEFINITE);
             PS_TRACE(0, k, 1)
-            // inv(L_kk) to V, write-through; the flag goes out behind the first product (the stores drain beside it)
+#ifdef EKF_SWEEP_TRACE
+            if (a.trace && tid == 0) { // (written before the join's barrier)
+                a.trace[8 * k + 5] = g_w2_clock[0];
+                a.trace[8 * k + 6] = g_w2_clock[1];
+                a.trace[8 * k + 7] = g_w2_clock[2] > g_w2_clock[3] ? g_w2_clock[2] : g_w2_clock[3];
+            }
+#endif
+            // inv(L_kk) to V, write-through; the flag goes out behind the first product (the stores drain beside it).  (Measured and
+            // dropped, profiles/r05_persist_layout.txt: the stores by two wavefronts only, drains and both flags at the panel's end.)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int e = tid + 256 * q;
@@ -1030,13 +1039,20 @@ __global__ void __launch_bounds__(256, 2) k_chol_persist(PsArgs a)
     // ---------------------------------------------------------------------------------------------------------- rows of B
     {
         const int me = ticket - 1;
+        // one block of columns per worker: the tail of a panel learns what the next one would wait for (one inlined body for both
+        // cases: a second copy of the sum's loop costs the kernel ~40 spilled registers)
+        const bool chained = PL && a.n_b == a.n_bcols;
+        PsBNext nx;
+        nx.sums = nx.last = nx.inv = false;
         for (int k = 0; k < nbk; ++k) {
             for (int cb = me; cb < a.n_bcols; cb += a.n_b) {
                 bool ok;
                 const int tb = me == 0 ? 1024 : 2048;
                 if (me == 0 || me == a.n_b - 1) { PS_TRACE(tb, k, 0) }
-                if (PL) ok = ps_b_rows_planes(a, k, cb + a.bp.bcol0, pool, sX, &hfail_s);
-                else ok = ps_b_rows_f64(a, k, cb, pool, sX, &hfail_s);
+                if (PL) {
+                    const int bcol = cb + a.bp.bcol0;
+                    ok = ps_b_rows_planes(chained, a, k, bcol, pool, sX, &hfail_s, nx, a.bp.bexp[bcol * NB + (tid & 31)] - 1022);
+                } else ok = ps_b_rows_f64(a, k, cb, pool, sX, &hfail_s);
                 if (!ok) return;
                 if (me == 0 || me == a.n_b - 1) { PS_TRACE(tb, k, 4) }
             }

@@ -20,6 +20,10 @@
 #include <mutex>
 #include <cstdlib>
 #include <atomic>
+#ifdef EKF_SWEEP_TRACE // when each of the four wavefronts of the chain workgroup reaches the join of the factorisation (scripts/persist_trace.py)
+namespace ekf { __device__ unsigned long long g_w2_clock[4]; }
+#define W2_STAMP(slot) { if ((slot) >= 40 && (slot) < 44 && (threadIdx.x & 63) == 0) ekf::g_w2_clock[(slot) - 40] = wall_clock64(); }
+#endif
 #include "chol32.h"
 #include "mma_tile.h"
 #include "digit_planes.h"

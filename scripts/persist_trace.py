@@ -59,10 +59,10 @@ tl = buf[3072:4096].reshape(-1, 8)
 t0 = int(ch[0][0])
 us = lambda x: (int(x) - t0) / 100.0 if int(x) else float("nan")  # noqa: E731
 print(f"N={N} precision {prec}: update of m={m.value} rows, {nbk} panels; us after the chain's first panel started")
-print("  k | chain: start  factored published  own tile | next tiles ready | first B: start  sumA  L(k,k-1)  inv  [summed  product  cut]  end | last B: start   end | tiles: col k+1  L(i,k)   all")
+print("  k | chain: start [A half  I half  band of two]  factored published  own tile | next tiles ready | first B: start  sumA  L(k,k-1)  inv  [summed  product  cut]  end | last B: start   end | tiles: col k+1  L(i,k)   all")
 for k in range(nbk):
     c, x, y, z = ch[k], b0[k], b1[k], tl[k]
-    print(f"{k:3d} | {us(c[0]):8.2f} {us(c[1]):8.2f} {us(c[2]):8.2f} {us(c[3]):8.2f} | {us(c[4]):8.2f} | "
+    print(f"{k:3d} | {us(c[0]):8.2f} [{us(c[5]):7.2f} {us(c[6]):7.2f} {us(c[7]):7.2f}] {us(c[1]):8.2f} {us(c[2]):8.2f} {us(c[3]):8.2f} | {us(c[4]):8.2f} | "
           f"{us(x[0]):8.2f} {us(x[1]):8.2f} {us(x[2]):8.2f} {us(x[3]):8.2f} [{us(x[5]):7.2f} {us(x[6]):7.2f} {us(x[7]):7.2f}] {us(x[4]):8.2f} | {us(y[0]):8.2f} {us(y[4]):8.2f} | "
           f"{us(z[0]):8.2f} {us(z[1]):8.2f} {us(z[2]):8.2f}")
 
