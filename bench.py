@@ -568,8 +568,9 @@ def main():
                         "sweep_end_to_downdate_note": "HIP events: end of the sweep's last launch -> start of the downdate kernel = dx, state "
                                                       "update and, above 2048 rows, the triangular inverse and the int8 GEMM B = inv(L) G"}
                        if exact else {}),
-                    "floor_note": "profiles/r05_persist_trace_n1000_f32x.txt: the chain workgroup alone needs 6.5-7 us per panel (4.4-5 us of it the "
-                                  "32 x 32 factor-and-invert under load), the rows of B 8.4-9 us per LATE panel; round 4, one launch per panel: 9.8 us",
+                    "floor_note": "profiles/r05_persist_trace_n1000_f32x.txt: a panel of the chain workgroup is 7.0-7.1 us (band of two done +4.2, "
+                                  "the 32 x 32 factorisation proper +3.0, joined inverse +5.1, published +6.2, own tile +7.0); the first ~6 panels of a wide "
+                                  "sweep 8-11 us (tile tasks), the rows of B 7-8 us per LATE panel; round 4, one launch per panel: 9.8-10.1 us",
                 }
         st = max(int(tm.steps), 1)
         stages = {k: getattr(tm, k) / st for k in ("prediction_ms", "matching_ms", "ransac_ms", "update_li_ms",

@@ -218,8 +218,9 @@ int ekf_set_update_path(EkfEngine *e, int path);
  * (a resident critical workgroup factorises panel after panel, tile and row-block workers follow it through flags; updates of at
  * most 2048 rows on an unsharded engine in the fp64 and the exact configuration, otherwise launches as under AUTO),
  * EKF_SWEEP_LAUNCHES the round-4 rule (single launches while a launch is bound by its look-ahead factorisation, pairs once the
- * rows of B = inv(L) H P are the longest role), EKF_SWEEP_AUTO (the default): persistent where it applies, else LAUNCHES
- * (DESIGN.md 4.3).  Same result to rounding; a tuning / test knob. */
+ * rows of B = inv(L) H P are the longest role), EKF_SWEEP_AUTO (the default): persistent where it applies AND the map has fewer
+ * than 8192 state columns (above, its row-block workers take several blocks of columns each and two panels per launch are faster:
+ * N = 2000, 14.0 against 20.4 us per panel), else LAUNCHES.  Same result to rounding; a tuning / test knob. */
 enum { EKF_SWEEP_PAIRS = 0, EKF_SWEEP_SINGLE = 1, EKF_SWEEP_AUTO = 2, EKF_SWEEP_PERSISTENT = 3, EKF_SWEEP_LAUNCHES = 4 };
 int ekf_set_sweep_mode(EkfEngine *e, int mode);
 

@@ -179,39 +179,53 @@ void launch_predict(EkfEngine *e)
 
 // ------------------------------------------------------------------------------------------------------ A3
 // One thread per work item: pixel prediction, visibility, and (when predicted) the Jacobian blocks.
-__global__ void __launch_bounds__(256)
+// list != null (ONE workgroup of BLOCK threads covers all work items): the ordered compaction of the predicted items -- k_compact's
+// job -- in the same launch: list[k] = feature index of the k-th predicted item, *out_count = how many.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 k_predict_features(const double *st, CamD cam, const double *feat_pos, const int *feat_type, const int *idx,
-                   int count, int *flag, int *vis, double *uv_tab, double *Hs_tab, double *Hf_tab, int *vis_full)
+                   int count, int *flag, int *vis, double *uv_tab, double *Hs_tab, double *Hf_tab, int *vis_full, int *list, int *out_count)
 {
-    const int w = blockIdx.x * 256 + threadIdx.x;
-    if (w >= count) return;
-    const int fi = idx ? idx[w] : w;
-    const double *x = st + ST_X;
-    const double *R = st + ST_R;
-    double Rt[9], Rinv[9];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) Rt[j * 3 + i] = R[i * 3 + j];
-    inv3(R, Rinv);
-    double fp[6];
-    for (int i = 0; i < 6; ++i) fp[i] = feat_pos[6 * fi + i];
-    const int type = feat_type[fi];
-    double uv[2];
-    const bool ok = predict_pixel(cam, x, Rt, Rinv, fp, type, uv);
-    flag[w] = ok ? 1 : 0;
-    vis[fi] = ok ? 1 : 0;
-    // the list of unseen features the map management consumes is the one of the step's FULL prediction (EKF.cpp:277-284);
-    // the outlier re-prediction after the first update must not disturb it (its own "unseen" list is discarded, :472-476)
-    if (vis_full) vis_full[fi] = ok ? 1 : 0;
-    if (ok) {
-        uv_tab[2 * fi] = uv[0];
-        uv_tab[2 * fi + 1] = uv[1];
-        if (Hs_tab) {
-            double Hs[14], Hf[12];
-            measurement_jacobians(cam, x, Rinv, fp, type, uv, Hs, Hf);
-            for (int i = 0; i < 14; ++i) Hs_tab[14 * fi + i] = Hs[i];
-            for (int i = 0; i < 12; ++i) Hf_tab[12 * fi + i] = Hf[i];
+    __shared__ int wtot[16];
+    const int w = blockIdx.x * BLOCK + threadIdx.x;
+    if (list && threadIdx.x < 16) wtot[threadIdx.x] = 0;
+    bool ok = false;
+    int fi = 0;
+    if (w < count) {
+        fi = idx ? idx[w] : w;
+        const double *x = st + ST_X;
+        const double *R = st + ST_R;
+        double Rt[9], Rinv[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Rt[j * 3 + i] = R[i * 3 + j];
+        inv3(R, Rinv);
+        double fp[6];
+        for (int i = 0; i < 6; ++i) fp[i] = feat_pos[6 * fi + i];
+        const int type = feat_type[fi];
+        double uv[2];
+        ok = predict_pixel(cam, x, Rt, Rinv, fp, type, uv);
+        flag[w] = ok ? 1 : 0;
+        vis[fi] = ok ? 1 : 0;
+        // the list of unseen features the map management consumes is the one of the step's FULL prediction (EKF.cpp:277-284);
+        // the outlier re-prediction after the first update must not disturb it (its own "unseen" list is discarded, :472-476)
+        if (vis_full) vis_full[fi] = ok ? 1 : 0;
+        if (ok) {
+            uv_tab[2 * fi] = uv[0];
+            uv_tab[2 * fi + 1] = uv[1];
+            if (Hs_tab) {
+                double Hs[14], Hf[12];
+                measurement_jacobians(cam, x, Rinv, fp, type, uv, Hs, Hf);
+                for (int i = 0; i < 14; ++i) Hs_tab[14 * fi + i] = Hs[i];
+                for (int i = 0; i < 12; ++i) Hf_tab[12 * fi + i] = Hf[i];
+            }
         }
     }
+    if (!list) return; // (uniform)
+    __syncthreads();
+    int total;
+    const int pos = block_exclusive_scan_1024(ok ? 1 : 0, wtot, &total); // (wavefronts that do not exist left zeros)
+    if (ok) list[pos] = fi;
+    if (threadIdx.x == 0) *out_count = total;
 }
 
 // Ordered compaction of flag[0..count) by one 1024-thread block: list[k] = feature index of the k-th predicted
@@ -240,12 +254,22 @@ void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool sta
         (void)hipMemsetAsync(e->d.counts + (sub ? CNT_NPRED_SUB : CNT_NPRED), 0, sizeof(int), e->stream);
         return;
     }
+    int *list = sub ? e->d.plist_sub : e->d.plist, *cnt = e->d.counts + (sub ? CNT_NPRED_SUB : CNT_NPRED);
+#define PF_ARGS(L_, C_) e->d.state, e->cam, e->d.feat_pos, e->d.feat_type, d_idx, count, e->d.work_flag, state_only ? e->d.pred_vis2 : e->d.pred_vis, \
+                        state_only ? e->d.pred_uv2 : e->d.pred_uv, state_only ? nullptr : e->d.Hs, state_only ? nullptr : e->d.Hf,                      \
+                        sub ? nullptr : e->d.pred_vis_full, L_, C_
+    // up to PF_ONE_MAX work items: one workgroup, the compaction in the same launch (one launch fewer per prediction)
+    if (count <= 256) {
+        k_predict_features<256><<<1, 256, 0, e->stream>>>(PF_ARGS(list, cnt));
+        return;
+    }
+    if (count <= e->pf_one_max) {
+        k_predict_features<1024><<<1, 1024, 0, e->stream>>>(PF_ARGS(list, cnt));
+        return;
+    }
     const int nb = (count + 255) / 256;
-    k_predict_features<<<nb, 256, 0, e->stream>>>(e->d.state, e->cam, e->d.feat_pos, e->d.feat_type, d_idx, count,
-                                                  e->d.work_flag, state_only ? e->d.pred_vis2 : e->d.pred_vis,
-                                                  state_only ? e->d.pred_uv2 : e->d.pred_uv,
-                                                  state_only ? nullptr : e->d.Hs, state_only ? nullptr : e->d.Hf,
-                                                  sub ? nullptr : e->d.pred_vis_full);
+    k_predict_features<256><<<nb, 256, 0, e->stream>>>(PF_ARGS(nullptr, nullptr));
+#undef PF_ARGS
     k_compact<<<1, 1024, 0, e->stream>>>(e->d.work_flag, d_idx, count, sub ? e->d.plist_sub : e->d.plist,
                                          e->d.counts + (sub ? CNT_NPRED_SUB : CNT_NPRED));
 }
