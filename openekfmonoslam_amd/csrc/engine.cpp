@@ -183,7 +183,6 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
         e->cfg.precision = cfg->max_features <= EKF_AUTO_F32_MAX_FEATURES ? EKF_PRECISION_F32_EXACT
                            : (cfg->max_features <= EKF_AUTO_EXACT_MAX_FEATURES ? EKF_PRECISION_F64_EXACT : EKF_PRECISION_F64);
     e->exact = e->cfg.precision == EKF_PRECISION_F32_EXACT || e->cfg.precision == EKF_PRECISION_F64_EXACT;
-    if (const char *ev = std::getenv("EKF_PF_ONE_MAX")) e->pf_one_max = atoi(ev); // (A/B timing of launch_predict_features' one-workgroup form)
     e->f32 = e->cfg.precision == EKF_PRECISION_F32 || e->cfg.precision == EKF_PRECISION_F32_EXACT;
     if ((cfg->flags & 0xff) == 1) { // EKF_DESCRIPTOR_F32_L2(cols)
         const int cols = (cfg->flags >> 8) & 0xffff;

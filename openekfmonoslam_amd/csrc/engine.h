@@ -207,7 +207,6 @@ struct EkfEngine {
     int b_path = 0;            // ekf_set_update_path: 0 by size (B_SWEEP_MAX), 1 B in the sweep, 2 inverse + GEMM
     int sweep_mode = 2;        // ekf_set_sweep_mode: EKF_SWEEP_* (2 AUTO: one persistent launch per update where it applies, chol_persist.h)
     unsigned ps_epoch = 0, ps_arrive = 0; // persistent sweep: epoch of its flags, tickets handed out so far
-    int pf_one_max = 1024;                // launch_predict_features: up to this many work items in ONE workgroup with the compaction fused
     int ps_fault = 0;                     // ekf_debug_stall_next_sweep: the next persistent sweep runs without its chain workgroup
     bool counted_alive = false; // this engine is in g_engines_alive (set at the end of a successful create)
     int ps_cap[2] = {0, 0};    // resident workgroups of k_chol_persist<false / true> on this device (0: not asked yet, -1: unusable)

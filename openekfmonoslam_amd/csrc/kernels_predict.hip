@@ -258,13 +258,11 @@ void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool sta
 #define PF_ARGS(L_, C_) e->d.state, e->cam, e->d.feat_pos, e->d.feat_type, d_idx, count, e->d.work_flag, state_only ? e->d.pred_vis2 : e->d.pred_vis, \
                         state_only ? e->d.pred_uv2 : e->d.pred_uv, state_only ? nullptr : e->d.Hs, state_only ? nullptr : e->d.Hf,                      \
                         sub ? nullptr : e->d.pred_vis_full, L_, C_
-    // up to PF_ONE_MAX work items: one workgroup, the compaction in the same launch (one launch fewer per prediction)
+    // up to 256 work items (small maps; the outliers re-predicted after the first update): one workgroup, the compaction in the same
+    // launch -- one launch fewer per prediction (N = 200: 4051-4091 -> 4131-4150 updates/s).  (One 1024-thread workgroup for up to 1024
+    // items was measured too: the prediction of an N = 1000 map got 4 us slower on one CU than it gained.)
     if (count <= 256) {
         k_predict_features<256><<<1, 256, 0, e->stream>>>(PF_ARGS(list, cnt));
-        return;
-    }
-    if (count <= e->pf_one_max) {
-        k_predict_features<1024><<<1, 1024, 0, e->stream>>>(PF_ARGS(list, cnt));
         return;
     }
     const int nb = (count + 255) / 256;

@@ -33,21 +33,22 @@ namespace ekf {
 // ---------------------------------------------------------------------------------------------------- gather
 // Per selected match i: A[2i..2i+1, :] = HP[2f..2f+1, :], its Jacobian blocks, position/dimension and the
 // dead-banded innovation nu (Update.cpp:125-135).  Rows m..m_pad of A are zero-filled for the k-tiled kernels.
-template <typename T, typename TP = float> // TP: type of the diagonal table (the covariance itself on one GPU, the float table of a sharded engine)
-__global__ void __launch_bounds__(256)
-k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
-         const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
-         double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, int *bexp, const TP *Pdiag, int ldpd,
-         int n, int *grow)
+// (the body takes its workgroup coordinates as arguments: k_gather_assemble runs it beside the assembly of S in ONE launch)
+template <typename T, typename TP> // TP: type of the diagonal table (the covariance itself on one GPU, the float table of a sharded engine)
+__device__ __forceinline__ void
+gather_body(const int bx, const int by, const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
+            const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
+            double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, int *bexp, const TP *Pdiag, int ldpd,
+            int n, int *grow)
 {
     // grow != nullptr (exact configuration, rows of B from digit planes): the rows are NOT copied -- their consumers (k_assemble_S,
     // b_rows_planes) read H P through the row map grow[row] = row of H P, -1 for the zero rows m .. m_pad; the launch then has
     // one workgroup column (grid.x = 1 covers the per-match bookkeeping; the column scales are written by grid.y = 0's columns)
-    const int row = blockIdx.y;
+    const int row = by;
     if (bexp && Pdiag) {
         // rows of B from digit planes (chol_bplanes.h): the column scales are known before B exists, |B_kj| <= sqrt(P_jj); the
         // m_pad workgroups of this launch (one per row, no copy) share the columns
-        if (blockIdx.x == 0) {
+        if (bx == 0) {
             const int per = (n_pad + m_pad - 1) / m_pad;
             for (int j = row * per + threadIdx.x; j < min((row + 1) * per, n_pad); j += 256) {
                 const double pjj = j < n ? (double)Pdiag[(size_t)j * ldpd + j] : 0.0;
@@ -57,7 +58,7 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
     } else if (bexp && row == 0) {
         // exact downdate, column scales of B collected by k_dx_partial (atomicMax of the entries' exponents): start from zero
         constexpr int VWz = 16 / sizeof(T);
-        const int jz = (blockIdx.x * 256 + threadIdx.x) * VWz;
+        const int jz = (bx * 256 + threadIdx.x) * VWz;
 #pragma unroll
         for (int v = 0; v < VWz; ++v)
             if (jz + v < n_pad) bexp[jz + v] = 0;
@@ -65,16 +66,16 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
     // 16 bytes per thread: the copy is pure HBM traffic (n_pad and ld are multiples of 128 elements)
     constexpr int VW = 16 / sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(VW)));
-    const int j = (blockIdx.x * 256 + threadIdx.x) * VW;
+    const int j = (bx * 256 + threadIdx.x) * VW;
     const int m = 2 * M;
     if (row < m) {
         const int i = row >> 1, r = row & 1;
         const int fi = matches[i].featureIndex;
         if (grow) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) grow[row] = 2 * fi + r;
+            if (bx == 0 && threadIdx.x == 0) grow[row] = 2 * fi + r;
         } else if (j < n_pad) *(vec_t *)(A + (size_t)row * ld + j) = *(const vec_t *)(HP + (size_t)(2 * fi + r) * ld + j);
-        if (blockIdx.x == 0 && threadIdx.x < 16) Gc[(size_t)row * 16 + threadIdx.x] = threadIdx.x < 13 ? HPc[(size_t)(2 * fi + r) * 16 + threadIdx.x] : 0.0;
-        if (blockIdx.x == 0 && r == 0) {
+        if (bx == 0 && threadIdx.x < 16) Gc[(size_t)row * 16 + threadIdx.x] = threadIdx.x < 13 ? HPc[(size_t)(2 * fi + r) * 16 + threadIdx.x] : 0.0;
+        if (bx == 0 && r == 0) {
             const int t = threadIdx.x;
             if (t < 14) mHs[14 * i + t] = Hs_tab[14 * fi + t];
             else if (t < 26) mHf[12 * i + t - 14] = Hf_tab[12 * fi + t - 14];
@@ -88,16 +89,27 @@ k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, i
         }
     } else if (row < m_pad) {
         if (grow) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) grow[row] = -1;
+            if (bx == 0 && threadIdx.x == 0) grow[row] = -1;
         } else if (j < n_pad) {
             vec_t zero;
 #pragma unroll
             for (int v = 0; v < VW; ++v) zero[v] = (T)0;
             *(vec_t *)(A + (size_t)row * ld + j) = zero;
         }
-        if (blockIdx.x == 0 && threadIdx.x < 16) Gc[(size_t)row * 16 + threadIdx.x] = 0.0;
-        if (blockIdx.x == 0 && threadIdx.x == 0) nu[row] = 0.0;
+        if (bx == 0 && threadIdx.x < 16) Gc[(size_t)row * 16 + threadIdx.x] = 0.0;
+        if (bx == 0 && threadIdx.x == 0) nu[row] = 0.0;
     }
+}
+
+template <typename T, typename TP = float>
+__global__ void __launch_bounds__(256)
+k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
+         const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
+         double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, int *bexp, const TP *Pdiag, int ldpd,
+         int n, int *grow)
+{
+    gather_body<T, TP>((int)blockIdx.x, (int)blockIdx.y, matches, M, m_pad, HP, A, ld, n_pad, uv_tab, Hs_tab, Hf_tab, feat_type, feat_covpos, nu, mHs, mHf,
+                       mpos, mdim, HPc, Gc, bexp, Pdiag, ldpd, n, grow);
 }
 
 // sum over the four lanes of a quad, in every lane: two DPP quad permutes (lane ^ 1, lane ^ 2) -- register moves, where
@@ -146,23 +158,31 @@ __device__ __forceinline__ void store_linv(double *V, double *W, float *Wf, int 
 
 // ------------------------------------------------------------------------------------------------ S = A H' + R
 // One thread per 2x2 block (a, b), b <= a, of the lower triangle.
+// direct != null (k_gather_assemble): nothing gathered is read -- the Jacobian blocks, positions and the rows of H P come straight
+// from the prediction tables through the matches' feature indices (the same numbers as their gathered copies: same S, bit for bit)
+struct AssembleDirect {
+    const EkfMatch *matches;
+    const double *Hs_tab, *Hf_tab;
+    const int *feat_type, *feat_covpos;
+};
 template <typename T>
-__global__ void __launch_bounds__(256)
-k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, const int *mpos, const int *mdim,
-             double pixel_err, double *S, int ldS, double *V, double *W, float *Wf, int ldw, int *counts, int *lexp, const int *grow,
-             int b_lo, int b_hi, double *St, int ldst, int duties)
+__device__ __forceinline__ void
+assemble_body(const int bx, const int by, const T *A, int ld, int M, const double *mHs, const double *mHf, const int *mpos, const int *mdim,
+              double pixel_err, double *S, int ldS, double *V, double *W, float *Wf, int ldw, int *counts, int *lexp, const int *grow,
+              int b_lo, int b_hi, double *St, int ldst, int duties, const AssembleDirect *direct)
 {
     // [b_lo, b_hi), St: a rank of a row-sharded filter forms the block COLUMNS of its own matches only (it holds G[:, own
     // columns], k_g_cols) and writes them a second time transposed (St: row = column of S) for the exchange; duties: the first
     // diagonal block is factorised here (complete S only)
-    const int b = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int a = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const int b = bx * 16 + (threadIdx.x & 15);
+    const int a = by * 16 + (threadIdx.x >> 4);
     if (a < M && b <= a && b >= b_lo && b < b_hi) {
-        const int pos = mpos[b], d = mdim[b];
-        const double *hs = mHs + 14 * b, *hf = mHf + 12 * b;
+        const int fb = direct ? direct->matches[b].featureIndex : 0, fa = direct ? direct->matches[a].featureIndex : 0;
+        const int pos = direct ? direct->feat_covpos[fb] : mpos[b], d = direct ? feat_dim(direct->feat_type[fb]) : mdim[b];
+        const double *hs = direct ? direct->Hs_tab + 14 * fb : mHs + 14 * b, *hf = direct ? direct->Hf_tab + 12 * fb : mHf + 12 * b;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const T *ar = A + (size_t)(grow ? grow[2 * a + r] : 2 * a + r) * ld; // (grow: A is the H P table itself)
+            const T *ar = A + (size_t)(direct ? 2 * fa + r : (grow ? grow[2 * a + r] : 2 * a + r)) * ld; // (grow, direct: A is the H P table itself)
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
@@ -190,7 +210,7 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
             if (lexp && a == b) lexp[2 * a + r] = ilogb(sqrt(r == 0 ? s0 : s1) * 1.001) + 1 + 1022;
         }
     }
-    if (blockIdx.x != 0 || blockIdx.y != 0 || !duties) return;
+    if (bx != 0 || by != 0 || !duties) return;
     // Block (0, 0) has just written the first 32 x 32 diagonal block of S: factorise it here (what the sweep's
     // look-ahead does for every later block), which saves the separate launch that used to start the sweep.
     __shared__ double sa[NB][NB + 1], sx[NB][NB + 1];
@@ -204,6 +224,39 @@ k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, co
     __syncthreads();
     if (!block_chol_inv32_v4(sa, sx) && threadIdx.x == 0) counts[CNT_ERR] = EKF_ERR_NOT_POSITIVE_DEFINITE;
     store_linv(V, W, Wf, ldw, 0, sx);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_assemble_S(const T *A, int ld, int M, const double *mHs, const double *mHf, const int *mpos, const int *mdim,
+             double pixel_err, double *S, int ldS, double *V, double *W, float *Wf, int ldw, int *counts, int *lexp, const int *grow,
+             int b_lo, int b_hi, double *St, int ldst, int duties)
+{
+    assemble_body<T>((int)blockIdx.x, (int)blockIdx.y, A, ld, M, mHs, mHf, mpos, mdim, pixel_err, S, ldS, V, W, Wf, ldw, counts, lexp, grow, b_lo, b_hi,
+                     St, ldst, duties, nullptr);
+}
+
+// The gather's bookkeeping (and copy, where there is one) and the assembly of S in ONE launch (one GPU, nothing exchanged between the
+// two): workgroups 0 .. mb^2 - 1 assemble the 16 x 16 groups of 2 x 2 blocks (reading the prediction tables directly), the rest are
+// the gather's grid, row-major.  One launch fewer per update.
+template <typename T, typename TP>
+__global__ void __launch_bounds__(256)
+k_gather_assemble(int mb, int gxg, const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
+                  const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
+                  double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, int *bexp, const TP *Pdiag, int ldpd,
+                  int n, int *grow, double pixel_err, double *S, int ldS, double *V, double *W, float *Wf, int ldw, int *counts, int *lexp,
+                  int duties)
+{
+    const int id = (int)blockIdx.x;
+    if (id < mb * mb) {
+        const AssembleDirect dr{matches, Hs_tab, Hf_tab, feat_type, feat_covpos};
+        assemble_body<T>(id % mb, id / mb, HP, ld, M, nullptr, nullptr, nullptr, nullptr, pixel_err, S, ldS, V, W, Wf, ldw, counts, lexp, nullptr, 0, M,
+                         nullptr, 0, duties, &dr);
+    } else {
+        const int g = id - mb * mb;
+        gather_body<T, TP>(g % gxg, g / gxg, matches, M, m_pad, HP, A, ld, n_pad, uv_tab, Hs_tab, Hf_tab, feat_type, feat_covpos, nu, mHs, mHf, mpos,
+                           mdim, HPc, Gc, bexp, Pdiag, ldpd, n, grow);
+    }
 }
 
 // ------------------------------------------------------------------------- row-sharded filter: G by symmetry, S by columns
@@ -1550,12 +1603,22 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     if (persist && e->sweep_mode == EKF_SWEEP_AUTO && n_pad >= 8192) persist = false;
     double *V = e->d.Dinv, *W = b_in_sweep ? nullptr : e->d.W; // W = inv(L)' (and L row-major in LL): the GEMM path's
     float *Wf = sizeof(TB) == 4 && !b_in_sweep ? e->d.Wf : nullptr;
+    bool merged_ga = false;
     {
         dim3 grid((n_pad / (int)(16 / sizeof(TB)) + 255) / 256, m_pad);
         if ((planes_b && !sharded) || sym_g) grid.x = 1; // no copy: one workgroup per row (bookkeeping, row map, its share of the column scales)
 #define GATHER_ARGS e->d.matches, M, m_pad, (const TB *)e->d.HP, G, ld, n_pad, e->d.pred_uv, e->d.Hs, e->d.Hf, e->d.feat_type, e->d.feat_covpos, e->d.nu, \
                     e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim, e->d.HPc, e->d.Gc, EXACT ? e->d.Bexp : nullptr
-        if (apriori && !sharded) // a-priori column scales from the diagonal of the covariance itself
+        merged_ga = !sharded && !sym_g && !e->after_gather;
+        if (merged_ga) {
+            // gather and the assembly of S in one launch (the assembly reads the prediction tables, not the gather's output)
+            const int mb = (M + 15) / 16;
+            int *gr = planes_b ? e->d.Grow : nullptr;
+#define GA_TAIL n, gr, e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts, planes_b ? e->d.Lexp : nullptr, persist ? 0 : 1
+            if (apriori) k_gather_assemble<TB, T><<<mb * mb + (int)(grid.x * grid.y), 256, 0, s>>>(mb, (int)grid.x, GATHER_ARGS, (const T *)e->d.P, ld, GA_TAIL);
+            else k_gather_assemble<TB, float><<<mb * mb + (int)(grid.x * grid.y), 256, 0, s>>>(mb, (int)grid.x, GATHER_ARGS, (const float *)nullptr, 0, GA_TAIL);
+#undef GA_TAIL
+        } else if (apriori && !sharded) // a-priori column scales from the diagonal of the covariance itself
             k_gather<TB, T><<<grid, 256, 0, s>>>(GATHER_ARGS, (const T *)e->d.P, ld, n, planes_b || sym_g ? e->d.Grow : nullptr);
         else
             k_gather<TB, float><<<grid, 256, 0, s>>>(GATHER_ARGS, apriori ? e->d.Pdiag : nullptr, 0, n,
@@ -1585,7 +1648,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             k_s_unpack<<<dim3((m + 255) / 256, m), 256, 0, s>>>(e->d.W, m_pad, e->d.S, ldS, m, 2 * b_lo, 2 * b_hi, e->d.Lexp);
             k_assemble_S<TB><<<dim3(1, 1), 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim, e->cfg.cam.pixelErrorX, e->d.S, ldS, V,
                                                        nullptr, nullptr, ldw, e->d.counts, nullptr, nullptr, 0, 0, nullptr, 0, 1);
-        } else
+        } else if (!merged_ga)
         k_assemble_S<TB><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts,
                                              planes_b ? e->d.Lexp : nullptr, planes_b && !sharded ? e->d.Grow : nullptr, 0, M, nullptr, 0,
