@@ -1465,8 +1465,10 @@ static int step_dev_fast(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *
     };
     // 1-2. prediction (:273-284), timesPredicted++ (EKF.cpp:572)
     launch_predict(e);
-    launch_predict_features(e, nullptr, N, false);
-    launch_hp_rows(e, e->d.plist, N, true, cnt + CNT_NPRED);
+    {   // (more than 256 features: the compaction of the predicted list rides in the launch of the H P rows)
+        const bool deferred = launch_predict_features(e, nullptr, N, false, true);
+        launch_hp_rows(e, e->d.plist, N, true, cnt + CNT_NPRED, deferred);
+    }
     tm.mark();
     // 4. matching (:337)
     {

@@ -305,9 +305,9 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int c, int *wtot /* __s
 // ---- launchers (kernels_*.hip) ; T selected by e->f32 ----------------------------------------------------
 void launch_predict(EkfEngine *e);
 // full (idx == nullptr) or subset prediction; fills tables, compacted list and CNT_NPRED / CNT_NPRED_SUB
-void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool tables_only_state);
+bool launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool state_only, bool defer_compact = false);
 // d_count != nullptr: n_list is an upper bound, the list's length is read on the device
-void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_predicted = false, const int *d_count = nullptr);
+void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_predicted = false, const int *d_count = nullptr, bool from_flags = false);
 // d_npred != nullptr: n_pred is an upper bound, the number of predictions is read on the device
 void launch_match(EkfEngine *e, int n_pred, int n_kp, const int *d_npred = nullptr, bool with_ransac_init = false);
 // d_M != nullptr (RANSAC launchers): M is an upper bound, the number of matches is read on the device

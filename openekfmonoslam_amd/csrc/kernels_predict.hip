@@ -247,12 +247,14 @@ __global__ void __launch_bounds__(1024) k_compact(const int *flag, const int *id
 
 // state_only: pixel predictions into the scratch tables (vis2/uv2, list plist_sub, counter CNT_NPRED_SUB) so the
 // tables the following stages consume stay untouched.
-void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool state_only)
+// defer_compact (the step's full prediction, more than 256 features): the compaction is left to the launch of k_hp_rows that follows
+// (launch_hp_rows(..., from_flags = true)); returns whether it was
+bool launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool state_only, bool defer_compact)
 {
     const bool sub = state_only || d_idx != nullptr;
     if (count <= 0) {
         (void)hipMemsetAsync(e->d.counts + (sub ? CNT_NPRED_SUB : CNT_NPRED), 0, sizeof(int), e->stream);
-        return;
+        return false;
     }
     int *list = sub ? e->d.plist_sub : e->d.plist, *cnt = e->d.counts + (sub ? CNT_NPRED_SUB : CNT_NPRED);
 #define PF_ARGS(L_, C_) e->d.state, e->cam, e->d.feat_pos, e->d.feat_type, d_idx, count, e->d.work_flag, state_only ? e->d.pred_vis2 : e->d.pred_vis, \
@@ -263,13 +265,15 @@ void launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool sta
     // items was measured too: the prediction of an N = 1000 map got 4 us slower on one CU than it gained.)
     if (count <= 256) {
         k_predict_features<256><<<1, 256, 0, e->stream>>>(PF_ARGS(list, cnt));
-        return;
+        return false;
     }
     const int nb = (count + 255) / 256;
     k_predict_features<256><<<nb, 256, 0, e->stream>>>(PF_ARGS(nullptr, nullptr));
 #undef PF_ARGS
+    if (defer_compact && !sub && !d_idx) return true;
     k_compact<<<1, 1024, 0, e->stream>>>(e->d.work_flag, d_idx, count, sub ? e->d.plist_sub : e->d.plist,
                                          e->d.counts + (sub ? CNT_NPRED_SUB : CNT_NPRED));
+    return false;
 }
 
 // ------------------------------------------------------------------------------------------------------ A4
@@ -284,14 +288,33 @@ template <typename T, typename TO>
 __global__ void __launch_bounds__(256)
 k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, const int *feat_covpos,
           const double *Hs_tab, const double *Hf_tab, TO *HP, double *S_tab, RowMap rm, double *HPc, unsigned *times_predicted,
-          const int *d_count)
+          const int *d_count, const int *flag, int n_items, int *list_out, int *count_out)
 {
-    // the grid is an upper bound when the length of the list is only known on the device (step path: no read-back)
-    if (d_count && (int)blockIdx.x >= *d_count) return;
+    const int tid = threadIdx.x;
+    if (flag) {
+        // the step's FULL prediction: workgroup x = feature x, predicted or not (k_predict_features' flags) -- nobody needs the compacted
+        // list here, so its compaction (k_compact's job, needed by the matcher) rides in this launch as one more workgroup
+        if ((int)blockIdx.x == n_items) {
+            if (blockIdx.y != 0) return;
+            __shared__ int wtot[16];
+            if (tid < 16) wtot[tid] = 0;
+            __syncthreads();
+            const int per = (n_items + 255) / 256;
+            const int b = tid * per, e = min(n_items, b + per);
+            int c = 0;
+            for (int i = b; i < e; ++i) c += flag[i] ? 1 : 0;
+            int total;
+            int pos = block_exclusive_scan_1024(c, wtot, &total); // (the wavefronts that do not exist left zeros)
+            for (int i = b; i < e; ++i)
+                if (flag[i]) list_out[pos++] = i;
+            if (tid == 0) *count_out = total;
+            return;
+        }
+        if (!flag[blockIdx.x]) return;
+    } else if (d_count && (int)blockIdx.x >= *d_count) return; // the grid is an upper bound when the length of the list is only known on the device (step path: no read-back)
     __shared__ double sH[26];     // Hs (2x7) then Hf (2x6)
     __shared__ double sHP[2][13]; // fp64 H P at columns 0..6 and pos..pos+d-1
-    const int fi = list[blockIdx.x];
-    const int tid = threadIdx.x;
+    const int fi = flag ? (int)blockIdx.x : list[blockIdx.x];
     const int d = feat_dim(feat_type[fi]);
     const int pos = feat_covpos[fi];
     // updateMapFeatures' timesPredicted++ (MapManagement.cpp:81-86) rides along when a step asks for it (every rank counts
@@ -397,23 +420,28 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
     }
 }
 
-void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_predicted, const int *d_count)
+// from_flags: the step's full prediction when launch_predict_features left the compaction to this launch (deferred_compact): the
+// workgroups go by k_predict_features' flags, one more workgroup writes the compacted list and its length
+void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_predicted, const int *d_count, bool from_flags)
 {
     unsigned *tp = count_predicted ? e->d.feat_times_predicted : nullptr;
     if (n_list <= 0) return;
     const int chunks_f = (e->n + 256 * 4 - 1) / (256 * 4), chunks_d = (e->n + 256 * 2 - 1) / (256 * 2);
+    const int *flag = from_flags ? e->d.work_flag : nullptr;
+    int *lo = from_flags ? e->d.plist : nullptr, *co = from_flags ? e->d.counts + CNT_NPRED : nullptr;
+    const int gx = n_list + (from_flags ? 1 : 0);
     if (e->exact && e->f32)
-        k_hp_rows<float, double><<<dim3(n_list, chunks_f), 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
+        k_hp_rows<float, double><<<dim3(gx, chunks_f), 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
                                                         e->d.feat_covpos, e->d.Hs, e->d.Hf, (double *)e->d.HP,
-                                                        e->d.pred_S, e->rm, e->d.HPc, tp, d_count);
+                                                        e->d.pred_S, e->rm, e->d.HPc, tp, d_count, flag, n_list, lo, co);
     else if (e->f32)
-        k_hp_rows<float, float><<<dim3(n_list, chunks_f), 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
+        k_hp_rows<float, float><<<dim3(gx, chunks_f), 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
                                                         e->d.feat_covpos, e->d.Hs, e->d.Hf, (float *)e->d.HP,
-                                                        e->d.pred_S, e->rm, e->d.HPc, tp, d_count);
+                                                        e->d.pred_S, e->rm, e->d.HPc, tp, d_count, flag, n_list, lo, co);
     else
-        k_hp_rows<double, double><<<dim3(n_list, chunks_d), 256, 0, e->stream>>>((const double *)e->d.P, e->ldP, e->n, d_list,
+        k_hp_rows<double, double><<<dim3(gx, chunks_d), 256, 0, e->stream>>>((const double *)e->d.P, e->ldP, e->n, d_list,
                                                          e->d.feat_type, e->d.feat_covpos, e->d.Hs, e->d.Hf,
-                                                         (double *)e->d.HP, e->d.pred_S, e->rm, e->d.HPc, tp, d_count);
+                                                         (double *)e->d.HP, e->d.pred_S, e->rm, e->d.HPc, tp, d_count, flag, n_list, lo, co);
 }
 
 // predictMeasurementState on the current state into an EkfPrediction array (device), all features.
