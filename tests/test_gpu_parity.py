@@ -265,8 +265,10 @@ def test_rescue_identical_mask(eng_mod, oracle_lib, seq50):
     np.testing.assert_array_equal(r_e, r_o)
 
 
-@pytest.mark.parametrize("nfeat,frames", [(12, 5), (50, 6)])
+@pytest.mark.parametrize("nfeat,frames", [(12, 5), (50, 6), (256, 2), (257, 2)])
 def test_full_step_sequence_fp64(eng_mod, oracle_lib, nfeat, frames):
+    """(256 / 257 features: either side of the size up to which k_predict_features compacts its own list in the same launch; above, the
+    compaction rides in the launch of the H P rows -- csrc/kernels_predict.hip)"""
     seq = SyntheticSequence(nfeat, frames)
     e, o = make_pair(eng_mod, oracle_lib, seq)
     for t, (kps, desc) in enumerate(seq.frames):
