@@ -1556,9 +1556,12 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     const bool planes_b = EXACT && b_in_sweep && m_pad <= B_SWEEP_MAX && e->d.Lq != nullptr && update_cov && (!sharded || shard_cols);
     const bool apriori = planes_b || shard_cols || (EXACT && !b_in_sweep && update_cov && e->d.Wq != nullptr); // column scales of B from diag(P)
     // sharded step with the rows of B from digit planes: G by symmetry and S by columns (k_g_cols) instead of the exchange of the rows of G
+    // (round 5: also above 2048 rows, where B = inv(L) G is the int8 GEMM over the rank's own column tiles: no rows of G travel at any size)
     bool sym_g = false;
+    const bool gemm_own = EXACT && !b_in_sweep && update_cov && e->d.Wq != nullptr && shard_cols;
     if constexpr (EXACT)
-        sym_g = shard_cols && planes_b && e->after_gather != nullptr && (int)e->shard_rb.size() == e->shard_world + 1 && e->d.W != nullptr;
+        sym_g = shard_cols && (planes_b || gemm_own) && e->after_gather != nullptr && (int)e->shard_rb.size() == e->shard_world + 1 &&
+                e->d.W != nullptr && e->d.Tbuf != nullptr;
     BPlanes bp{};
     // sharded: this rank forms the column blocks [cb0, cb1) of B -- the blocks whose first column lies in its share of the state
     // rows (rank 0: from column 0) -- and receives the others' digit planes afterwards (the B role divided by the ranks)
@@ -1634,20 +1637,25 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         if (sym_g) {
             // G[:, own columns] (and the camera block) from the own rows of P; S by the block columns of the own matches, one
             // all-gather of those columns (transposed image in W, which the sweep path does not use), the rest of S's duties after it
-            const int c_lo = cb0 * NB, c_hi = cb1 * NB;
+            // (rows of B in the sweep: the rank's 32-column blocks; inverse + GEMM: its 128-column tiles, rounded outwards like the GEMM's)
+            const int c_lo = planes_b ? cb0 * NB : col_rb[e->shard_rank] / 128 * 128;
+            const int c_hi = planes_b ? cb1 * NB : std::min(n_pad, round_up(col_rb[e->shard_rank + 1], 128));
+            // the transposed image of the own block columns of S for the exchange: W where the sweep forms B (nobody reads it there), the
+            // scratch of the triangular inverse where W will hold inv(L)' (its other triangle must stay zero)
+            double *St = planes_b ? e->d.W : e->d.Tbuf;
             const int b_lo = e->shard_rb[e->shard_rank] / 2, b_hi = e->shard_rb[e->shard_rank + 1] / 2;
             if (c_lo > 0) k_g_cols<T><<<dim3(1, (m_pad + 63) / 64), 256, 0, s>>>((const T *)e->d.P, ld, e->rm, n, M, e->d.mHs, e->d.mHf, e->d.mpos,
                                                                           e->d.mdim, (double *)G, ld, 0, NB, m_pad);
             k_g_cols<T><<<dim3((c_hi - c_lo + 63) / 64, (m_pad + 63) / 64), 256, 0, s>>>((const T *)e->d.P, ld, e->rm, n, M, e->d.mHs, e->d.mHf,
                                                                                   e->d.mpos, e->d.mdim, (double *)G, ld, c_lo, c_hi, m_pad);
             k_assemble_S<TB><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim, e->cfg.cam.pixelErrorX, e->d.S, ldS, V,
-                                                 nullptr, nullptr, ldw, e->d.counts, e->d.Lexp, nullptr, b_lo, b_hi, e->d.W, m_pad, 0);
+                                                 nullptr, nullptr, ldw, e->d.counts, e->d.Lexp, nullptr, b_lo, b_hi, St, m_pad, 0);
             // (rows of the image are m_pad doubles: only the live columns of S travel, not the capacity-strided ldW)
-            e->hook_rc = e->exchange_hook(e, EKF_XCHG_SCOLS, e->d.W, (size_t)m_pad * sizeof(double), e->shard_rb, "the columns of S");
+            e->hook_rc = e->exchange_hook(e, EKF_XCHG_SCOLS, St, (size_t)m_pad * sizeof(double), e->shard_rb, "the columns of S");
             if (e->hook_rc) return;
-            k_s_unpack<<<dim3((m + 255) / 256, m), 256, 0, s>>>(e->d.W, m_pad, e->d.S, ldS, m, 2 * b_lo, 2 * b_hi, e->d.Lexp);
+            k_s_unpack<<<dim3((m + 255) / 256, m), 256, 0, s>>>(St, m_pad, e->d.S, ldS, m, 2 * b_lo, 2 * b_hi, e->d.Lexp);
             k_assemble_S<TB><<<dim3(1, 1), 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim, e->cfg.cam.pixelErrorX, e->d.S, ldS, V,
-                                                       nullptr, nullptr, ldw, e->d.counts, nullptr, nullptr, 0, 0, nullptr, 0, 1);
+                                                       W, nullptr, ldw, e->d.counts, nullptr, nullptr, 0, 0, nullptr, 0, 1);
         } else if (!merged_ga)
         k_assemble_S<TB><<<grid, 256, 0, s>>>(G, ld, M, e->d.mHs, e->d.mHf, e->d.mpos, e->d.mdim,
                                              e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts,

@@ -64,6 +64,7 @@ class LocalShardGroup:
         self._barrier = threading.Barrier(world)
         self._bases = {}
         self.bytes_exchanged = 0
+        self.bytes_by_kind = {}  # what rank 0 pulled, per kind of exchange (EKF_XCHG_*)
         for r, e in enumerate(self.engines):
             e.set_exchange(self._make_exchange(r))
 
@@ -87,6 +88,7 @@ class LocalShardGroup:
                         eng.device_copy(base + lo, self._bases[(what, r)] + lo, hi - lo)
                     if me == 0:
                         self.bytes_exchanged += hi - lo
+                        self.bytes_by_kind[what] = self.bytes_by_kind.get(what, 0) + hi - lo
             self._barrier.wait()  # nobody overwrites a block somebody is still pulling
             return 0
 

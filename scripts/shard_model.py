@@ -7,8 +7,8 @@ Inputs  : profiles/<r>_bench_n2000_f32x.json, <r>_bench_n5000_f32x.json (ms per 
           first frame twice, so its totals are not per-frame figures of the timed frames).
 Model   : downdate x 2/G (a rank computes both triangles of its own rows); rows of B / G with the sweep bounded below by the
           dependent chain (CHAIN_US per 32-row panel, the fast configuration's measured launch period); the GEMM / G; the inverse
-          and everything else replicated; per update a rank receives (G-1)/G of the five digit planes of B (5 B per element) and, above 2048
-          rows, of the rows of G (8 B per element; below: of the columns of S, 8 m^2 B) over G-1 xGMI links of LINK_GBS each, not overlapped with compute.
+          and everything else replicated; per update a rank receives (G-1)/G of the five digit planes of B (5 B per element) and of the
+          columns of S (8 m^2 B; until round 4, above 2048 rows: of the rows of G, 8 B per element) over G-1 xGMI links of LINK_GBS each, not overlapped with compute.
 No multi-GPU measurement exists on this pool: this is arithmetic on one-GPU measurements, not a scaling result."""
 import csv
 import json
@@ -17,6 +17,7 @@ import sys
 
 CHAIN_US = 9.1    # us per panel of the dependent chain (k_chol_step with the rows-of-B role hidden; profiles/r04_bench_n1000_f32.json)
 LINK_GBS = 153.0  # one xGMI link, one direction (MI355X_MICROARCH.md)
+SYM_ABOVE = True  # G by symmetry also above 2048 rows (csrc/kernels_update.hip, sym_g): no rows of G travel at any size
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 
 
@@ -54,7 +55,9 @@ def model(tag, d, n_state, gemm_share, ranks):
         gg = gemm_ms / g
         # rows of B in the sweep (<= 2048 rows): no rows of G travel (G[:, own columns] by symmetry from the own rows of P); S is
         # assembled by block columns and all-gathered: 8 m^2 bytes per update (two updates of ~62 % and ~38 % of the frame's rows)
-        recv_g = (0.53 * rows_m * rows_m * 8.0 if b_in_sweep else rows_m * n_state * 8.0) * (g - 1) / g
+        # (round 5: the same above 2048 rows -- the inverse + GEMM path forms G[:, own column tiles] by symmetry too; SYM_ABOVE = False
+        # restores the round-4 model, where the gathered rows of G travelled there: rows_m n 8 bytes)
+        recv_g = (0.53 * rows_m * rows_m * 8.0 if (b_in_sweep or SYM_ABOVE) else rows_m * n_state * 8.0) * (g - 1) / g
         recv_p = rows_m * n_state * 5.0 * (g - 1) / g
         xt = (recv_g + recv_p) / ((g - 1) * LINK_GBS * 1e9) * 1e3
         tg = dg + sg + inv_ms + gg + rest + xt

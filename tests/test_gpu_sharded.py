@@ -257,9 +257,10 @@ def test_n2000_exact_ranks_two_frames_vs_oracle_and_model(eng_mod, oracle_lib, w
     second frame's updates (m = 1342 and 1568 rows) inside the sweep from int8 digit planes, the first frame's m = 3714 rescue
     update by inverse + GEMM over its own column tiles -- then the digit planes travel: the bytes a rank receives and the columns
     it forms are asserted against the cost model of DESIGN.md section 8:
-    bytes = (n_pad - own columns) x 5 x round_up(m, 32) per update, own columns = its share of the state rows (rounded to 32 on the
-    inverse + GEMM path).  Below 2048 rows no rows of G travel: G[:, own columns] comes from the rank's own rows of P by symmetry and
-    S is assembled by block columns and all-gathered (EKF_XCHG_SCOLS)."""
+    bytes = (n_pad - own columns) x 5 x round_up(m, 32) per update, own columns = exactly its share of the state rows.  No rows of G
+    travel on either path (round 5: above 2048 rows too): G[:, own columns] comes from the rank's own rows of P by symmetry and S is
+    assembled by block columns and all-gathered (EKF_XCHG_SCOLS); the exchange of gathered rows (EKF_XCHG_HP) must not happen in a
+    covariance update of the exact configuration."""
     from parity_metric import over_tolerance, parity_report
 
     N, F = 2000, 2
@@ -296,12 +297,13 @@ def test_n2000_exact_ranks_two_frames_vs_oracle_and_model(eng_mod, oracle_lib, w
         own_exact = (n_pad if r == world - 1 else hi) - lo
         r32 = lambda v: (v + 31) // 32 * 32  # noqa: E731
         own_rounded = (n_pad if r == world - 1 else min(n_pad, r32(hi))) - (0 if r == 0 else min(n_pad, r32(lo)))
-        assert c1 - c0 == (own_exact if planes_rows[-1] <= 2048 else own_rounded), (r, c0, c1, own_exact, own_rounded)
-        want = sum((n_pad - (own_exact if mk <= 2048 else own_rounded)) * 5 * mk for mk in planes_rows)
+        assert c1 - c0 == own_exact, (r, c0, c1, own_exact, own_rounded)
+        want = sum((n_pad - own_exact) * 5 * mk for mk in planes_rows)
         assert got == want, (r, got, want)
     assert cols[0][0] == 0 and cols[-1][1] == n_pad and all(cols[r][1] == cols[r + 1][0] for r in range(world - 1)), cols
     share = [(c1 - c0) / n_pad for c0, c1 in cols]
-    print(f"  column shares of the rows of B: {[f'{s:.3f}' for s in share]}; planes received by rank 0: {grp.engines[0].shard_counters()[0] / 1e6:.1f} MB")
+    print(f"  column shares of the rows of B: {[f'{s:.3f}' for s in share]}; planes received by rank 0: {grp.engines[0].shard_counters()[0] / 1e6:.1f} MB;"
+          f" pulled by rank 0 per kind of exchange (MB): { {k: round(v / 1e6, 1) for k, v in sorted(grp.bytes_by_kind.items())} }")
     assert max(share) <= 1.0 / world + 0.02  # the B role's m^2 n is divided by the ranks
     grp.close()
 
