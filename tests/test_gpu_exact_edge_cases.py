@@ -82,6 +82,53 @@ def test_sweep_modes_exact(eng_mod, oracle_lib, mode):
     assert_parity(e, o, f"sweep mode {mode}", 170)
 
 
+@pytest.mark.parametrize("mode,persistent", [pytest.param(2, True, id="auto"), pytest.param(3, True, id="persistent"),
+                                             pytest.param(4, False, id="launches")])
+def test_sweep_mode_decides_the_launch_count_exact(eng_mod, oracle_lib, mode, persistent):
+    """EKF_SWEEP_AUTO takes the persistent sweep on a map of fewer than 8192 state columns (ONE launch per update:
+    ekf_timing_sweep_launches == updates), EKF_SWEEP_LAUNCHES the launch-per-panel sweep (a launch per panel or pair); both give the
+    oracle's answer."""
+    seq = SyntheticSequence(170, 2, outlier_fraction=0.0, distractors_per_feature=0.0, max_bit_flips=0)
+    e, o = make_pair(eng_mod, oracle_lib, seq, precision=EXACT)
+    e.set_sweep_mode(mode)
+    e.timing(True)
+    e.timing_reset()
+    for t in range(2):
+        gi = e.step(*seq.frames[t])
+        oi = o.step(*seq.frames[t], ALGORITHMIC)
+        _same_info(gi, oi, f"frame {t}")
+    sw = e.sweep_timing()
+    assert sw["updates"] > 0 and sw["panels"] > sw["updates"]
+    assert (sw["launches"] == sw["updates"]) == persistent, sw
+    assert_parity(e, o, f"sweep mode {mode}", 170)
+
+
+def test_auto_sweep_keeps_the_launch_per_panel_sweep_on_wide_maps(eng_mod):
+    """From 8192 state columns on (N >= 1364) EKF_SWEEP_AUTO leaves the persistent sweep (its B workers would take several blocks of
+    columns each: N = 2000 measured 20.4 against 14.0 us per panel); EKF_SWEEP_PERSISTENT still forces it and gives the same filter
+    to rounding (one update of 1200 rows through the stage functions)."""
+    seq = SyntheticSequence(1400, 1, width=1280, height=720)
+    out = []
+    for mode in (2, 3):
+        e = eng_mod.EkfEngine(seq.cam, seq.par, 1400, max_keypoints=len(seq.frames[0][0]) + 64, precision=EXACT)
+        e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+        e.set_sweep_mode(mode)
+        e.timing(True)
+        e.timing_reset()
+        e.predict()
+        preds, _, _ = e.predict_measurements()
+        e.update(_matches_from_predictions(preds, 600))  # 1200 rows: the rows of B inside the sweep
+        sw = e.sweep_timing()
+        x, fp, P = e.get_state()
+        out.append((sw, x, fp, P))
+        e.close()
+    (swa, xa, fa, Pa), (swp, xp, fpp, Pp) = out
+    assert swa["launches"] > swa["updates"] and swp["launches"] == swp["updates"] == 1, (swa, swp)
+    # (two orders of the same fp64 sums under one fp32 rounding of P per entry: far inside the 1e-5 either holds against the oracle)
+    assert np.abs(xa - xp).max() <= 1e-7 and np.abs(fa - fpp).max() <= 1e-7, (np.abs(xa - xp).max(), np.abs(fa - fpp).max())
+    assert np.abs(Pa - Pp).max() <= 1e-6 * np.abs(Pa).max()
+
+
 def test_ragged_inputs_exact(eng_mod, oracle_lib, seq12):
     """no keypoints, then a normal frame; camera turned away; a frame in which every keypoint is displaced"""
     e, o = make_pair(eng_mod, oracle_lib, seq12, precision=EXACT)
