@@ -1464,9 +1464,9 @@ static int step_dev_fast(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *
         }
     };
     // 1-2. prediction (:273-284), timesPredicted++ (EKF.cpp:572)
-    launch_predict(e);
-    {   // (more than 256 features: the compaction of the predicted list rides in the launch of the H P rows)
-        const bool deferred = launch_predict_features(e, nullptr, N, false, true);
+    {   // covariance strips and pixel predictions in one launch; with more than 256 features the compaction of the predicted list
+        // rides in the launch of the H P rows
+        const bool deferred = launch_predict_with_features(e, N);
         launch_hp_rows(e, e->d.plist, N, true, cnt + CNT_NPRED, deferred);
     }
     tm.mark();

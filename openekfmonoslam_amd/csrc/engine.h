@@ -306,6 +306,7 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int c, int *wtot /* __s
 void launch_predict(EkfEngine *e);
 // full (idx == nullptr) or subset prediction; fills tables, compacted list and CNT_NPRED / CNT_NPRED_SUB
 bool launch_predict_features(EkfEngine *e, const int *d_idx, int count, bool state_only, bool defer_compact = false);
+bool launch_predict_with_features(EkfEngine *e, int count); // step path: prepare, then covariance strips + all features in one launch
 // d_count != nullptr: n_list is an upper bound, the list's length is read on the device
 void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_predicted = false, const int *d_count = nullptr, bool from_flags = false);
 // d_npred != nullptr: n_pred is an upper bound, the number of predictions is read on the device

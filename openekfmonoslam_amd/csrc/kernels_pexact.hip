@@ -160,10 +160,20 @@ k_dx_planes(const int8_t *Bq, size_t b_stride, int ldq, int m16, int n, const in
     const int per = (m16 + DX_SPLIT - 1) / DX_SPLIT;
     const int kb0 = ks * per, kb1 = min(m16, kb0 + per);
     double sum = 0.0;
+    // (the next group's five 16-byte loads travel while this one is summed: a thread has only 2-4 groups, one round trip each otherwise)
+    uint4 nx[PX_S];
+    if (kb0 < kb1) {
+#pragma unroll
+        for (int s = 0; s < PX_S; ++s) nx[s] = *(const uint4 *)(Bq + (size_t)s * b_stride + ((size_t)kb0 * ldq + j) * 16);
+    }
     for (int kb = kb0; kb < kb1; ++kb) {
         uint4 d[PX_S];
 #pragma unroll
-        for (int s = 0; s < PX_S; ++s) d[s] = *(const uint4 *)(Bq + (size_t)s * b_stride + ((size_t)kb * ldq + j) * 16);
+        for (int s = 0; s < PX_S; ++s) d[s] = nx[s];
+        if (kb + 1 < kb1) {
+#pragma unroll
+            for (int s = 0; s < PX_S; ++s) nx[s] = *(const uint4 *)(Bq + (size_t)s * b_stride + ((size_t)(kb + 1) * ldq + j) * 16);
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             long long X = 0;

@@ -114,15 +114,16 @@ __device__ void predict_prepare_serial(double *st, double *sG)
 // Sharded storage (RowMap): the camera rows are replicated, so every rank computes the whole row strip; the column
 // strip only exists for the rows a rank owns.  Both strips are the same arithmetic on bitwise-equal operands, which
 // keeps P[a][j] on one rank identical to P[j][a] on the owner of row j.
+// (the body takes its workgroup index as an argument: k_predict_cov_features runs it beside the pixel predictions in ONE launch)
 template <typename T>
-__global__ void __launch_bounds__(256) k_predict_cov(T *P, int ld, int n, const double *st, RowMap rm)
+__device__ __forceinline__ void predict_cov_body(const int bx, T *P, int ld, int n, const double *st, RowMap rm)
 {
     __shared__ double sF[169];
     __shared__ double sC[169];
     __shared__ double sFP[169];
     const int tid = threadIdx.x;
     for (int i = tid; i < 169; i += 256) sF[i] = st[ST_F + i];
-    if (blockIdx.x == 0) {
+    if (bx == 0) {
         for (int i = tid; i < 169; i += 256) sC[i] = (double)P[(size_t)(i / 13) * ld + (i % 13)];
         __syncthreads();
         if (tid < 169) {
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(256) k_predict_cov(T *P, int ld, int n, const 
         return;
     }
     __syncthreads();
-    const int j = 13 + (blockIdx.x - 1) * 256 + tid;
+    const int j = 13 + (bx - 1) * 256 + tid;
     if (j >= n) return;
     const bool mine = owns_row(rm, j);
     T *prow = P + (size_t)local_row(rm, j) * ld;
@@ -167,6 +168,12 @@ __global__ void __launch_bounds__(256) k_predict_cov(T *P, int ld, int n, const 
     }
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256) k_predict_cov(T *P, int ld, int n, const double *st, RowMap rm)
+{
+    predict_cov_body<T>((int)blockIdx.x, P, ld, n, st, rm);
+}
+
 void launch_predict(EkfEngine *e)
 {
     k_predict_prepare<<<1, 256, 0, e->stream>>>(e->d.state, e->par);
@@ -182,12 +189,12 @@ void launch_predict(EkfEngine *e)
 // list != null (ONE workgroup of BLOCK threads covers all work items): the ordered compaction of the predicted items -- k_compact's
 // job -- in the same launch: list[k] = feature index of the k-th predicted item, *out_count = how many.
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK)
-k_predict_features(const double *st, CamD cam, const double *feat_pos, const int *feat_type, const int *idx,
-                   int count, int *flag, int *vis, double *uv_tab, double *Hs_tab, double *Hf_tab, int *vis_full, int *list, int *out_count)
+__device__ __forceinline__ void
+predict_features_body(const int bx, const double *st, const CamD &cam, const double *feat_pos, const int *feat_type, const int *idx,
+                      int count, int *flag, int *vis, double *uv_tab, double *Hs_tab, double *Hf_tab, int *vis_full, int *list, int *out_count)
 {
     __shared__ int wtot[16];
-    const int w = blockIdx.x * BLOCK + threadIdx.x;
+    const int w = bx * BLOCK + threadIdx.x;
     if (list && threadIdx.x < 16) wtot[threadIdx.x] = 0;
     bool ok = false;
     int fi = 0;
@@ -226,6 +233,48 @@ k_predict_features(const double *st, CamD cam, const double *feat_pos, const int
     const int pos = block_exclusive_scan_1024(ok ? 1 : 0, wtot, &total); // (wavefronts that do not exist left zeros)
     if (ok) list[pos] = fi;
     if (threadIdx.x == 0) *out_count = total;
+}
+
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_predict_features(const double *st, CamD cam, const double *feat_pos, const int *feat_type, const int *idx,
+                   int count, int *flag, int *vis, double *uv_tab, double *Hs_tab, double *Hf_tab, int *vis_full, int *list, int *out_count)
+{
+    predict_features_body<BLOCK>((int)blockIdx.x, st, cam, feat_pos, feat_type, idx, count, flag, vis, uv_tab, Hs_tab, Hf_tab, vis_full, list, out_count);
+}
+
+// EKF::step's prediction: the covariance strips (predictCovariance) and the pixel predictions + Jacobians of every feature
+// (predictMeasurementState) both need only what k_predict_prepare left in the state block and touch disjoint data: ONE launch,
+// workgroups [0, nb_cov) the strips, the rest the features.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_predict_cov_features(int nb_cov, T *P, int ld, int n, RowMap rm, const double *st, CamD cam, const double *feat_pos, const int *feat_type,
+                       int count, int *flag, int *vis, double *uv_tab, double *Hs_tab, double *Hf_tab, int *vis_full, int *list, int *out_count)
+{
+    if ((int)blockIdx.x < nb_cov) predict_cov_body<T>((int)blockIdx.x, P, ld, n, st, rm);
+    else predict_features_body<256>((int)blockIdx.x - nb_cov, st, cam, feat_pos, feat_type, nullptr, count, flag, vis, uv_tab, Hs_tab, Hf_tab,
+                                    vis_full, list, out_count);
+}
+
+// launch_predict + launch_predict_features(e, nullptr, count, false, true) of the step path in two launches instead of three (or
+// four); returns whether the compaction of the predicted list is left to launch_hp_rows(..., from_flags = true)
+bool launch_predict_with_features(EkfEngine *e, int count)
+{
+    if (count <= 0) {
+        launch_predict(e);
+        return launch_predict_features(e, nullptr, count, false, true);
+    }
+    k_predict_prepare<<<1, 256, 0, e->stream>>>(e->d.state, e->par);
+    const int nb_cov = 1 + (e->n > 13 ? (e->n - 13 + 255) / 256 : 0);
+    const int nb_f = (count + 255) / 256;
+    const bool one = count <= 256; // one workgroup of features: it compacts its own list
+    int *list = one ? e->d.plist : nullptr, *cnt = one ? e->d.counts + CNT_NPRED : nullptr;
+#define PCF_ARGS e->ldP, e->n, e->rm, e->d.state, e->cam, e->d.feat_pos, e->d.feat_type, count, e->d.work_flag, e->d.pred_vis, e->d.pred_uv, e->d.Hs, \
+                 e->d.Hf, e->d.pred_vis_full, list, cnt
+    if (e->f32) k_predict_cov_features<float><<<nb_cov + nb_f, 256, 0, e->stream>>>(nb_cov, (float *)e->d.P, PCF_ARGS);
+    else k_predict_cov_features<double><<<nb_cov + nb_f, 256, 0, e->stream>>>(nb_cov, (double *)e->d.P, PCF_ARGS);
+#undef PCF_ARGS
+    return !one;
 }
 
 // Ordered compaction of flag[0..count) by one 1024-thread block: list[k] = feature index of the k-th predicted
