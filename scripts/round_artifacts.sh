@@ -21,11 +21,8 @@ $B --workload n1000_f32x --sweep-mode 4 > "$out/bench_n1000_f32x_launches.json" 
 $B --workload n200_f64 --sweep-mode 4 --steps 60 --warmup 10 > "$out/bench_n200_f64_launches.json" 2> /dev/null
 $B --matcher ncc --workload n2000_f32x --steps 20 --warmup 5 > "$out/bench_n2000_f32x_ncc.json" 2> /dev/null
 $B --emulate-shards 4 --workload n2000_f32x --steps 6 --warmup 2 --no-cpu-baseline > "$out/bench_n2000_f32x_emulated4.json" 2> /dev/null
-# the downdate kernel alone: variants (0 persistent, 1 first version), bitwise check against the CPU, ablations when built
-for v in 0 1; do timeout 300 scripts/micro/pu_i8_bench 1000 298,1014,2000 15 $v; done > "$out/pu_i8_bench.txt" 2>&1
-for a in 1 3 7 11 15; do
-  [ -x scripts/micro/pu_i8_bench_abl$a ] && { echo "== PX_ABL=$a"; timeout 120 scripts/micro/pu_i8_bench_abl$a 1000 1014 15 0 | tail -3; }
-done >> "$out/pu_i8_bench.txt" 2>&1
+# the downdate kernel alone: variants (0 persistent, 1 first version), bitwise check against the CPU, ablations at m = 298 / 1014 when built
+bash scripts/pu_i8_micro.sh > "$out/pu_i8_bench.txt" 2>&1
 # timelines of the persistent sweep: only when the debug build is there (scripts/build_trace_variant.sh)
 if [ -f variants/libekf_engine_trace.so ]; then
   EKF_ENGINE_LIB=variants/libekf_engine_trace.so timeout 300 python scripts/persist_trace.py 1000 12 0 2>/dev/null | grep -v amdgpu.ids > "$out/persist_trace_n1000_f32x.txt"
