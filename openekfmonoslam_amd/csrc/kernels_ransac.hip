@@ -93,44 +93,49 @@ k_ransac_hyp(const double *st, CamD cam, double thr, const double *feat_pos, con
     }
 }
 
-// Sequential bookkeeping of the hypothesis loop (1PointRansac.cpp:125,164-178) over one batch.
+// Sequential bookkeeping of the hypothesis loop (1PointRansac.cpp:125,164-178) over one batch.  The decisions depend only on the
+// batch's support counts and the loop state, and of the inlier masks only the LAST improving hypothesis' survives: every thread
+// replays the loop in registers (no barrier, no trip to memory per hypothesis -- as one thread with the state in global memory and
+// two barriers per hypothesis this kernel took 7 us), then the workgroup copies that one mask and thread 0 writes the state back.
 __global__ void __launch_bounds__(256)
 k_ransac_select(int *counts, const int *hyp_count, const uint8_t *hyp_flags, uint8_t *best_flags, int M, int h0,
                 int batch, int mcap, double prob, const int *d_M, int *mirror, int publish_seq)
 {
-    __shared__ int improved, stop;
     if (d_M) M = *d_M;
     const int tid = threadIdx.x;
+    int best = counts[CNT_RS_BEST], besth = counts[CNT_RS_BESTH], nhyp = counts[CNT_RS_NHYP], next = counts[CNT_RS_NEXT];
+    __syncthreads(); // (everyone has read the state thread 0 rewrites below)
+    int last = -1;
+    bool stop = false, done = false;
     for (int b = 0; b < batch; ++b) {
         const int i = h0 + b;
-        if (tid == 0) {
-            improved = 0;
-            stop = 0;
-            const unsigned nhyp = (unsigned)counts[CNT_RS_NHYP];
-            if (!((unsigned)i < nhyp && i < M)) {
-                stop = 1;
-                counts[CNT_RS_DONE] = 1;
-            } else {
-                const int ns = hyp_count[b];
-                if (ns > counts[CNT_RS_BEST]) {
-                    counts[CNT_RS_BEST] = ns;
-                    counts[CNT_RS_BESTH] = i;
-                    const double e = 1.0 - (double)ns / (double)M;
-                    counts[CNT_RS_NHYP] = (int)(log(1.0 - prob) / log(1.0 - (1.0 - e)));
-                    improved = 1;
-                }
-                counts[CNT_RS_NEXT] = i + 1;
-            }
+        if (!((unsigned)i < (unsigned)nhyp && i < M)) {
+            stop = true;
+            done = true;
+            break;
         }
-        __syncthreads();
-        if (stop) break;
-        if (improved)
-            for (int k = tid; k < M; k += 256) best_flags[k] = hyp_flags[(size_t)b * mcap + k];
-        __syncthreads();
+        const int ns = hyp_count[b];
+        if (ns > best) {
+            best = ns;
+            besth = i;
+            const double e = 1.0 - (double)ns / (double)M;
+            nhyp = (int)(log(1.0 - prob) / log(1.0 - (1.0 - e)));
+            last = b;
+        }
+        next = i + 1;
     }
-    if (tid == 0 && !stop) {
+    if (!stop) {
         const int i = h0 + batch;
-        if (!((unsigned)i < (unsigned)counts[CNT_RS_NHYP] && i < M)) counts[CNT_RS_DONE] = 1;
+        if (!((unsigned)i < (unsigned)nhyp && i < M)) done = true;
+    }
+    if (last >= 0)
+        for (int k = tid; k < M; k += 256) best_flags[k] = hyp_flags[(size_t)last * mcap + k];
+    if (tid == 0) {
+        counts[CNT_RS_BEST] = best;
+        counts[CNT_RS_BESTH] = besth;
+        counts[CNT_RS_NHYP] = nhyp;
+        counts[CNT_RS_NEXT] = next;
+        if (done) counts[CNT_RS_DONE] = 1;
     }
     if (publish_seq > 0) publish_counts_block(counts, mirror, publish_seq);
 }
