@@ -307,7 +307,8 @@ class EkfEngine:
         self._chk(self.L.ekf_set_update_path(self.h, int(path)))
 
     def set_sweep_mode(self, mode):
-        """2: by size (default), 1: one panel of the Cholesky sweep per launch, 0: two panels per launch (ekf_engine.h)"""
+        """2: by size (default: ONE persistent launch per update on maps below 8192 state columns, launches per panel above),
+        3: the persistent sweep wherever it is available, 4: launches per panel (1 / 0: one / two panels per launch); ekf_engine.h"""
         self._chk(self.L.ekf_set_sweep_mode(self.h, int(mode)))
 
     def keep_step_predictions(self, on=True):
