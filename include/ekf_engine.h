@@ -79,7 +79,9 @@ typedef struct EkfStepInfo {
     int32_t n_outliers;
     int32_t n_rescued;
     int32_t status;
-    int32_t _pad;
+    int32_t n_sweep_retries; /* updates of this step whose persistent Cholesky sweep timed out and that were run again, transparently,
+                              * on the launch-per-panel sweep (the slot the oracle's OrcStepInfo leaves as padding; 0 in normal
+                              * operation; ekf_get_sweep_retries totals them) */
 } EkfStepInfo;
 
 /* Accumulated GPU time per stage, in milliseconds, under the reference's own stage names
@@ -216,7 +218,8 @@ int ekf_set_update_path(EkfEngine *e, int path);
 /* How the blocked Cholesky sweep of S (replaces S.inv(), EKF/Update.cpp:108) is launched: EKF_SWEEP_SINGLE one 32-row panel per
  * launch, EKF_SWEEP_PAIRS two panels per launch with a 64 x 64 look-ahead inverse, EKF_SWEEP_PERSISTENT ONE launch per update
  * (a resident critical workgroup factorises panel after panel, tile and row-block workers follow it through flags; updates of at
- * most 2048 rows on an unsharded engine in the fp64 and the exact configuration, otherwise launches as under AUTO),
+ * most 2048 rows on an unsharded engine in the fp64 and the exact configuration whose grid fits the device, otherwise launches as
+ * under AUTO; a sweep whose waits time out is run again on the launch-per-panel path, see ekf_get_sweep_retries),
  * EKF_SWEEP_LAUNCHES the round-4 rule (single launches while a launch is bound by its look-ahead factorisation, pairs once the
  * rows of B = inv(L) H P are the longest role), EKF_SWEEP_AUTO (the default): persistent where it applies AND the map has fewer
  * than 8192 state columns (above, its row-block workers take several blocks of columns each and two panels per launch are faster:
@@ -283,12 +286,12 @@ int ekf_timing_sweep_launches(EkfEngine *e, int64_t *launches, double *slice_ms)
  * fp64 arithmetic": the accuracy floor of EKF_PRECISION_F32 / _F32_EXACT on a sequence (scripts/storage_floor_gpu.py).  The
  * reference keeps everything in double (Core/Base.h:67). */
 int ekf_round_covariance_to_f32(EkfEngine *e);
-/* Test aid for the watchdog of the persistent Cholesky sweep (csrc/chol_persist.h): the NEXT persistent sweep of this engine runs
- * without its chain workgroup -- the situation of a role that never became resident.  Every other role then waits for a hand-off
- * that cannot come; the bounded waits (30 ms) must end the kernel and the update must return EKF_ERR_TIMEOUT instead of hanging
- * the stream.  One sweep only; the engine's filter state is undefined afterwards (ekf_set_state / ekf_reset before going on).
- * No counterpart in the reference. */
-int ekf_debug_stall_next_sweep(EkfEngine *e);
+/* Updates re-run on the launch-per-panel sweep since the engine was created because their persistent sweep
+ * (EKF_SWEEP_PERSISTENT / _AUTO) timed out: the sweep needs all of its workgroups resident at once, which another process's
+ * kernels on the device or a device partition can prevent; its waits are bounded (30 ms), the kernels behind a failed sweep leave
+ * x and P untouched, and the engine runs the same update again from the same P -- the caller sees EKF_OK and this counter.
+ * (The fault-injection hook that exercises this path is declared in ekf_test_hooks.h, not here.) */
+int ekf_get_sweep_retries(const EkfEngine *e);
 
 /* -- row-sharded filter (multi-GPU) ----------------------------------------------------------
  * One engine per GPU / rank.  Rank g stores the 13 camera rows of P (replicated, updated identically everywhere)

@@ -1,0 +1,27 @@
+/*
+ * ekf_test_hooks.h -- fault injection for the test suite.  NOT part of the drop-in boundary (include/ekf_engine.h): nothing a host
+ * of the reference would call.  The symbols are exported by libekf_engine.so so that the tests can reach them through the same
+ * C ABI as everything else.
+ */
+#ifndef EKF_TEST_HOOKS_H
+#define EKF_TEST_HOOKS_H
+
+#include "ekf_engine.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The NEXT persistent Cholesky sweep of this engine (csrc/chol_persist.h) runs without its chain workgroup -- the situation of a
+ * role that never became resident.  Every other role then waits for a hand-off that cannot come; the bounded waits (30 ms) must end
+ * the kernel with the sticky code EKF_ERR_TIMEOUT, the kernels behind the sweep must leave x and P untouched, and the engine must
+ * run the update again on the launch-per-panel sweep: the caller sees EKF_OK, the oracle's result, and one more
+ * ekf_get_sweep_retries.  One sweep only.  No counterpart in the reference. */
+int ekf_debug_stall_next_sweep(EkfEngine *e);
+/* ... the same for the persistent sweep AFTER the next `skip` ones (skip = 1: the second update of the next EKF::step). */
+int ekf_debug_stall_sweep_after(EkfEngine *e, int skip);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EKF_TEST_HOOKS_H */

@@ -28,7 +28,7 @@
 #pragma once
 
 struct SweepCtl {
-    unsigned arrive;    // tickets handed out (all launches)
+    unsigned reserved;  // (roles come from blockIdx: no tickets)
     unsigned inv_ready; // epoch base + panels whose inv(L_kk) is published
     unsigned err;       // != 0: the launch is failing, everybody leaves
     unsigned pad[29];
@@ -55,7 +55,6 @@ struct PsArgs {
     BPlanes bp;
     SweepCtl *ctl;
     unsigned eb;          // epoch base of this sweep's flag values
-    unsigned arrive_base; // tickets handed out before this launch
     int n_b, n_bcols, n_t;
     int n_cus;  // > 0: block n_cus is an empty spacer (in-order dispatch would put it on the chain workgroup's CU)
     int fault;  // test aid (ekf_debug_stall_next_sweep): the chain workgroup leaves at once, as if it had never become resident
@@ -192,6 +191,26 @@ __device__ __forceinline__ bool ps_wait_all(const unsigned *flags, int count, un
     const int r = okv_s;
     __syncthreads();
     return r != 0;
+}
+
+// intra-workgroup hand-off through an LDS word (the chain workgroup's two helper wavefronts): wait until *word >= value, or until
+// the workgroup's failure word is raised / the wall-time bound runs out (then false, with the failure word raised for the partner)
+__device__ __forceinline__ bool ps_lds_wait(int *word, int value, int *fail_s)
+{
+    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= value) return true;
+    const long long t0 = wall_clock64();
+    unsigned n = 0;
+    for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= value) return true;
+        if ((++n & 15u) == 0) {
+            if (__hip_atomic_load(fail_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return false;
+            if (wall_clock64() - t0 > PS_TIMEOUT_TICKS) {
+                __hip_atomic_store(fail_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return false;
+            }
+        }
+    }
 }
 
 // every storing wavefront drains its stores, then ONE lane raises the flag
@@ -674,7 +693,9 @@ __global__ void __launch_bounds__(256, 2) k_chol_persist(PsArgs a)
                 }
                 // Y2 = U2 - L2 L2' : the lower quadrants -- (0, 0) here, (1, 0) and (1, 1) there, (1, 0) needs the other rows of L2
                 if (h == 1) {
-                    while (__hip_atomic_load(&hs_l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < k) __builtin_amdgcn_s_sleep(1);
+                    // (bounded like every other spin: wavefront 2 may have left through the failure path -- its own time-out or
+                    // somebody's error -- after this wavefront saw the same three flags arrive)
+                    if (!ps_lds_wait(&hs_l2, k, &hfail_s)) return;
                     asm volatile("" ::: "memory");
                 }
 #pragma unroll
@@ -689,7 +710,7 @@ __global__ void __launch_bounds__(256, 2) k_chol_persist(PsArgs a)
                 if (h == 1) {
                     if (lane == 0) __hip_atomic_store(&hs_wb, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
-                    while (__hip_atomic_load(&hs_wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < k) __builtin_amdgcn_s_sleep(1);
+                    if (!ps_lds_wait(&hs_wb, k, &hfail_s)) return;
                     if (lane == 0) __hip_atomic_store(&done[(size_t)(k + 1) * PS_NBC + k], a.eb + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             };

@@ -1,6 +1,7 @@
 // engine.cpp -- C ABI of the MI355X EKF engine (see include/ekf_engine.h).  Host orchestration only: every
 // number is produced by the HIP kernels in kernels_*.hip; there is no CPU compute path.
 #include "engine.h"
+#include "../../include/ekf_test_hooks.h"
 
 #include <cmath>
 #include <cstdio>
@@ -116,7 +117,8 @@ const char *ekf_last_error(const EkfEngine *e) { return e ? e->err.c_str() : "nu
 void ekf_engine_destroy(EkfEngine *e)
 {
     if (!e) return;
-    if (e->counted_alive) --g_engines_alive;
+    sweep_registry_detach(e->ps_reg, e);
+    e->ps_reg.reset();
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     DeviceArrays &d = e->d;
@@ -361,8 +363,7 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     }
     e->shard_feat_begin.assign(world + 1, 0);
     e->exchange_hook = exchange_rows;
-    ++g_engines_alive;
-    e->counted_alive = true;
+    e->ps_reg = sweep_registry_attach(e->device); // persistent sweeps of the engines on one device are ordered (engine.h)
     *out = e;
     return EKF_OK;
 }
@@ -1232,17 +1233,47 @@ static int update_dev(EkfEngine *e, int M, bool update_cov, bool lean = false)
     return check_async(e);
 }
 
+// e->h_counts[CNT_ERR] != 0 was read back: the last update enqueued failed and, with everything enqueued behind it, left the filter
+// as it was (filter_frozen, engine.h).  Clears the flag.  A persistent sweep that timed out (another process's kernels on the
+// device, a partition that could not hold the grid: chol_persist.h) is not the caller's problem: the SAME update -- its match list
+// is still in d.msel -- runs again on the launch-per-panel sweep, which has no cross-workgroup waits, from the untouched P
+// (S, nu and the gathered rows are formed again); *status stays EKF_OK when that succeeds and the engine counts the retry.
+// Anything else (S not positive definite) goes to *status: that update is skipped, as the reference skips it (cv::invert
+// returns zeros, K = 0: EKF/Update.cpp:101-108).  Returns a hard error (HIP, exchange) or EKF_OK.
+static int recover_failed_update(EkfEngine *e, int *status)
+{
+    const int code = e->h_counts[CNT_ERR];
+    if (!code) return EKF_OK;
+    HIPCHK(hipMemsetAsync(e->d.counts + CNT_ERR, 0, sizeof(int), e->stream));
+    e->h_counts[CNT_ERR] = 0;
+    e->p_exact_sym = e->last_update_sym; // (the frozen downdate did not symmetrise an uploaded P)
+    if (code == EKF_ERR_TIMEOUT && e->last_update_persist && e->last_update_M > 0) {
+        ++e->force_launches;
+        int rc = update_dev(e, e->last_update_M, e->last_update_cov, false);
+        --e->force_launches;
+        ++e->sweep_retries;
+        if (rc) return rc;
+        if ((rc = read_counts(e))) return rc;
+        if (!e->h_counts[CNT_ERR]) return EKF_OK;
+        const int code2 = e->h_counts[CNT_ERR]; // the retry's own outcome (it cannot time out)
+        HIPCHK(hipMemsetAsync(e->d.counts + CNT_ERR, 0, sizeof(int), e->stream));
+        e->h_counts[CNT_ERR] = 0;
+        e->p_exact_sym = e->last_update_sym;
+        *status = code2;
+    } else {
+        *status = code;
+    }
+    e->err = *status == EKF_ERR_TIMEOUT ? "the persistent Cholesky sweep timed out" : "S = H P H' + R is not positive definite";
+    return EKF_OK;
+}
+
 static int finish_update(EkfEngine *e)
 {
     int rc = read_counts(e);
     if (rc) return rc;
-    if (e->h_counts[CNT_ERR]) {
-        const int code = e->h_counts[CNT_ERR];
-        HIPCHK(hipMemsetAsync(e->d.counts + CNT_ERR, 0, sizeof(int), e->stream));
-        e->err = "S = H P H' + R is not positive definite";
-        return code;
-    }
-    return EKF_OK;
+    int status = EKF_OK;
+    if ((rc = recover_failed_update(e, &status))) return rc;
+    return status;
 }
 
 int ekf_update(EkfEngine *e, const EkfMatch *matches, int M)
@@ -1378,6 +1409,7 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
     EkfStepInfo li;
     std::memset(&li, 0, sizeof(li));
     int status = EKF_OK, rc;
+    const int retries0 = e->sweep_retries;
     StageTimer tm(e);
     tm.mark();
     // 1-2. prediction (:273-284)
@@ -1412,8 +1444,13 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
     int nr = 0;
     if (no > 0) {
         int nop = 0;
-        if ((rc = predict_measurements_dev(e, e->d.work_idx, no, &nop, false, lean))) return rc;
-        if (e->h_counts[CNT_ERR]) status = e->h_counts[CNT_ERR];
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if ((rc = predict_measurements_dev(e, e->d.work_idx, no, &nop, false, lean))) return rc;
+            if (!e->h_counts[CNT_ERR]) break;
+            // the first update failed (seen at this stage's read-back; everything behind it was frozen): run it again or skip it
+            // (recover_failed_update), then this stage again
+            if ((rc = recover_failed_update(e, &status))) return rc;
+        }
         if (nop > 0) {
             EkfMatch *save = e->d.matches;
             e->d.matches = e->d.mout;
@@ -1430,13 +1467,10 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
     if ((rc = update_dev(e, nr, true, lean))) return rc;
     tm.mark();
     if ((rc = read_counts(e))) return rc;
-    if (e->h_counts[CNT_ERR]) {
-        status = e->h_counts[CNT_ERR];
-        HIPCHK(hipMemsetAsync(e->d.counts + CNT_ERR, 0, sizeof(int), e->stream));
-        e->err = "S = H P H' + R is not positive definite";
-    }
+    if ((rc = recover_failed_update(e, &status))) return rc;
     tm.finish();
     li.status = status;
+    li.n_sweep_retries = e->sweep_retries - retries0;
     if (info) *info = li;
     return status;
 }
@@ -1452,17 +1486,15 @@ static int step_dev_fast(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *
     EkfStepInfo li;
     std::memset(&li, 0, sizeof(li));
     int status = EKF_OK, rc;
-    StageTimer tm(e);
-    tm.mark();
+    const int retries0 = e->sweep_retries;
     const int N = e->N;
     int *cnt = e->d.counts;
-    auto take_error = [&]() {
-        if (e->h_counts[CNT_ERR]) {
-            status = e->h_counts[CNT_ERR];
-            (void)hipMemsetAsync(cnt + CNT_ERR, 0, sizeof(int), e->stream);
-            e->err = "S = H P H' + R is not positive definite";
-        }
-    };
+    // A failed update is seen at the next read-back; until then everything enqueued behind it has left the filter alone
+    // (filter_frozen, engine.h), so whatever ran meanwhile is simply run again after recover_failed_update.
+    bool restarted = false;
+restart:
+    StageTimer tm(e);
+    tm.mark();
     // 1-2. prediction (:273-284), timesPredicted++ (EKF.cpp:572)
     {   // covariance strips and pixel predictions in one launch; with more than 256 features the compaction of the predicted list
         // rides in the launch of the H P rows
@@ -1486,7 +1518,13 @@ static int step_dev_fast(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *
     const int seq_r = next_publish_seq(e);
     launch_ransac_batch(e, N, 0, batch, cnt + CNT_NMATCH, seq_r);
     if ((rc = wait_counts(e, seq_r))) return rc;
-    take_error(); // a failure of the previous step's last update, when its final read-back was skipped
+    if (e->h_counts[CNT_ERR] && !restarted) {
+        // the previous step's last update failed and its final read-back was skipped (ekf_set_async_errors): this step's prediction
+        // did not touch the filter -- recover (that update again, or skipped and reported here), then this step from its start
+        if ((rc = recover_failed_update(e, &status))) return rc;
+        restarted = true;
+        goto restart;
+    }
     const int np = e->h_counts[CNT_NPRED], M = e->h_counts[CNT_NMATCH];
     e->n_pred = np;
     li.n_predicted = np;
@@ -1514,13 +1552,18 @@ static int step_dev_fast(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *
     // undefined behaviour, see step_dev).
     int nr = 0;
     if (no > 0) {
-        launch_predict_features(e, e->d.work_idx, no, false);
-        launch_hp_rows(e, e->d.plist_sub, no, false, cnt + CNT_NPRED_SUB);
-        const int seq_p = next_publish_seq(e);
-        // rescueOutliers (EKF.cpp:84-97) and the partition it feeds in one launch: rescued matches join the inliers (EKF.cpp:552-556)
-        launch_partition(e, e->d.mout, no, e->d.mask, e->d.msel, nullptr, cnt + CNT_NRESC, true, d_desc, nullptr, seq_p, true);
-        if ((rc = wait_counts(e, seq_p))) return rc;
-        take_error();
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            launch_predict_features(e, e->d.work_idx, no, false);
+            launch_hp_rows(e, e->d.plist_sub, no, false, cnt + CNT_NPRED_SUB);
+            const int seq_p = next_publish_seq(e);
+            // rescueOutliers (EKF.cpp:84-97) and the partition it feeds in one launch: rescued matches join the inliers (EKF.cpp:552-556)
+            launch_partition(e, e->d.mout, no, e->d.mask, e->d.msel, nullptr, cnt + CNT_NRESC, true, d_desc, nullptr, seq_p, true);
+            if ((rc = wait_counts(e, seq_p))) return rc;
+            if (!e->h_counts[CNT_ERR]) break;
+            // the first update failed: the partition above did nothing (the inliers are still in d.msel); that update again or
+            // skipped, then this stage again
+            if ((rc = recover_failed_update(e, &status))) return rc;
+        }
         nr = e->h_counts[CNT_NRESC];
     }
     li.n_rescued = nr;
@@ -1530,10 +1573,11 @@ static int step_dev_fast(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *
     tm.mark();
     if (!e->async_errors) {
         if ((rc = read_counts(e))) return rc;
-        take_error();
+        if ((rc = recover_failed_update(e, &status))) return rc;
     }
     tm.finish();
     li.status = status;
+    li.n_sweep_retries = e->sweep_retries - retries0;
     if (info) *info = li;
     return status;
 }
@@ -1931,10 +1975,19 @@ int ekf_timing_sweep(EkfEngine *e, double *kernel_ms, int64_t *panels, int64_t *
     return EKF_OK;
 }
 
-int ekf_debug_stall_next_sweep(EkfEngine *e)
+int ekf_get_sweep_retries(const EkfEngine *e) { return e ? e->sweep_retries : 0; }
+
+int ekf_debug_stall_next_sweep(EkfEngine *e) // include/ekf_test_hooks.h
 {
     if (!e) return EKF_ERR_INVALID_ARG;
     e->ps_fault = 1;
+    return EKF_OK;
+}
+
+int ekf_debug_stall_sweep_after(EkfEngine *e, int skip)
+{
+    if (!e || skip < 0) return EKF_ERR_INVALID_ARG;
+    e->ps_fault = skip + 1; // counted down by the persistent launches; the one that reaches zero runs without its chain workgroup
     return EKF_OK;
 }
 

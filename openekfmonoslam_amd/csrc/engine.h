@@ -5,6 +5,8 @@
 #include <atomic>
 #include <cstdint>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -165,6 +167,25 @@ struct Image {
     int seq_n = 0, seq_w = 0, seq_h = 0, seq_stride = 0, seq_channels = 0;
 };
 
+// Persistent Cholesky sweeps (chol_persist.h) need ALL their workgroups resident at once; two of them in flight on one device, each
+// only partly resident, would wait for each other's workgroups until the watchdog ends both.  Engines of one process that share a
+// device therefore share one registry (held by shared_ptr: it lives exactly as long as its engines): with more than one member every
+// persistent launch is ordered behind the last persistent launch of any OTHER member by an event.  (Other processes on the device
+// cannot be ordered; the watchdog and the automatic retry on the launch-per-panel sweep cover them.)
+struct SweepRegistry {
+    std::mutex mu;
+    int device = 0;
+    int members = 0;                  // engines attached
+    hipEvent_t last = nullptr;        // end of the most recent persistent sweep recorded here
+    const void *owner = nullptr;      // the engine that recorded it
+    ~SweepRegistry()
+    {
+        if (last) (void)hipEventDestroy(last);
+    }
+};
+std::shared_ptr<SweepRegistry> sweep_registry_attach(int device); // kernels_update.hip
+void sweep_registry_detach(const std::shared_ptr<SweepRegistry> &reg, const void *engine);
+
 struct Frames {
     int n = 0;
     std::vector<int> offset, count;
@@ -206,9 +227,17 @@ struct EkfEngine {
     int n_cus = 256;           // compute units of the device (launch-shape decisions)
     int b_path = 0;            // ekf_set_update_path: 0 by size (B_SWEEP_MAX), 1 B in the sweep, 2 inverse + GEMM
     int sweep_mode = 2;        // ekf_set_sweep_mode: EKF_SWEEP_* (2 AUTO: one persistent launch per update where it applies, chol_persist.h)
-    unsigned ps_epoch = 0, ps_arrive = 0; // persistent sweep: epoch of its flags, tickets handed out so far
-    int ps_fault = 0;                     // ekf_debug_stall_next_sweep: the next persistent sweep runs without its chain workgroup
-    bool counted_alive = false; // this engine is in g_engines_alive (set at the end of a successful create)
+    unsigned ps_epoch = 0;                // persistent sweep: epoch of its flags
+    int ps_fault = 0;                     // include/ekf_test_hooks.h: countdown; the persistent sweep that takes it to zero runs without its chain workgroup
+    std::shared_ptr<ekf::SweepRegistry> ps_reg; // the device's registry of persistent sweeps (shared with the other engines on it)
+    // automatic retry of an update whose persistent sweep timed out (EKF_ERR_TIMEOUT): the kernels behind a failed sweep leave the
+    // filter untouched (filter_frozen), so the update is run again from the same P on the launch-per-panel sweep
+    int force_launches = 0;               // > 0: updates use the launch-per-panel sweep whatever sweep_mode says (the retry itself)
+    int sweep_retries = 0;                // updates re-run this way since the engine was created (ekf_get_sweep_retries)
+    int last_update_M = 0;                // matches of the last update enqueued (its list is still in d.msel)
+    bool last_update_cov = true;          // ... a covariance update (false: updateOnlyState)
+    bool last_update_sym = false;         // p_exact_sym as it was before that update
+    bool last_update_persist = false;     // that update's sweep was the persistent launch
     int ps_cap[2] = {0, 0};    // resident workgroups of k_chol_persist<false / true> on this device (0: not asked yet, -1: unusable)
     bool async_errors = false; // ekf_set_async_errors: no read-back at the end of a step
     bool p_exact_sym = false; // P known to be bitwise symmetric (engine-maintained invariant)
@@ -257,8 +286,6 @@ struct EkfEngine {
 
 namespace ekf {
 
-extern std::atomic<int> g_engines_alive; // engines of this process (kernels_update.hip: persistent sweeps of different engines are chained)
-
 // C[i][j] = alpha sum_k X[k][i] Y[k][j] (kernels_gemm.hip); batch element b adds b * (xb, yb, cb, ctb) elements
 struct XtyArgs {
     const void *X; int ldx; long long xb;
@@ -275,6 +302,16 @@ struct XtyArgs {
     double alpha;
 };
 void launch_xty(EkfEngine *e, const XtyArgs &a, int batch, bool f32, hipStream_t stream);
+
+// A failed factorisation of S (EKF_ERR_NOT_POSITIVE_DEFINITE) or a timed-out persistent sweep (EKF_ERR_TIMEOUT) leaves its code in
+// counts[CNT_ERR] until the host has read it.  While it is set the filter is FROZEN: the kernels that write the state, the covariance
+// or the map's bookkeeping return at once (the downdate and the state update of the failed update itself, and whatever of the
+// following stages was enqueued before the host looked), so the host finds x, P and the map exactly as they were before the failed
+// update and can run it again (time-out) or go on without it (S not positive definite: the reference's cv::invert returns zeros
+// there, i.e. K = 0 and an unchanged filter, EKF/Update.cpp:101-108).  counts == nullptr: no guard (stage calls that synchronise).
+#ifdef __HIPCC__
+__device__ __forceinline__ bool filter_frozen(const int *counts) { return counts != nullptr && counts[CNT_ERR] != 0; }
+#endif
 
 // Exclusive prefix sum of one int per thread over a 1024-thread workgroup (and the total): inside a wavefront by shuffles,
 // across the 16 wavefronts through LDS -- one barrier, where a Hillis-Steele scan in LDS needs twenty.  Device code only.

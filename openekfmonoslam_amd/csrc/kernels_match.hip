@@ -222,6 +222,10 @@ k_partition(const EkfMatch *src, int M, const uint8_t *flags, EkfMatch *dst1, Ek
 {
     __shared__ int wtot[16];
     const int tid = threadIdx.x;
+    if (filter_frozen(counts)) { // behind a failed update (engine.h): the lists and the map's bookkeeping stay; the host still gets its block
+        if (publish_seq > 0) publish_counts_block(counts, mirror, publish_seq);
+        return;
+    }
     const int per = (M + 1023) / 1024;
     const int b = tid * per, e = min(M, b + per);
     if (rescue_mask) {

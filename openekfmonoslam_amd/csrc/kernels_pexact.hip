@@ -259,9 +259,10 @@ __device__ __forceinline__ void px_step(const unsigned char *sb, int offA, int o
 template <bool AVG>
 __global__ void __launch_bounds__(512, 2)
 k_p_update_i8(float *P, int ldp, int n, const int8_t *Bq, int ldq, size_t plane_stride, int m_k, const int *bexp, int per_xcd,
-              const int4 *units)
+              const int4 *units, const int *counts)
 {
     constexpr int TM = 128, MB = 32;
+    if (filter_frozen(counts)) return; // the update's sweep failed: P stays as it was (engine.h)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][PX_S * 8192];
     const int4 unit = units[(size_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)]; // XCD-aware work order, see k_p_update
     if (unit.x < 0) return;
@@ -443,10 +444,11 @@ constexpr int PX_RING = 3;
 template <bool RECT, typename TP = float>
 __global__ void __launch_bounds__(512, 2)
 k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq, int ldq, size_t plane_stride, int m_k,
-               const int *__restrict__ bexp, int per_xcd, const int4 *__restrict__ units, int slots, RowMap rm)
+               const int *__restrict__ bexp, int per_xcd, const int4 *__restrict__ units, int slots, RowMap rm, const int *__restrict__ counts)
 {
     constexpr int TM = 128, MB = 32, SLAB = PX_S * 8192;
     constexpr int ST = MB + 4; // row stride of the epilogue's staging image: 16-byte aligned rows
+    if (filter_frozen(counts)) return; // the update's sweep failed: P stays as it was (engine.h; one scalar load before anything is in flight)
     __shared__ __attribute__((aligned(16))) unsigned char ring[PX_RING * SLAB];
     __shared__ __attribute__((aligned(16))) float sTall[8 * MB * ST];
     __shared__ int sExp[2][2 * TM];
@@ -825,7 +827,7 @@ __device__ __forceinline__ void px_step_q(unsigned ldsA, unsigned ldsB, v16i (&a
 template <bool RECT>
 __global__ void __launch_bounds__(256, 1)
 k_p_update_i8q(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq, int ldq, size_t plane_stride, int m_k,
-               const int *__restrict__ bexp, int per_xcd, const int4 *__restrict__ units, int slots, RowMap rm)
+               const int *__restrict__ bexp, int per_xcd, const int4 *__restrict__ units, int slots, RowMap rm, const int * /*counts*/)
 {
     constexpr int TM = 128, MB = 32, SLAB = PX_S * 8192;
     constexpr int ST = MB + 4; // row stride of the epilogue's staging image: 16-byte aligned rows
@@ -1249,18 +1251,18 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bo
     if (!e->f32) { // fp64-stored P (EKF_PRECISION_F64_EXACT): the persistent kernel with the fp64 epilogue; an arbitrary upload is
                    // symmetrised first (0.5 (P + P') - B'B = 0.5 ((P - B'B) + (P - B'B)'): B'B is symmetric)
         if (!e->p_exact_sym && !rect) k_symmetrize_P<<<dim3((n + 255) / 256, n), 256, 0, s>>>((double *)e->d.P, ld, n);
-        if (rect) k_p_update_i8p<true, double><<<e->n_cus, 512, 0, s>>>((double *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
-        else k_p_update_i8p<false, double><<<e->n_cus, 512, 0, s>>>((double *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
+        if (rect) k_p_update_i8p<true, double><<<e->n_cus, 512, 0, s>>>((double *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts);
+        else k_p_update_i8p<false, double><<<e->n_cus, 512, 0, s>>>((double *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts);
     } else
-    if (!e->p_exact_sym && !rect) k_p_update_i8<true><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
-    else if (g_px_variant == 1 || PX_S != 5) k_p_update_i8<false><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm);
+    if (!e->p_exact_sym && !rect) k_p_update_i8<true><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->d.counts);
+    else if (g_px_variant == 1 || PX_S != 5) k_p_update_i8<false><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->d.counts);
 #if PX_S_VALUE == 5
 #ifdef PX_BENCH
-    else if (g_px_variant == 3 && rect) k_p_update_i8q<true><<<e->n_cus, 256, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
-    else if (g_px_variant == 3) k_p_update_i8q<false><<<e->n_cus, 256, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
+    else if (g_px_variant == 3 && rect) k_p_update_i8q<true><<<e->n_cus, 256, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts);
+    else if (g_px_variant == 3) k_p_update_i8q<false><<<e->n_cus, 256, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts);
 #endif
-    else if (rect) k_p_update_i8p<true><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
-    else k_p_update_i8p<false><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm);
+    else if (rect) k_p_update_i8p<true><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts);
+    else k_p_update_i8p<false><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts);
 #endif
     bool launched = true;
     {   // a launch that the runtime refuses (resources) would leave P silently un-downdated

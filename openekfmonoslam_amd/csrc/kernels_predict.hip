@@ -15,9 +15,11 @@ __device__ void predict_prepare_serial(double *st, double *sG);
 // the state, :251-252; dt = 1, :246).  One workgroup: thread 0 forms F, G and the predicted state (a chain of a few hundred dependent
 // fp64 operations); the 169 entries of G Q G' -- a thousand multiply-adds, half of the 9 us the kernel took as one thread -- are dealt
 // to the workgroup behind one barrier.
-__global__ void __launch_bounds__(256) k_predict_prepare(double *st, ParD par)
+// counts != nullptr (EKF::step's launch): a step enqueued behind a failed update leaves the filter as it is (engine.h: filter_frozen)
+__global__ void __launch_bounds__(256) k_predict_prepare(double *st, ParD par, const int *counts)
 {
     __shared__ double sG[13 * 6];
+    if (filter_frozen(counts)) return;
     const double dt = 1.0;
     const double ln = par.linearAccelSD * par.linearAccelSD * dt * dt;
     const double an = par.angularAccelSD * par.angularAccelSD * dt * dt;
@@ -176,7 +178,7 @@ __global__ void __launch_bounds__(256) k_predict_cov(T *P, int ld, int n, const 
 
 void launch_predict(EkfEngine *e)
 {
-    k_predict_prepare<<<1, 256, 0, e->stream>>>(e->d.state, e->par);
+    k_predict_prepare<<<1, 256, 0, e->stream>>>(e->d.state, e->par, nullptr);
     const int nb = 1 + (e->n > 13 ? (e->n - 13 + 255) / 256 : 0);
     if (e->f32)
         k_predict_cov<float><<<nb, 256, 0, e->stream>>>((float *)e->d.P, e->ldP, e->n, e->d.state, e->rm);
@@ -249,10 +251,13 @@ k_predict_features(const double *st, CamD cam, const double *feat_pos, const int
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_predict_cov_features(int nb_cov, T *P, int ld, int n, RowMap rm, const double *st, CamD cam, const double *feat_pos, const int *feat_type,
-                       int count, int *flag, int *vis, double *uv_tab, double *Hs_tab, double *Hf_tab, int *vis_full, int *list, int *out_count)
+                       int count, int *flag, int *vis, double *uv_tab, double *Hs_tab, double *Hf_tab, int *vis_full, int *list, int *out_count,
+                       const int *counts)
 {
-    if ((int)blockIdx.x < nb_cov) predict_cov_body<T>((int)blockIdx.x, P, ld, n, st, rm);
-    else predict_features_body<256>((int)blockIdx.x - nb_cov, st, cam, feat_pos, feat_type, nullptr, count, flag, vis, uv_tab, Hs_tab, Hf_tab,
+    if ((int)blockIdx.x < nb_cov) {
+        if (filter_frozen(counts)) return; // (the pixel predictions only fill tables: they may run)
+        predict_cov_body<T>((int)blockIdx.x, P, ld, n, st, rm);
+    } else predict_features_body<256>((int)blockIdx.x - nb_cov, st, cam, feat_pos, feat_type, nullptr, count, flag, vis, uv_tab, Hs_tab, Hf_tab,
                                     vis_full, list, out_count);
 }
 
@@ -264,13 +269,13 @@ bool launch_predict_with_features(EkfEngine *e, int count)
         launch_predict(e);
         return launch_predict_features(e, nullptr, count, false, true);
     }
-    k_predict_prepare<<<1, 256, 0, e->stream>>>(e->d.state, e->par);
+    k_predict_prepare<<<1, 256, 0, e->stream>>>(e->d.state, e->par, e->d.counts);
     const int nb_cov = 1 + (e->n > 13 ? (e->n - 13 + 255) / 256 : 0);
     const int nb_f = (count + 255) / 256;
     const bool one = count <= 256; // one workgroup of features: it compacts its own list
     int *list = one ? e->d.plist : nullptr, *cnt = one ? e->d.counts + CNT_NPRED : nullptr;
 #define PCF_ARGS e->ldP, e->n, e->rm, e->d.state, e->cam, e->d.feat_pos, e->d.feat_type, count, e->d.work_flag, e->d.pred_vis, e->d.pred_uv, e->d.Hs, \
-                 e->d.Hf, e->d.pred_vis_full, list, cnt
+                 e->d.Hf, e->d.pred_vis_full, list, cnt, e->d.counts
     if (e->f32) k_predict_cov_features<float><<<nb_cov + nb_f, 256, 0, e->stream>>>(nb_cov, (float *)e->d.P, PCF_ARGS);
     else k_predict_cov_features<double><<<nb_cov + nb_f, 256, 0, e->stream>>>(nb_cov, (double *)e->d.P, PCF_ARGS);
 #undef PCF_ARGS
@@ -337,7 +342,7 @@ template <typename T, typename TO>
 __global__ void __launch_bounds__(256)
 k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, const int *feat_covpos,
           const double *Hs_tab, const double *Hf_tab, TO *HP, double *S_tab, RowMap rm, double *HPc, unsigned *times_predicted,
-          const int *d_count, const int *flag, int n_items, int *list_out, int *count_out)
+          const int *d_count, const int *flag, int n_items, int *list_out, int *count_out, const int *counts)
 {
     const int tid = threadIdx.x;
     if (flag) {
@@ -372,7 +377,7 @@ k_hp_rows(const T *P, int ld, int n, const int *list, const int *feat_type, cons
     // a feature's 7 + d rows are 13 x n x w bytes, and one workgroup walking all of them was six dependent rounds -- the
     // outlier re-prediction, with fewer features than CUs, ran at a third of the bandwidth of the full pass)
     const bool first = blockIdx.y == 0;
-    if (times_predicted && tid == 0 && first) times_predicted[fi]++;
+    if (times_predicted && tid == 0 && first && !filter_frozen(counts)) times_predicted[fi]++;
     if (!owns_row(rm, pos)) return; // sharded: the owner of the feature's rows computes them, the exchange delivers them
     const T *Pf = P + (size_t)local_row(rm, pos) * ld;
     if (tid < 14) sH[tid] = Hs_tab[14 * fi + tid];
@@ -482,15 +487,15 @@ void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_pred
     if (e->exact && e->f32)
         k_hp_rows<float, double><<<dim3(gx, chunks_f), 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
                                                         e->d.feat_covpos, e->d.Hs, e->d.Hf, (double *)e->d.HP,
-                                                        e->d.pred_S, e->rm, e->d.HPc, tp, d_count, flag, n_list, lo, co);
+                                                        e->d.pred_S, e->rm, e->d.HPc, tp, d_count, flag, n_list, lo, co, e->d.counts);
     else if (e->f32)
         k_hp_rows<float, float><<<dim3(gx, chunks_f), 256, 0, e->stream>>>((const float *)e->d.P, e->ldP, e->n, d_list, e->d.feat_type,
                                                         e->d.feat_covpos, e->d.Hs, e->d.Hf, (float *)e->d.HP,
-                                                        e->d.pred_S, e->rm, e->d.HPc, tp, d_count, flag, n_list, lo, co);
+                                                        e->d.pred_S, e->rm, e->d.HPc, tp, d_count, flag, n_list, lo, co, e->d.counts);
     else
         k_hp_rows<double, double><<<dim3(gx, chunks_d), 256, 0, e->stream>>>((const double *)e->d.P, e->ldP, e->n, d_list,
                                                          e->d.feat_type, e->d.feat_covpos, e->d.Hs, e->d.Hf,
-                                                         (double *)e->d.HP, e->d.pred_S, e->rm, e->d.HPc, tp, d_count, flag, n_list, lo, co);
+                                                         (double *)e->d.HP, e->d.pred_S, e->rm, e->d.HPc, tp, d_count, flag, n_list, lo, co, e->d.counts);
 }
 
 // predictMeasurementState on the current state into an EkfPrediction array (device), all features.

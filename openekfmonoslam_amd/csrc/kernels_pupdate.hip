@@ -41,8 +41,9 @@ namespace ekf {
 // Swapping the operands of an MFMA product changes no bit, so P[i][j] here equals P[j][i] on the rank that owns j.
 template <typename T, bool AVG, bool RECT>
 __global__ void __launch_bounds__(256, sizeof(T) == 4 ? PU_MIN_WAVES : 3)
-k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, const int4 *units, RowMap rm, int stagger)
+k_p_update(T *P, int ldp, int n, const T *B, int ldb, int m_pad, int per_xcd, const int4 *units, RowMap rm, int stagger, const int *counts)
 {
+    if (filter_frozen(counts)) return; // the update's sweep failed: P stays as it was (engine.h)
     using M = Mma<T>;
     constexpr int MB = M::MB, TM = 4 * MB, KI = 64 / MB, VEC = M::VEC;
     constexpr int LOADS = PU_BK * TM / (256 * VEC);
@@ -620,6 +621,7 @@ static void launch_p_update_t(EkfEngine *e, int m_pad, int grid, const int4 *tm,
     T *P = (T *)e->d.P;
     const T *B = (const T *)e->d.A;
     const int stagger = g_pu_stagger_override >= 0 ? g_pu_stagger_override : ((m_pad < 512 && grid >= 768) ? 80 : 0);
+    const int *frz = sizeof(T) == 8 ? e->d.counts : nullptr; // fp64 configuration: a failed sweep leaves P alone (engine.h: filter_frozen)
     if constexpr (sizeof(T) == 4 && PU_F32_PAIRS) {
         if (rect) k_p_update_f32<false, true><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger);
         else if (avg) k_p_update_f32<true, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger);
@@ -627,11 +629,11 @@ static void launch_p_update_t(EkfEngine *e, int m_pad, int grid, const int4 *tm,
         return;
     }
     if (rect)
-        k_p_update<T, false, true><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger);
+        k_p_update<T, false, true><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger, frz);
     else if (avg)
-        k_p_update<T, true, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger);
+        k_p_update<T, true, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger, frz);
     else
-        k_p_update<T, false, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger);
+        k_p_update<T, false, false><<<grid, 256, 0, s>>>(P, e->ldP, e->n, B, e->ldP, m_pad, e->pu_per_xcd, tm, e->rm, stagger, frz);
 }
 
 void launch_p_update(EkfEngine *e, int m_pad, int m)

@@ -1127,8 +1127,9 @@ __device__ inline void quat_norm_dev(double *st)
 // the un-normalised q (:168).
 __global__ void __launch_bounds__(256)
 k_state_apply(double *st, double *feat_pos, const int *feat_type, const int *feat_covpos, int N, const double *part,
-              int ldpart, int normalise)
+              int ldpart, int normalise, const int *counts)
 {
+    if (filter_frozen(counts)) return; // the update's sweep failed: x stays as it was (engine.h)
     const int t = blockIdx.x * 256 + threadIdx.x;
     // this thread's feature parameter: the k-splits are requested together, before the camera part below
     const bool live = t < N * 6 && (t % 6) < feat_dim(feat_type[t / 6]);
@@ -1168,11 +1169,12 @@ k_state_apply(double *st, double *feat_pos, const int *feat_type, const int *fea
 // normalizeCovariance (Update.cpp:64-85): P <- D P D', D = diag(I3, J, I).  Five disjoint blocks; block 0 owns
 // the 7x7 corner pieces, every other thread owns column j of the row strip 3..6 and row j of the column strip.
 template <typename T>
-__global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, const double *st, RowMap rm)
+__global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, const double *st, RowMap rm, const int *counts)
 {
     __shared__ double J[16];
     __shared__ double C[7][7];
     const int tid = threadIdx.x;
+    if (filter_frozen(counts)) return;
     if (tid < 16) J[tid] = st[ST_JN + tid];
     if (blockIdx.x == 0) {
         if (tid < 49) C[tid / 7][tid % 7] = (double)P[(size_t)(tid / 7) * ld + tid % 7];
@@ -1235,12 +1237,13 @@ __global__ void __launch_bounds__(256) k_normalize_cov(T *P, int ld, int n, cons
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_apply_normalize(T *P, int ld, int n, double *st, RowMap rm, double *feat_pos, const int *feat_type, const int *feat_covpos, int N,
-                  const double *part, int ldpart)
+                  const double *part, int ldpart, const int *counts)
 {
     __shared__ double J[16];
     __shared__ double C[7][7];
     __shared__ double cam[13];
     const int tid = threadIdx.x;
+    if (filter_frozen(counts)) return; // the update's sweep failed: x and P stay as they were (engine.h)
     const int t = blockIdx.x * 256 + tid;
     const bool live = t < N * 6 && (t % 6) < feat_dim(feat_type[t / 6]);
     const int jf = live ? feat_covpos[t / 6] + t % 6 : 0;
@@ -1424,12 +1427,42 @@ k_fix_normalize(T *P, int ld, int n, RowMap rm, const double *dsave, const doubl
 void launch_p_update(EkfEngine *e, int m_pad, int m);
 
 // ---------------------------------------------------------------------------------------------- persistent sweep launcher
-// Two persistent launches that are each only partly resident would wait for each other's workgroups until the watchdog ends
-// them: sweeps of different engines of this process on one device are chained by an event (the second waits for the first).
-static std::mutex g_ps_mu;
-static hipEvent_t g_ps_last[16] = {};
-static const EkfEngine *g_ps_owner[16] = {};
-std::atomic<int> g_engines_alive{0}; // engines of this process (engine.cpp counts them)
+// The registry of persistent sweeps of one device (engine.h: SweepRegistry).  The table below only FINDS the registry of a device;
+// the registry itself belongs to the engines attached to it (shared_ptr) and goes with the last of them.
+std::shared_ptr<SweepRegistry> sweep_registry_attach(int device)
+{
+    static std::mutex table_mu;
+    static std::map<int, std::weak_ptr<SweepRegistry>> table;
+    std::shared_ptr<SweepRegistry> reg;
+    {
+        std::lock_guard<std::mutex> lk(table_mu);
+        reg = table[device].lock();
+        if (!reg) {
+            reg = std::make_shared<SweepRegistry>();
+            reg->device = device;
+            table[device] = reg;
+        }
+    }
+    bool others;
+    {
+        std::lock_guard<std::mutex> lk(reg->mu);
+        others = reg->members > 0;
+        ++reg->members;
+    }
+    // a member that launched while it was alone recorded nothing: drain the device once, AFTER the count went up under the lock --
+    // every persistent launch is made under the same lock, so it either saw the new count (and records from now on) or was enqueued
+    // before this point (and is drained here)
+    if (others) (void)hipDeviceSynchronize();
+    return reg;
+}
+
+void sweep_registry_detach(const std::shared_ptr<SweepRegistry> &reg, const void *engine)
+{
+    if (!reg) return;
+    std::lock_guard<std::mutex> lk(reg->mu);
+    --reg->members;
+    if (reg->owner == engine) reg->owner = nullptr; // (the event stays: it marks work of a stream that is drained before it is destroyed)
+}
 
 #ifdef EKF_SWEEP_TRACE // debug builds only (scripts/persist_trace.py): the stamps of the LAST persistent sweep launched while enabled
 constexpr int PS_TRACE_WORDS = 4096;
@@ -1460,9 +1493,13 @@ static int persist_capacity(EkfEngine *e)
     return cap;
 }
 
-// one launch for the whole sweep of an update of m rows; false: not launched (the caller runs the launch-per-panel sweep)
+// grid layout of the persistent sweep of an update of m rows with n_bcols 32-column blocks of B; false: it does not fit the device
+// (decided BEFORE the gather / assembly launch, which skips the first block's factorisation for a persistent sweep)
+struct PsLayout {
+    int nbk, n_b, n_t, grid, layout_cus;
+};
 template <bool PL>
-static bool launch_persistent_sweep(EkfEngine *e, int m, const double *G, double *Bout, int n_bcols, const BPlanes &bp)
+static bool persist_layout(EkfEngine *e, int m, int n_bcols, PsLayout &L)
 {
     const int cap = persist_capacity<PL>(e);
     const int nbk = (m + NB - 1) / NB;
@@ -1482,22 +1519,30 @@ static bool launch_persistent_sweep(EkfEngine *e, int m, const double *G, double
     n_t = std::max(n_t, (ntiles + 63) / 64);
     if (1 + n_b + n_t + 1 > cap) return false;
     const bool spacer = 1 + n_b + n_t > C;
-    const int grid = 1 + n_b + n_t + (spacer ? 1 : 0);
-    const int layout_cus = spacer ? C : 0;
+    L.nbk = nbk;
+    L.n_b = n_b;
+    L.n_t = n_t;
+    L.grid = 1 + n_b + n_t + (spacer ? 1 : 0);
+    L.layout_cus = spacer ? C : 0;
+    return true;
+}
+
+// one launch for the whole sweep of an update of m rows (layout from persist_layout); false: not launched
+template <bool PL>
+static bool launch_persistent_sweep(EkfEngine *e, int m, const double *G, double *Bout, int n_bcols, const BPlanes &bp, const PsLayout &L)
+{
     if (e->ps_epoch >= (1u << 22) || e->ps_epoch == 0) { // (re)start the epochs of the flags well before they can wrap
         if (hipMemsetAsync(e->d.sweep_ctl, 0, sweep_ctl_bytes(), e->stream) != hipSuccess) return false;
         e->ps_epoch = 0;
-        e->ps_arrive = 0;
     }
     ++e->ps_epoch;
     PsArgs a{};
-    a.S = e->d.S; a.LL = e->d.LL; a.ldS = e->ldS; a.m = m; a.nbk = nbk;
+    a.S = e->d.S; a.LL = e->d.LL; a.ldS = e->ldS; a.m = m; a.nbk = L.nbk;
     a.V = e->d.Dinv; a.ldw = e->ldW; a.nu = e->d.nu; a.zvec = e->d.zvec; a.counts = e->d.counts;
     a.G = G; a.Bout = Bout; a.ld = e->ldP; a.bp = bp;
-    a.ctl = (SweepCtl *)e->d.sweep_ctl; a.eb = e->ps_epoch * PS_EPOCH_STEP; a.arrive_base = e->ps_arrive;
-    a.n_b = n_b; a.n_bcols = n_bcols; a.n_t = n_t; a.n_cus = layout_cus;
-    a.fault = e->ps_fault;
-    e->ps_fault = 0; // one sweep only
+    a.ctl = (SweepCtl *)e->d.sweep_ctl; a.eb = e->ps_epoch * PS_EPOCH_STEP;
+    a.n_b = L.n_b; a.n_bcols = n_bcols; a.n_t = L.n_t; a.n_cus = L.layout_cus;
+    a.fault = (e->ps_fault > 0 && --e->ps_fault == 0) ? 1 : 0; // include/ekf_test_hooks.h: one sweep only
     a.trace = nullptr;
 #ifdef EKF_SWEEP_TRACE
     if (g_ps_trace_on) {
@@ -1509,18 +1554,21 @@ static bool launch_persistent_sweep(EkfEngine *e, int m, const double *G, double
         }
     }
 #endif
-    e->ps_arrive += (unsigned)(1 + n_b + n_t);
-    const int dev = e->device >= 0 && e->device < 16 ? e->device : 0;
-    if (g_engines_alive.load() > 1) {
-        // more than one engine in this process: order this sweep behind the last persistent sweep of any other engine on the device
-        std::lock_guard<std::mutex> lk(g_ps_mu);
-        if (!g_ps_last[dev] && hipEventCreateWithFlags(&g_ps_last[dev], hipEventDisableTiming) != hipSuccess) g_ps_last[dev] = nullptr;
-        if (g_ps_last[dev] && g_ps_owner[dev] && g_ps_owner[dev] != e) (void)hipStreamWaitEvent(e->stream, g_ps_last[dev], 0);
-        k_chol_persist<PL><<<grid, 256, 0, e->stream>>>(a);
-        if (g_ps_last[dev]) (void)hipEventRecord(g_ps_last[dev], e->stream);
-        g_ps_owner[dev] = e;
-    } else {
-        k_chol_persist<PL><<<grid, 256, 0, e->stream>>>(a);
+    SweepRegistry *reg = e->ps_reg.get();
+    if (!reg) {
+        k_chol_persist<PL><<<L.grid, 256, 0, e->stream>>>(a);
+        return true;
+    }
+    // every persistent launch goes through the registry's lock; with other engines on the device it waits for the last persistent
+    // sweep of any OTHER engine and leaves its own end behind as the event the next one waits for
+    std::lock_guard<std::mutex> lk(reg->mu);
+    const bool shared = reg->members > 1;
+    if (shared && !reg->last && hipEventCreateWithFlags(&reg->last, hipEventDisableTiming) != hipSuccess) reg->last = nullptr;
+    if (shared && reg->last && reg->owner && reg->owner != e) (void)hipStreamWaitEvent(e->stream, reg->last, 0);
+    k_chol_persist<PL><<<L.grid, 256, 0, e->stream>>>(a);
+    if (shared && reg->last) {
+        (void)hipEventRecord(reg->last, e->stream);
+        reg->owner = e;
     }
     return true;
 }
@@ -1534,6 +1582,9 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     const int m = 2 * M, n = e->n, ld = e->ldP, ldS = e->ldS, ldw = e->ldW;
     const int m_pad = round_up(m, NB);
     const int n_pad = round_up(n, LD_ALIGN);
+    // the kernels behind the sweep that write x or P leave them alone when the sweep failed (filter_frozen, engine.h); the fast fp32
+    // configuration keeps its round-3 tail (its sweep is never the persistent launch: nothing to retry)
+    const int *frz = (sizeof(T) == 4 && !EXACT) ? nullptr : e->d.counts;
     TB *G = (TB *)e->d.G; // gathered rows of H P (or the H P table itself, see planes_b)
     TB *A = (TB *)e->d.A; // B = inv(L) G
     // B = inv(L) G: up to B_SWEEP_MAX rows, row block k is formed inside the launch of panel k (forward substitution
@@ -1596,14 +1647,24 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     }
     // ONE persistent launch for the whole sweep (chol_persist.h) where it applies: B inside the sweep, at most B_SWEEP_MAX rows, one
     // GPU, fp64 arithmetic of B (the fp64 and the exact configuration); otherwise the launch-per-panel sweep below
-    const int lmode = (e->sweep_mode == EKF_SWEEP_PERSISTENT || e->sweep_mode == EKF_SWEEP_LAUNCHES) ? EKF_SWEEP_AUTO : e->sweep_mode;
-    bool persist = (e->sweep_mode == EKF_SWEEP_AUTO || e->sweep_mode == EKF_SWEEP_PERSISTENT) && b_in_sweep && m_pad <= B_SWEEP_MAX &&
+    const int sweep_mode = e->force_launches > 0 ? EKF_SWEEP_LAUNCHES : e->sweep_mode; // (the retry of a timed-out persistent sweep)
+    const int lmode = (sweep_mode == EKF_SWEEP_PERSISTENT || sweep_mode == EKF_SWEEP_LAUNCHES) ? EKF_SWEEP_AUTO : sweep_mode;
+    bool persist = (sweep_mode == EKF_SWEEP_AUTO || sweep_mode == EKF_SWEEP_PERSISTENT) && b_in_sweep && m_pad <= B_SWEEP_MAX &&
                    !sharded && sizeof(TB) == 8 && e->d.sweep_ctl != nullptr;
-    if (persist && (planes_b ? persist_capacity<true>(e) : persist_capacity<false>(e)) < 64) persist = false;
     // by size: one B worker per block of 32 columns is what the persistent sweep is laid out for; on wider maps (from 8192 state columns
     // on, where the launch-per-panel sweep switches to two panels per launch) its B workers take several blocks each and it loses:
     // N = 2000, 20.4 against 14.0 us per panel (profiles/r05_bench_n2000_f32x_persistent.json)
-    if (persist && e->sweep_mode == EKF_SWEEP_AUTO && n_pad >= 8192) persist = false;
+    if (persist && sweep_mode == EKF_SWEEP_AUTO && n_pad >= 8192) persist = false;
+    // its grid must fit the device's resident workgroups -- decided HERE, before the gather / assembly launch leaves the first
+    // block's factorisation to the chain workgroup (a device partition with few CUs: the launch-per-panel sweep instead)
+    PsLayout ps_layout{};
+    if constexpr (sizeof(TB) == 8) {
+        if (persist) persist = planes_b ? persist_layout<true>(e, m, cb1 - cb0, ps_layout) : persist_layout<false>(e, m, n_pad / NB, ps_layout);
+    } else persist = false;
+    e->last_update_M = M; // what a retry needs (engine.cpp: recover_failed_update)
+    e->last_update_cov = update_cov;
+    e->last_update_sym = e->p_exact_sym;
+    e->last_update_persist = persist;
     double *V = e->d.Dinv, *W = b_in_sweep ? nullptr : e->d.W; // W = inv(L)' (and L row-major in LL): the GEMM path's
     float *Wf = sizeof(TB) == 4 && !b_in_sweep ? e->d.Wf : nullptr;
     bool merged_ga = false;
@@ -1686,10 +1747,10 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     if (persist) {
         bool launched = false;
         if constexpr (sizeof(TB) == 8) {
-            if (planes_b) launched = launch_persistent_sweep<true>(e, m, (const double *)G, nullptr, cb1 - cb0, bp);
-            else launched = launch_persistent_sweep<false>(e, m, (const double *)G, (double *)A, n_pad / NB, BPlanes{});
+            if (planes_b) launched = launch_persistent_sweep<true>(e, m, (const double *)G, nullptr, cb1 - cb0, bp, ps_layout);
+            else launched = launch_persistent_sweep<false>(e, m, (const double *)G, (double *)A, n_pad / NB, BPlanes{}, ps_layout);
         }
-        if (!launched) { // cannot happen after the capacity check above; the first block still wants its factorisation
+        if (!launched) { // (only a failed memset of the flag block is left: the layout was checked before the gather)
             e->err = "persistent sweep could not be launched";
             e->hook_rc = EKF_ERR_HIP;
             return;
@@ -1821,13 +1882,13 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const int nt = max(e->N * 6, 1);
         if (!merged_tail)
             k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
-                                                           e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
+                                                           e->N, e->d.dx_part, ld, update_cov ? 1 : 0, frz);
     } else if (gemm_planes || planes_b) { // B exists as digit planes only
         launch_dx_planes(e, round_up(m, 32));
         const int nt = max(e->N * 6, 1);
         if (!merged_tail)
             k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
-                                                           e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
+                                                           e->N, e->d.dx_part, ld, update_cov ? 1 : 0, frz);
     } else {
         dim3 grid((n + 255) / 256, DX_SPLIT);
         const bool fix = update_cov && sizeof(T) == 4 && !EXACT; // (the exact downdate needs no fp64 repair of the diagonal / camera rows)
@@ -1851,7 +1912,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         const int nt = max(e->N * 6, 1);
         if (!merged_tail)
             k_state_apply<<<(nt + 255) / 256, 256, 0, s>>>(e->d.state, e->d.feat_pos, e->d.feat_type, e->d.feat_covpos,
-                                                           e->N, e->d.dx_part, ld, update_cov ? 1 : 0);
+                                                           e->N, e->d.dx_part, ld, update_cov ? 1 : 0, frz);
     }
     if (!update_cov) return;
     const bool fix_diag = sizeof(T) == 4 && !EXACT;
@@ -1866,10 +1927,10 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     if (merged_tail) {
         const int nt = max(e->N * 6, 1);
         k_apply_normalize<T><<<max(nb, (nt + 255) / 256), 256, 0, s>>>((T *)e->d.P, ld, n, e->d.state, e->rm, e->d.feat_pos, e->d.feat_type,
-                                                                       e->d.feat_covpos, e->N, e->d.dx_part, ld);
+                                                                       e->d.feat_covpos, e->N, e->d.dx_part, ld, frz);
         return;
     }
-    k_normalize_cov<T><<<nb, 256, 0, s>>>((T *)e->d.P, ld, n, e->d.state, e->rm);
+    k_normalize_cov<T><<<nb, 256, 0, s>>>((T *)e->d.P, ld, n, e->d.state, e->rm, frz);
 }
 
 void launch_update(EkfEngine *e, int M, bool update_cov)

@@ -55,7 +55,7 @@ class EkfStepInfo(C.Structure):
         ("n_outliers", C.c_int32),
         ("n_rescued", C.c_int32),
         ("status", C.c_int32),
-        ("_pad", C.c_int32),
+        ("n_sweep_retries", C.c_int32),
     ]
 
 

@@ -105,7 +105,7 @@ ABI = {
                               C.POINTER(C.c_double)]),
     "ekf_timing_sweep_launches": (_i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ekf_round_covariance_to_f32": (_i, [_vp]),
-    "ekf_debug_stall_next_sweep": (_i, [_vp]),
+    "ekf_get_sweep_retries": (_i, [_vp]),
     "ekf_shard_rows": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "ekf_engine_create_sharded": (_i, [C.POINTER(EkfEngineConfig), _i, _i, C.POINTER(_vp)]),
     "ekf_set_exchange": (_i, [_vp, _vp, _vp]),
@@ -114,6 +114,12 @@ ABI = {
     "ekf_shard_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "ekf_shard_counters": (_i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ekf_device_copy": (_i, [_vp, _vp, _vp, C.c_size_t]),
+}
+
+# include/ekf_test_hooks.h: fault injection for the tests, not part of the boundary
+TEST_HOOKS = {
+    "ekf_debug_stall_next_sweep": (_i, [_vp]),
+    "ekf_debug_stall_sweep_after": (_i, [_vp, _i]),
 }
 
 # int fn(void *user, int what, void *device_base, size_t row_bytes, const int32_t *row_begin, int world, int rank)
@@ -139,7 +145,7 @@ def load_library():
         pass
     override = os.environ.get("EKF_ENGINE_LIB")  # A/B timing of another build of the engine (scripts/build_variant.sh)
     L = C.CDLL(os.path.abspath(override) if override else LIB_PATH)
-    for name, (rt, at) in ABI.items():
+    for name, (rt, at) in list(ABI.items()) + list(TEST_HOOKS.items()):
         if override and not hasattr(L, name):
             continue
         fn = getattr(L, name)
@@ -301,6 +307,15 @@ class EkfEngine:
         """no read-back at the end of step(): a failed second update is reported by the next step instead"""
         if hasattr(self.L, "ekf_set_async_errors"):
             self._chk(self.L.ekf_set_async_errors(self.h, 1 if on else 0))
+
+    @property
+    def sweep_retries(self):
+        """updates re-run on the launch-per-panel sweep because their persistent sweep timed out (ekf_get_sweep_retries)"""
+        return int(self.L.ekf_get_sweep_retries(self.h))
+
+    def stall_sweep(self, skip=0):
+        """test hook (include/ekf_test_hooks.h): the persistent sweep after the next `skip` ones runs without its chain workgroup"""
+        self._chk(self.L.ekf_debug_stall_sweep_after(self.h, int(skip)))
 
     def set_update_path(self, path):
         """0: by size, 1: B = inv(L) H P inside the Cholesky sweep, 2: explicit inverse + GEMM (ekf_engine.h)"""

@@ -25,7 +25,12 @@ def test_library_exports_every_declared_symbol(lib):
     declared = set(re.findall(r"\b(ekf_[a-z_0-9]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     assert declared == set(engine.ABI), (declared ^ set(engine.ABI))
-    for name in declared:
+    # the fault-injection hooks of the test suite live in their own header, outside the drop-in boundary
+    hooks = open(os.path.join(ROOT, "include", "ekf_test_hooks.h")).read()
+    declared_hooks = set(re.findall(r"\b(ekf_[a-z_0-9]+)\s*\(", hooks))
+    assert declared_hooks == set(engine.TEST_HOOKS), (declared_hooks ^ set(engine.TEST_HOOKS))
+    assert not (declared_hooks & declared)
+    for name in declared | declared_hooks:
         assert hasattr(lib, name), name
     assert lib.ekf_abi_version() == 1
 

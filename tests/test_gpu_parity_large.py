@@ -154,7 +154,8 @@ def test_n5000_fp32_against_committed_summary(eng_mod, precision):
     assert p13_own <= 1e-4, p13_own
 
 
-@pytest.mark.parametrize("precision,expect,tol", [(AUTO, 0, 1e-9), (3, 3, None)], ids=["auto", "fp64_stored_exact"])
+@pytest.mark.parametrize("precision,expect,tol", [(AUTO, 0, 1e-9), (3, 3, None), (EXACT, EXACT, "survey")],
+                         ids=["auto", "fp64_stored_exact", "fp32_stored_exact"])
 def test_n5000_three_frames_against_committed_summary(eng_mod, precision, expect, tol):
     """configs[4] map size over THREE frames: after every frame the engine's decisions, state blocks, EVERY feature parameter, camera
     block, diagonal, trace, Frobenius norm and a 64 x 64 sample of P against the per-frame oracle summaries of
@@ -163,7 +164,12 @@ def test_n5000_three_frames_against_committed_summary(eng_mod, precision, expect
     1e-12).  The exact int8 update on an fp64-stored covariance (EKF_PRECISION_F64_EXACT, 2.4 x faster) holds every BLOCK at 1e-5 on
     all three frames and every feature parameter on the first two (2.8e-6); on the third one far feature's inverse depth is 2.5e-5 ...
     3.4e-5 of its own value off (fp32 storage, EKF_PRECISION_F32_EXACT: 3.6e-4, round 4) -- asserted block-wise, the component-wise
-    figure of frame 3 held to 1e-4 as a regression guard: it is why AUTO does not select it above 2048 features."""
+    figure of frame 3 held to 1e-4 as a regression guard: it is why AUTO does not select it above 2048 features.
+    fp32_stored_exact -- configs[4] says "fp32": EKF_PRECISION_F32_EXACT over the same three frames (what `bench.py --gpus 8` runs per
+    rank) under the gates SURVEY 8(d) states for every reported number: identical decisions on every frame, every state BLOCK within
+    1e-5, P within 1e-5 in max-norm (camera block, diagonal, 64 x 64 sample) and in Frobenius norm.  Its component-wise figure (one far
+    feature's inverse depth against its own value: 1.7e-5 / 1.4e-4 on frames 2 / 3, round 4) is printed, and held to 1e-3 as a
+    regression guard only -- the configuration that holds 1e-5 component-wise at this size is AUTO."""
     path = os.path.join(GOLDEN, "oracle_n5000_f3_summary.npz")
     if not os.path.exists(path):
         pytest.skip("summary fixture not minted")
@@ -181,7 +187,7 @@ def test_n5000_three_frames_against_committed_summary(eng_mod, precision, expect
     for t in range(F):
         i = e.step(*seq.frames[t])
         assert [i.n_predicted, i.n_matches, i.n_hypotheses, i.n_inliers, i.n_outliers, i.n_rescued, i.status] == list(z["info"][t]), t
-        if tol is not None and t < F - 1:
+        if tol == 1e-9 and t < F - 1:
             continue  # (the all-fp64 engine: the last frame tells; every get_state moves 7 GB)
         x, fp, P = e.get_state()
         be = block_errs(x, fp, z[f"x13_t{t}"], z[f"feature_pos_t{t}"])
@@ -198,7 +204,11 @@ def test_n5000_three_frames_against_committed_summary(eng_mod, precision, expect
         reports.append((t, be, p13_own))
     e.close()
     for t, be, p13_own in reports:
-        if tol is not None:
+        if tol == "survey":
+            bad = {k: v for k, v in be.items() if k != "features_componentwise" and not v <= F32_TOL}
+            if not be["features_componentwise"] <= 1e-3:
+                bad["features_componentwise"] = be["features_componentwise"]
+        elif tol is not None:
             bad = {k: v for k, v in be.items() if not v <= tol}
         else:
             bad = {k: v for k, v in be.items() if k != "features_componentwise" and not v <= F32_TOL}

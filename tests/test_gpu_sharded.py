@@ -33,8 +33,11 @@ def _run_group(seq, world, precision, frames, transport="hip"):
 
 
 @pytest.mark.parametrize("nfeat,world,precision", [(50, 2, 0), (50, 3, 0), (23, 4, 0), (200, 2, 1), (200, 3, 1), (200, 2, 2), (200, 3, 2),
-                                                   (420, 4, 2)])
+                                                   (420, 4, 2), (200, 2, 3), (420, 4, 3), (1100, 3, 4)])
 def test_sharded_steps_match_unsharded(eng_mod, oracle_lib, nfeat, world, precision):
+    """precision 3 (EKF_PRECISION_F64_EXACT) and 4 (AUTO: resolves to 3 between 1025 and 2048 features) on a sharded engine
+    (ADVICE r5): the rectangular fp64 epilogue of the exact downdate (k_p_update_i8p<true, double>), k_diag_extract<double> and
+    k_g_cols<double> on fp64-stored row shards."""
     frames = 3
     seq = SyntheticSequence(nfeat, frames)
     grp, infos = _run_group(seq, world, precision, frames)
@@ -52,6 +55,7 @@ def test_sharded_steps_match_unsharded(eng_mod, oracle_lib, nfeat, world, precis
     # one from G formed by symmetry out of its own rows of P (k_g_cols) where the unsharded one reads the cached H P rows -- two
     # roundings of the same fp32-stored filter, ~1e-6 apart component-wise after three frames (measured); held to the north-star 1e-5
     tol = 1e-12 if precision == 0 else (1e-6 if precision == 1 else 1e-5)
+    assert ref.precision == (3 if precision == 4 else precision)
     assert state_err(x, fp, xr, fpr) <= tol
     assert rel_max(P, Pr) <= tol
     # replicated pieces are bitwise identical on every rank
