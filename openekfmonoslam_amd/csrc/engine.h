@@ -142,6 +142,7 @@ struct DeviceArrays {
     uint8_t *mask = nullptr;   // generic byte mask output (rescue)
     void *pu_tilemap = nullptr; // int2 (ti, tj) per upper-triangle tile, XCD-friendly order
     void *sweep_ctl = nullptr;  // flags of the persistent Cholesky sweep (chol_persist.h), zeroed once
+    unsigned *pu_ctr = nullptr; // exact downdate, two workgroups per CU (k_p_update_i8d): unit counters, two sets of eight (one per XCD list)
     int8_t *Bq = nullptr;       // EKF_PRECISION_F32_EXACT: PX_S digit planes of B, each [bq_rows / 16][ldP][16] bytes (kernels_pexact.hip)
     int *Bexp = nullptr;        // its column scales (biased exponents), ldP ints
     int8_t *Lq = nullptr;       // digit planes of L for the rows of B formed from planes (chol_bplanes.h): PX_S x lq_nbk^2 KB
@@ -256,6 +257,7 @@ struct EkfEngine {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> px_events; // exact configuration: end of the sweep -> start of the downdate (inverse, GEMM, digit planes, dx, state)
     hipEvent_t px_mid = nullptr;                               // recorded after the sweep's last launch (timing only)
     int pu_slots = 0;         // resident workgroups of the downdate kernel on this device (0: not asked yet, -1: unknown)
+    int pu_parity = 0;        // k_p_update_i8d: the counter set the next launch uses (it zeroes the other one)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // image-only work of the next frame, overlapped with the update
     hipEvent_t ev_main = nullptr, ev_prefetch = nullptr;

@@ -373,6 +373,12 @@ k_p_update_i8(float *P, int ldp, int n, const int8_t *Bq, int ldq, size_t plane_
 // supposed to travel during the step were drained before its first product -- and (b) their waits are written here: LDS
 // operations complete in order, so "at most k newer reads outstanding" is exact.  The waits name the registers they
 // release ("+v"), which keeps every product behind its wait.
+#ifndef PX_ZERO_C
+#define PX_ZERO_C 1 // k_p_update_i8p: start a unit's accumulators with C = 0 in the first step's products instead of zeroing 160 registers
+#endif
+#ifndef PX_PRIO
+#define PX_PRIO 0   // k_p_update_i8p: raised wave priority around the products of a step (measured)
+#endif
 #ifndef PX_ABL
 #define PX_ABL 0 // timing ablations of scripts/micro/pu_i8_bench.hip only (WRONG results): 1 no epilogue, 2 no slab loads in the loop,
                  // 4 no barrier, 8 no operand reads
@@ -382,21 +388,24 @@ k_p_update_i8(float *P, int ldp, int n, const int8_t *Bq, int ldq, size_t plane_
         if (PX_ABL & 8) asm volatile("" : "=v"(dst));                                                                         \
         else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));                                 \
     } while (0)
-template <bool FULL>
+// PSTR: bytes per plane of a slab in LDS; BOFF: offset of the J side inside a plane's block; FIRST: the unit's first step -- every
+// accumulator's first product takes the constant 0 as its C operand instead of a register that would have to be zeroed first (160
+// moves per unit and wavefront)
+template <bool FULL, int PSTR = 8192, int BOFF = 4096, bool FIRST = false>
 __device__ __forceinline__ void px_step_ring(unsigned ldsA, unsigned ldsB, v16i (&acc)[2][PX_S])
 {
     v4i b0, b1, b2, b3, b4, a[2][2];
-    PX_DS_READ(b0, ldsB, 4096);
-    PX_DS_READ(b1, ldsB, 4096 + 8192);
-    PX_DS_READ(b2, ldsB, 4096 + 2 * 8192);
-    PX_DS_READ(b3, ldsB, 4096 + 3 * 8192);
-    PX_DS_READ(b4, ldsB, 4096 + 4 * 8192);
+    PX_DS_READ(b0, ldsB, BOFF);
+    PX_DS_READ(b1, ldsB, BOFF + PSTR);
+    PX_DS_READ(b2, ldsB, BOFF + 2 * PSTR);
+    PX_DS_READ(b3, ldsB, BOFF + 3 * PSTR);
+    PX_DS_READ(b4, ldsB, BOFF + 4 * PSTR);
     PX_DS_READ(a[0][0], ldsA, 0);
     if (FULL) PX_DS_READ(a[0][1], ldsA, 512);
 #define PX_GROUP(s_, cur, nxt)                                                                                                \
     if (s_ + 1 < PX_S) {                                                                                                      \
-        PX_DS_READ(a[nxt][0], ldsA, (s_ + 1) * 8192);                                                                         \
-        if (FULL) PX_DS_READ(a[nxt][1], ldsA, (s_ + 1) * 8192 + 512);                                                         \
+        PX_DS_READ(a[nxt][0], ldsA, (s_ + 1) * PSTR);                                                                         \
+        if (FULL) PX_DS_READ(a[nxt][1], ldsA, (s_ + 1) * PSTR + 512);                                                         \
     }                                                                                                                         \
     if (s_ == 0) {                                                                                                            \
         if (FULL) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(a[0][0]), "+v"(a[0][1])); \
@@ -411,8 +420,14 @@ __device__ __forceinline__ void px_step_ring(unsigned ldsA, unsigned ldsB, v16i 
     {                                                                                                                         \
         const v4i bb[PX_S] = {b0, b1, b2, b3, b4};                                                                            \
         _Pragma("unroll") for (int t = 0; t < PX_S - s_; ++t) {                                                               \
-            acc[0][s_ + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[cur][0], bb[t], acc[0][s_ + t], 0, 0, 0);                \
-            if (FULL) acc[1][s_ + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[cur][1], bb[t], acc[1][s_ + t], 0, 0, 0);      \
+            if (FIRST && s_ == 0) { /* level t's first product of the unit */                                                 \
+                const v16i zc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                             \
+                acc[0][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[cur][0], bb[t], zc, 0, 0, 0);                             \
+                if (FULL) acc[1][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[cur][1], bb[t], zc, 0, 0, 0);                   \
+            } else {                                                                                                          \
+                acc[0][s_ + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[cur][0], bb[t], acc[0][s_ + t], 0, 0, 0);            \
+                if (FULL) acc[1][s_ + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[cur][1], bb[t], acc[1][s_ + t], 0, 0, 0);  \
+            }                                                                                                                 \
         }                                                                                                                     \
     }
     PX_GROUP(0, 0, 1)
@@ -533,14 +548,16 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
             sExp[ui & 1][tid] = c < n ? bexp[c] - 1022 : 0;
         }
         v16i acc[2][PX_S];
+#if !PX_ZERO_C // (PX_ZERO_C: the unit's first step starts the accumulators with the constant 0 as C: no 160 moves per unit and wavefront)
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int L = 0; L < PX_S; ++L)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[x][L][r] = 0;
-#define PXP_LOOP(FULL_)                                                                                                       \
-    for (int t = 0; t < nk; ++t, ++g) {                                                                                       \
+#endif
+#define PXP_STEP(FULL_, FIRST_)                                                                                               \
+    {                                                                                                                         \
         /* step g has landed (this wavefront's pieces): everything but the PX_S loads of step g + 1 is complete */            \
         if (g + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PX_S) : "memory");                                        \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                 \
@@ -548,11 +565,18 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
         /* wavefronts w and w + 4 share a SIMD: one of them requests its pieces of step g + 2 before its products, the   */    \
         /* other after them, so that one multiplies while the other issues (an LDS-DMA costs 60-180 issue cycles)      */    \
         if (!late && !(PX_ABL & 2)) { PXP_ISSUE() }                                                                           \
-        px_step_ring<FULL_>(ring_lds + (g % PX_RING) * SLAB + offA, ring_lds + (g % PX_RING) * SLAB + offB, acc);             \
+        if (PX_PRIO) __builtin_amdgcn_s_setprio(2);                                                                           \
+        px_step_ring<FULL_, 8192, 4096, FIRST_>(ring_lds + (g % PX_RING) * SLAB + offA, ring_lds + (g % PX_RING) * SLAB + offB, acc); \
+        if (PX_PRIO) __builtin_amdgcn_s_setprio(0);                                                                           \
         if (late && !(PX_ABL & 2)) { PXP_ISSUE() }                                                                            \
+        ++g;                                                                                                                  \
     }
+#define PXP_LOOP(FULL_)                                                                                                       \
+    PXP_STEP(FULL_, (PX_ZERO_C != 0))                                                                                         \
+    for (int t = 1; t < nk; ++t) PXP_STEP(FULL_, false)
         if (full) { PXP_LOOP(true) } else { PXP_LOOP(false) }
 #undef PXP_LOOP
+#undef PXP_STEP
         if (PX_ABL & 1) {
             int h = 0;
 #pragma unroll
@@ -722,6 +746,239 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
 #undef PXP_ISSUE
 }
 
+
+// ---------------------------------------------------------------- the downdate, two independent workgroups per CU (round 6)
+// (scripts/micro/pu_i8_bench.hip, variant 4, only: a MEASURED ALTERNATIVE that did not win -- bit-identical results on the whole matrix,
+// 117-121 us against 108-115 at m = 298, 274 against 269-283 at m = 1014, 477-492 against 467-486 at m = 2000, N = 1000;
+// profiles/r06_pu_i8_dual.txt.  Kept out of the library.)
+#ifdef PX_BENCH
+// What k_p_update_i8p cannot hide (profiles/r05_pu_i8_bench.txt): its eight wavefronts share ONE ring of slabs and one barrier, so
+// all of them leave the k-loop together -- nobody multiplies during a unit's epilogue (6.9 us) and turnover (2.4 us), which at ten
+// k-steps per unit (the m < 512 class) is 40 % of the unit.  Here a CU holds TWO independent workgroups of four wavefronts (one per
+// SIMD, so a SIMD still runs two wavefronts of 160 accumulators each): each works on its own HALF tile (64 rows x 128 columns:
+// wavefront wc = 64 x 32 = two MFMA blocks, as before) with its own ring and its own barrier.  The two drift apart by themselves,
+// and whenever one is in its epilogue, waits for a slab or fetches a unit, the other one owns the MFMA pipe.
+//   * slab of one step = 32 rows of k: per plane [I side: 2 k-groups x 64 columns x 16 B][J side: 2 k-groups x 128 columns x 16 B]
+//     = 6 pieces of 1 KB, 30 KB per step (the J side is fetched per half tile: 1.5 x the L2 -> LDS traffic of the shared ring);
+//     a wavefront issues eight LDS-DMA pieces per step (30 pieces dealt to four wavefronts, two of them fetch one piece twice:
+//     a uniform count keeps the wait a constant); ring of TWO slabs (80 KB of LDS per workgroup), one step in flight;
+//   * units are handed out dynamically: one counter per XCD list, a workgroup fetches the unit after next while it starts the
+//     current one (the ring runs on across units), so a CU's two workgroups need no static balance.  The counters of the NEXT
+//     launch are zeroed by this one (two sets, alternating);
+//   * the accumulators are not zeroed: the first step's products take the constant 0 as C (px_step_ring<.., FIRST>).
+// Same digits, same integer sums, same fp64 combination, same single rounding: bit-identical to k_p_update_i8p.
+template <bool RECT, typename TP = float>
+__global__ void __launch_bounds__(256, 2)
+k_p_update_i8d(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq, int ldq, size_t plane_stride, int m_k,
+               const int *__restrict__ bexp, int per_xcd, const int4 *__restrict__ units, RowMap rm, const int *__restrict__ counts,
+               unsigned *__restrict__ ctr, int parity)
+{
+    constexpr int TM = 128, TH = 64, MB = 32, PSTR = 6144, SLAB = PX_S * PSTR;
+    constexpr int ST = MB + 4; // row stride of the epilogue's staging image: 16-byte aligned rows
+    __shared__ __attribute__((aligned(16))) unsigned char ring[2 * SLAB];
+    __shared__ __attribute__((aligned(16))) float sTall[4 * MB * ST];
+    __shared__ int sExp[2][TH + TM];
+    __shared__ int4 sUnit[3];
+    __shared__ int sMeta[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // = wc: the wavefront's 32 columns of the tile
+    const int kg = lane >> 5, idx = lane & 31;
+    const int nk = m_k / 32;
+    const int xcd = blockIdx.x & 7;
+    // the other set of counters, for the next launch (also when this launch does nothing: the sets alternate per LAUNCH)
+    if (blockIdx.x < 8 && tid == 0) ctr[(parity ^ 1) * 8 + blockIdx.x] = 0u;
+    if (filter_frozen(counts)) return; // the update's sweep failed: P stays as it was (engine.h)
+    const int4 *ul = units + (size_t)xcd * per_xcd;
+    unsigned *my_ctr = ctr + parity * 8 + xcd;
+    // next unit of this XCD's list (wave-uniform; called by wavefront 0 only).  The descriptor is fetched by a SCALAR load.
+    auto grab = [&]() -> int4 {
+        unsigned k = 0u;
+        if (lane == 0) k = atomicAdd(my_ctr, 1u);
+        k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+        if (k >= (unsigned)per_xcd) return make_int4(-1, -1, -1, 0);
+        v4i u;
+        const int4 *p = ul + k;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(u) : "s"(p) : "memory");
+        return make_int4(u[0], u[1], u[2], u[3]);
+    };
+    if (wv == 0) {
+        const int4 u0 = grab();
+        const int4 u1 = u0.x < 0 ? u0 : grab();
+        if (lane == 0) {
+            sUnit[0] = u0;
+            sUnit[1] = u1;
+            sMeta[0] = ldp;
+            sMeta[1] = 0;
+        }
+    }
+    __syncthreads();
+    auto unit_at = [&](int ui) -> int4 {
+        const int4 u = sUnit[ui % 3];
+        return make_int4(__builtin_amdgcn_readfirstlane(u.x), __builtin_amdgcn_readfirstlane(u.y), __builtin_amdgcn_readfirstlane(u.z), 0);
+    };
+    if (unit_at(0).x < 0) return;
+    // first global row (= column of B) of row tile t
+    auto row0 = [&](int t) { return RECT ? (t == 0 ? 0 : rm.r0 + (t - 1) * TM) : t * TM; };
+
+    // ---- the slab pipeline.  A plane of a slab has six places of 1 KB: 0, 1 = I side k-group 0, 1; 2 .. 5 = J side k-group (p - 2) / 2,
+    // column half (p - 2) % 2.  The wavefronts of parity par = wv & 1 own the places par, par + 2, par + 4 (a = 0, 1, 2) of all five
+    // planes: fifteen pieces r = 3 s + a for two wavefronts -- hi = wv >> 1 = 0 takes r = 0 .. 7, hi = 1 takes r = 14 .. 7 (piece 7
+    // is fetched twice: the same eight instructions for everybody, a constant wait).  Piece j of a wavefront: plane s_j = j / 3, place
+    // a_j = j % 3, mirrored (4 - s_j, 2 - a_j) for hi = 1 -- every address is (a scalar that moves by a constant with j) + (one of
+    // three lane offsets), which is what the LDS-DMA's scalar-base form wants.
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const size_t step_stride = (size_t)2 * ldq * 16;
+    const int par = wv & 1, hi = wv >> 1;
+    const long long plane_step = hi ? -(long long)plane_stride : (long long)plane_stride; // from piece plane s_j to s_j + 1
+    const int8_t *plane_base = Bq + (hi ? 4 * plane_stride : (size_t)0);
+    const int lds_plane0 = hi ? 4 * PSTR : 0, lds_plane_step = hi ? -PSTR : PSTR;
+    const int lds_place0 = (par + (hi ? 4 : 0)) * 1024, lds_place_step = hi ? -2048 : 2048; // place a_j -> par + 2 a_j (mirrored: 2 - a_j)
+    int iu = 0, it = 0, ig = 0; // issue cursor: unit, step, global step
+    bool issue_live = true;
+    unsigned voff[3]; // lane offsets of the three places of the unit being issued (in piece order a_j = 0, 1, 2)
+    auto point = [&](const int4 &u) {
+        const int colI = row0(u.x) + TH * u.z, colJ = u.y * TM + 64 * par;
+        const unsigned vI = (unsigned)((par * ldq + colI + lane) * 16);  // place par: I side, k-group par
+        const unsigned vJ0 = (unsigned)((colJ + lane) * 16);             // place par + 2: J side, k-group 0, column half par
+        const unsigned vJ1 = (unsigned)((ldq + colJ + lane) * 16);       // place par + 4: J side, k-group 1
+        voff[0] = hi ? vJ1 : vI;
+        voff[1] = vJ0;
+        voff[2] = hi ? vI : vJ1;
+    };
+    point(unit_at(0));
+#define PXD_ISSUE()                                                                                                           \
+    if (issue_live) {                                                                                                         \
+        const bool last_ = it + 1 == nk;                                                                                      \
+        int4 un_ = make_int4(0, 0, 0, 0);                                                                                     \
+        if (last_) un_ = unit_at(iu + 1); /* (an LDS read: before the pieces are in flight, or the compiler drains them) */  \
+        const int8_t *sb_ = plane_base + (size_t)it * step_stride;                                                            \
+        const int rb_ = (ig & 1) * SLAB + lds_plane0 + lds_place0;                                                            \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                       \
+            unsigned vo_ = voff[j % 3];                                                                                       \
+            asm volatile("" : "+v"(vo_)); /* a fresh 32-bit offset: scalar base + lane offset stays visible as such */        \
+            __builtin_amdgcn_global_load_lds((gptr_t)(sb_ + (long long)(j / 3) * plane_step + vo_),                           \
+                                             (lptr_t)(&ring[rb_ + (j / 3) * lds_plane_step + (j % 3) * lds_place_step]), 16, 0, 0); \
+        }                                                                                                                     \
+        ++ig;                                                                                                                 \
+        if (last_) {                                                                                                          \
+            it = 0;                                                                                                           \
+            ++iu;                                                                                                             \
+            if (un_.x < 0) issue_live = false;                                                                                \
+            else point(un_);                                                                                                  \
+        } else ++it;                                                                                                          \
+    }
+    PXD_ISSUE()
+    int g = 0; // global step being multiplied
+    const unsigned ring_lds = (unsigned)(size_t)(lptr_t)&ring[0];
+    float *sT = sTall + wv * MB * ST;
+    // operand addresses inside a slab: A = the half tile's rows (two blocks of 32: + 512), B = this wavefront's 32 columns
+    const unsigned offA = (unsigned)(kg * 1024 + idx * 16), offB = (unsigned)(kg * 2048 + (wv * MB + idx) * 16);
+    for (int ui = 0;; ++ui) {
+        const int4 unit = unit_at(ui);
+        if (unit.x < 0) break;
+        const int ti = unit.x, tj = unit.y, uz = unit.z;
+        const bool diag = RECT || ti == tj;
+        const int I0 = row0(ti) + TH * uz, J0 = tj * TM; // first row / column of the half tile
+        const int p_off = RECT ? (ti == 0 ? 0 : rm.base - rm.r0) : 0; // local minus global row
+        const int ilim = RECT ? (ti == 0 ? 13 : rm.r1) : n;
+        if (tid < TH + TM) { // the half tile's row and column scales, for the epilogue
+            const int c = (tid < TH ? I0 : J0 - TH) + tid;
+            sExp[ui & 1][tid] = c < n ? bexp[c] - 1022 : 0;
+        }
+        v16i acc[2][PX_S];
+        // (the first step of a unit on its own: its products start the accumulators, and wavefront 0 fetches the unit after next --
+        // its descriptor is read two barriers from here at the earliest)
+#define PXD_STEP(FIRST_)                                                                                                      \
+    {                                                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wavefront's pieces of step g have landed */                  \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); /* everyone's have; everyone has left the other buffer */ \
+        if (FIRST_ && wv == 0) {                                                                                              \
+            const int4 un = grab();                                                                                           \
+            if (lane == 0) sUnit[(ui + 2) % 3] = un;                                                                          \
+        }                                                                                                                     \
+        PXD_ISSUE()                                                                                                           \
+        const unsigned sb = ring_lds + (unsigned)(g & 1) * SLAB;                                                              \
+        px_step_ring<true, PSTR, 2048, FIRST_>(sb + offA, sb + offB, acc);                                                    \
+        ++g;                                                                                                                  \
+    }
+        PXD_STEP(true)
+        for (int t = 1; t < nk; ++t) PXD_STEP(false)
+#undef PXD_STEP
+        // epilogue: v = 2^(e_i + e_j - 12) sum_L acc_L 256^-L, P <- fl32(P - v); off-diagonal tiles also write the mirror image
+        // (as in k_p_update_i8p: addresses from a copy of ldp read back from LDS, old values requested here, both images leave
+        // through the wavefront's staging area as 16-byte stores)
+        if constexpr (sizeof(TP) == 4) {
+            float *Pe = reinterpret_cast<float *>(P);
+            const int lde = __builtin_amdgcn_readfirstlane(sMeta[0]);
+            float *sTe = sT + __builtin_amdgcn_readfirstlane(sMeta[1]);
+            const int *se = sExp[ui & 1];
+            const int ej = se[TH + wv * MB + idx];
+            float *pe = Pe + (size_t)(I0 + p_off) * lde + J0 + wv * MB;
+            const int le = 4 * kg * lde + idx;
+            float pv0[16], pv1[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pv0[r] = (pe + ((r & 3) + 8 * (r >> 2)) * lde)[le];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pv1[r] = (pe + (MB + (r & 3) + 8 * (r >> 2)) * lde)[le];
+            float *pm = Pe + (size_t)(J0 + wv * MB) * lde + I0; // mirror image of block (0, .) (never used when RECT)
+            const int q8 = lane >> 3, q4 = lane & 7;
+            float *sTd = sTe + 4 * kg * ST + idx;
+            float *sTt = sTe + idx * ST + 4 * kg;
+            const float4 *sTq = reinterpret_cast<const float4 *>(sTe + q8 * ST + 4 * q4);
+            const int lq = q8 * lde + 4 * q4;
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int bi = I0 + x * MB;
+                float out[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int li = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    double tsum = (double)acc[x][PX_S - 1][r];
+#pragma unroll
+                    for (int L = PX_S - 2; L >= 0; --L) tsum = fma(tsum, 1.0 / 256.0, (double)acc[x][L][r]);
+                    const double v = ldexp(tsum, se[x * MB + li] + ej - 12);
+                    out[r] = (float)((double)(x == 0 ? pv0[r] : pv1[r]) - v);
+                    sTd[((r & 3) + 8 * (r >> 2)) * ST] = out[r];
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const float4 v = sTq[i4 * 8 * ST / 4];
+                    const int gi = bi + 8 * i4 + q8, gj0 = J0 + wv * MB + 4 * q4;
+                    float *dst = (pe + (x * MB + 8 * i4) * lde) + lq;
+                    if (gi < ilim) {
+                        if (gj0 + 3 < n) *reinterpret_cast<float4 *>(dst) = v;
+                        else { // the ragged last column tile (n is not a multiple of 4): the padding stays untouched
+                            if (gj0 < n) dst[0] = v.x;
+                            if (gj0 + 1 < n) dst[1] = v.y;
+                            if (gj0 + 2 < n) dst[2] = v.z;
+                        }
+                    }
+                }
+                if (!diag) { // rows of an off-diagonal tile are all < n (its row range ends before its column range starts)
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sTt[(r & 3) + 8 * (r >> 2)] = out[r];
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        const float4 v = sTq[i4 * 8 * ST / 4];
+                        const int mj = J0 + wv * MB + 8 * i4 + q8; // row of the mirror = column of the block
+                        if (mj < n) *reinterpret_cast<float4 *>((pm + x * MB + 8 * i4 * lde) + lq) = v;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+#undef PXD_ISSUE
+}
+#endif // PX_BENCH (k_p_update_i8d)
 
 // ------------------------------------------------------------------------ the downdate, four wavefronts with 64 x 64 each
 // (scripts/micro/pu_i8_bench.hip, variant 3, only: a MEASURED ALTERNATIVE that lost -- bit-identical results, 330 us against 259 us
@@ -1195,7 +1452,7 @@ void launch_b_gemm_planes(EkfEngine *e, int m, int c_lo, int c_hi)
 // ------------------------------------------------------------------------------------------------ launcher
 void build_units(EkfEngine *e, int nt, int nrt, bool rect, int order); // kernels_pupdate.hip
 
-#ifdef PX_BENCH // scripts/micro/pu_i8_bench.hip only: 1 = one workgroup per unit (k_p_update_i8)
+#ifdef PX_BENCH // scripts/micro/pu_i8_bench.hip only: 1 = one workgroup per unit (k_p_update_i8), 4 = two workgroups per CU (k_p_update_i8d)
 int g_px_variant = 0;
 #else
 constexpr int g_px_variant = 0;
@@ -1247,7 +1504,44 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bo
         if (e2) (void)hipEventDestroy(e2);
         return;
     }
+    // two independent workgroups per CU on half tiles, units handed out dynamically (k_p_update_i8d): fp32-stored P
+#ifdef PX_BENCH
+    const bool dual = PX_S == 5 && e->f32 && (e->p_exact_sym || rect) && g_px_variant == 4;
+#else
+    constexpr bool dual = false;
+#endif
+    int grid_d = 0, per_d = 0;
+    const int4 *tm_d = nullptr;
+    if (dual) {
+        if (!e->d.pu_ctr) {
+            if (hipMalloc((void **)&e->d.pu_ctr, 16 * sizeof(unsigned)) != hipSuccess || hipMemset(e->d.pu_ctr, 0, 16 * sizeof(unsigned)) != hipSuccess) {
+                e->d.pu_ctr = nullptr;
+                e->err = "exact downdate: unit counters";
+                e->hook_rc = EKF_ERR_HIP;
+            }
+        }
+        const int keep = e->pu_slots;
+        e->pu_slots = 1 << 20; // a unit list of half tiles only (build_units: one half-round)
+        build_units(e, nt, nrt, rect, 0);
+        e->pu_slots = keep;
+        per_d = e->pu_per_xcd;
+        tm_d = (const int4 *)e->d.pu_tilemap;
+        grid_d = 2 * e->n_cus;
+        if (!e->d.pu_ctr || !tm_d || per_d == 0) {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            if (e2) (void)hipEventDestroy(e2);
+            return;
+        }
+    }
     if (e->timing) (void)hipEventRecord(e0, s);
+    if (dual) {
+#if PX_S_VALUE == 5 && defined(PX_BENCH)
+        if (rect) k_p_update_i8d<true><<<grid_d, 256, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, per_d, tm_d, e->rm, e->d.counts, e->d.pu_ctr, e->pu_parity);
+        else k_p_update_i8d<false><<<grid_d, 256, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, per_d, tm_d, e->rm, e->d.counts, e->d.pu_ctr, e->pu_parity);
+        e->pu_parity ^= 1;
+#endif
+    } else
     if (!e->f32) { // fp64-stored P (EKF_PRECISION_F64_EXACT): the persistent kernel with the fp64 epilogue; an arbitrary upload is
                    // symmetrised first (0.5 (P + P') - B'B = 0.5 ((P - B'B) + (P - B'B)'): B'B is symmetric)
         if (!e->p_exact_sym && !rect) k_symmetrize_P<<<dim3((n + 255) / 256, n), 256, 0, s>>>((double *)e->d.P, ld, n);

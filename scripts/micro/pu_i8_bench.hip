@@ -41,7 +41,7 @@ int main(int argc, char **argv)
     }
     const int rounds = argc > 3 ? atoi(argv[3]) : 7;
     const int variant = argc > 4 ? atoi(argv[4]) : 0; // 0 persistent kernel; 1 one workgroup per unit; 2 the AVG instance (first update after an upload)
-    g_px_variant = (variant == 1 || variant == 3) ? variant : 0; // 3: four wavefronts with 64 x 64 each (k_p_update_i8q)
+    g_px_variant = (variant == 1 || variant == 3 || variant == 4) ? variant : 0; // 3: four wavefronts with 64 x 64 each (k_p_update_i8q); 4: two workgroups per CU (k_p_update_i8d)
     const int n = 13 + 6 * N, ld = round_up(n, LD_ALIGN);
     int m_max = 0;
     for (int m : ms) m_max = std::max(m_max, m);
@@ -182,7 +182,7 @@ int main(int argc, char **argv)
                "max |v - fp64 B'B| %.3e (max |B'B| %.3e); max |P_new - fp64 result|: exact path %.3e, fp32 MFMA kernel %.3e\n",
                m, n, n_chk - n_bad, n_chk, asym, max_err64, max_ref, max_e32_new, max_e32_old);
         if (n_bad || asym) rc = 1;
-        if (variant == 3) { // the whole matrix against the eight-wavefront kernel's bits
+        if (variant == 3 || variant == 4) { // the whole matrix against the eight-wavefront kernel's bits
             const int keep = g_px_variant;
             g_px_variant = 0;
             hipMemcpy(dP, dP0, hP.size() * 4, hipMemcpyDeviceToDevice);

@@ -346,7 +346,7 @@ def test_stalled_sweep_inside_a_step_is_invisible_to_the_caller(eng_mod, oracle_
     if not async_errors:
         assert retried == 1
     assert_parity(e, o, f"stall {which}, async {async_errors}", 170)
-    _, tp, tm = e.map_features()
+    _, tp, tm = e.get_map_features()
     _, otp, otm = o.map_features()
     assert np.array_equal(tm, otm) and np.array_equal(tp, otp)
 
