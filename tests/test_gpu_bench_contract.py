@@ -76,6 +76,15 @@ def test_default_line_the_driver_runs_has_no_fraction_above_one():
     roof = d["roofline"]
     assert roof["unit"] == "TOP/s (int8)" and roof["peak"] == 5033.0 and roof["bound"] in ("hbm", "mfma")
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) <= 1e-12
+    # both int8 figures of the guides beside the derived peak (round-5 review item 8)
+    assert roof["guide_i8_peak_tops"] == 3944.0 and 0.0 < roof["frac_of_guide_i8_peak"] <= 1.0
+    assert abs(roof["frac_of_guide_i8_peak"] - roof["achieved"] / 3944.0) <= 1e-12
+    # the PCIe-inclusive secondary line (host keypoints through ekf_step) and the parity gate the configuration is held to
+    pi = d["pcie_inclusive"]
+    assert pi["value"] > 0 and pi["host_bytes_per_frame"] > 0 and pi["value"] <= 1.05 * d["value"]
+    assert "1e-5" in d["config"]["parity_gate"]
+    live = [p for p in d["cpu_baseline"]["literal_points"] if p.get("measured")]
+    assert sorted(p["N"] for p in live) == [200, 350]
     for name, c in roof["by_launch_class"].items():
         assert c.get("bound", "mfma") in ("mfma", "hbm", "fixed-cost"), (name, c.get("bound"))
     am = d["all_matched"]["p_update"]
