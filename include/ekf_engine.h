@@ -306,7 +306,12 @@ int ekf_get_sweep_retries(const EkfEngine *e);
  * of P by symmetry and S is assembled by block columns and all-gathered (EKF_XCHG_SCOLS).  DESIGN.md section 8. */
 typedef int (*EkfExchangeFn)(void *user, int what, void *device_base, size_t row_bytes, const int32_t *row_begin,
                              int world, int rank);
-enum { EKF_XCHG_HP = 0, EKF_XCHG_PRED_S = 1, EKF_XCHG_HPC = 2, EKF_XCHG_PDIAG = 3, EKF_XCHG_BPLANES = 4, EKF_XCHG_SCOLS = 5 };
+enum { EKF_XCHG_HP = 0, EKF_XCHG_PRED_S = 1, EKF_XCHG_HPC = 2, EKF_XCHG_PDIAG = 3, EKF_XCHG_BPLANES = 4, EKF_XCHG_SCOLS = 5,
+       /* round 6 -- matching and RANSAC divided by feature ownership: the per-prediction match tables (valid flag,
+        * keypoint index or matched pixel, distance; rows = prediction slots) and a RANSAC batch's support counts and inlier masks
+        * (rows = hypotheses of the batch) */
+       EKF_XCHG_MATCH_VALID = 6, EKF_XCHG_MATCH_KP = 7, EKF_XCHG_MATCH_DIST = 8, EKF_XCHG_MATCH_XY = 9,
+       EKF_XCHG_HYP_COUNT = 10, EKF_XCHG_HYP_FLAGS = 11 };
 /* what: which replicated table is being completed; device_base: its first row on this rank's GPU; rank r owns rows
  * [row_begin[r], row_begin[r+1]) of row_bytes each and has just written them.  The callback returns when this
  * rank's table holds every rank's rows (0 = ok).  It is called with the engine's stream idle. */

@@ -57,8 +57,16 @@ static RcclApi &rccl_api()
         // a copy that is already mapped (torch.distributed's "nccl" backend) first: two RCCL copies in one process would
         // each keep their own device state
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // EKF_RCCL_LIBRARY: this library and no other (a site's own RCCL build; the test suite's in-process stand-in,
+        // tests/cpp/mock_rccl.cpp, which lets a one-GPU box drive the in-stream exchange with several ranks)
+        if (const char *own = std::getenv("EKF_RCCL_LIBRARY")) {
+            if (*own) {
+                api.lib = dlopen(own, RTLD_NOW | RTLD_LOCAL);
+                if (!api.lib) return;
+            }
+        }
         for (const char *name : names)
-            if ((api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD))) break;
+            if (api.lib || (api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD))) break;
         for (int i = 0; !api.lib && i < 3; ++i) api.lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
         if (!api.lib) return;
 #define RCCL_SYM(field, sym) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, sym))
@@ -1001,9 +1009,15 @@ static int predict_measurements_dev(EkfEngine *e, const int *d_idx, int count, i
                                     bool lean = false)
 {
     launch_predict_features(e, d_idx, d_idx ? count : e->N, false);
+    const bool slots = lean && !d_idx && e->shard_world > 1; // sharded step: where each rank's run of the predicted list starts (matching by owner)
+    if (slots) launch_shard_bounds_idx(e, e->d.plist, e->d.counts + CNT_NPRED);
     int rc = read_counts(e);
     if (rc) return rc;
     const int np = e->h_counts[d_idx ? CNT_NPRED_SUB : CNT_NPRED];
+    if (slots) {
+        e->slot_rb.assign(e->shard_world + 1, 0);
+        for (int r = 0; r <= e->shard_world; ++r) e->slot_rb[r] = e->h_counts[CNT_SHARD0 + r];
+    } else if (!d_idx) e->slot_rb.clear();
     launch_hp_rows(e, d_idx ? e->d.plist_sub : e->d.plist, np, count_predicted);
     if (!d_idx) e->n_pred = np;
     *n_out = np;
@@ -1116,6 +1130,51 @@ static int match_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_de
     return check_async(e);
 }
 
+// Sharded EKF::step ("Matching: features/ellipses independent => shard by feature; image replicated; all-gather match
+// lists"): every rank gates and matches the predictions of the features it OWNS -- one run of slots of the feature-ordered
+// predicted list (slot_rb, predict_measurements_dev) -- with either matcher, the per-slot tables (valid flag, keypoint index or
+// matched pixel, distance) are all-gathered, and every rank compacts the same tables into the same match list
+// (Matching.cpp:217-262 divided by the ranks; the list is identical to the unsharded one, which the tests assert).
+static int match_sharded_dev(EkfEngine *e, bool use_ncc, const EkfKeypoint *d_kps, const uint8_t *d_desc, int n_kp, int *n_matches)
+{
+    const int W = e->shard_world, me = e->shard_rank, np = e->n_pred;
+    if ((int)e->slot_rb.size() != W + 1 || e->slot_rb[0] != 0 || e->slot_rb[W] != np) {
+        e->err = "sharded matching: the predicted list is not in feature order";
+        return EKF_ERR_INVALID_ARG;
+    }
+    if (use_ncc && !e->img.valid) {
+        e->err = "NCC matcher: no image uploaded";
+        return EKF_ERR_INVALID_ARG;
+    }
+    EkfKeypoint *save_k = e->d.kps;
+    uint8_t *save_d = e->d.kdesc;
+    if (!use_ncc) { // kernels read e->d.kps / kdesc; staged frames alias them in
+        e->d.kps = const_cast<EkfKeypoint *>(d_kps);
+        e->d.kdesc = const_cast<uint8_t *>(d_desc);
+    }
+    int rc = EKF_OK;
+    if (np > 0) {
+        if (use_ncc) launch_match_ncc_slots(e, e->slot_rb[me], e->slot_rb[me + 1]);
+        else launch_match_slots(e, n_kp, e->slot_rb[me], e->slot_rb[me + 1]);
+        rc = exchange_rows(e, EKF_XCHG_MATCH_VALID, e->d.mt_valid, sizeof(int), e->slot_rb, "the match flags");
+        if (!rc) rc = use_ncc ? exchange_rows(e, EKF_XCHG_MATCH_XY, e->d.mt_xy, sizeof(EkfKeypoint), e->slot_rb, "the matched pixels")
+                              : exchange_rows(e, EKF_XCHG_MATCH_KP, e->d.mt_kp, sizeof(int), e->slot_rb, "the matched keypoint indices");
+        if (!rc) rc = exchange_rows(e, EKF_XCHG_MATCH_DIST, e->d.mt_dist, sizeof(float), e->slot_rb, "the match distances");
+    }
+    if (!rc) {
+        if (use_ncc) {
+            if (np > 0) launch_match_compact_slots(e, np, e->d.mt_xy);
+            else HIPCHK(hipMemsetAsync(e->d.counts + CNT_NMATCH, 0, sizeof(int), e->stream));
+        } else launch_match_compact(e, np);
+    }
+    e->d.kps = save_k;
+    e->d.kdesc = save_d;
+    if (rc) return rc;
+    if ((rc = read_counts(e))) return rc;
+    *n_matches = e->h_counts[CNT_NMATCH];
+    return check_async(e);
+}
+
 int ekf_match(EkfEngine *e, const EkfKeypoint *kps, const uint8_t *desc32, int n_kp, EkfMatch *matches,
               int *n_matches)
 {
@@ -1132,31 +1191,44 @@ int ekf_match(EkfEngine *e, const EkfKeypoint *kps, const uint8_t *desc32, int n
 }
 
 // RANSAC over e->d.matches[0..M); on return best_flags holds the inlier mask, h_counts the loop state.
-// lean (sharded EKF::step, feature-ordered match list): a batch's hypotheses use the H.P rows of THEIR features as gain
-// columns; those features lie between the batch's first and last featureIndex, so that slice of the table is completed
-// before the batch runs (~80 rows instead of 2N; one batch is the rule).
+// lean (sharded EKF::step, feature-ordered match list): the hypotheses are divided by feature ownership, see below.
 static int ransac_dev(EkfEngine *e, int M, bool lean = false)
 {
     launch_ransac_init(e, M);
     launch_match_index(e, M);
     const int batch = e->cfg.ransac_batch;
-    for (int h0 = 0; h0 < M; h0 += batch) {
-        if (lean && e->shard_world > 1 && !e->hp_complete) {
-            const int h1 = std::min(M, h0 + batch);
-            launch_slice_bounds(e, e->d.matches, h0, h1);
-            int rc = read_counts(e);
-            if (rc) return rc;
-            const int f_lo = e->h_counts[CNT_AUX0], f_hi = e->h_counts[CNT_AUX1];
-            if (f_lo < 0 || f_hi < f_lo || f_hi >= e->N) {
-                e->err = "sharded RANSAC: the match list is not in feature order";
-                return EKF_ERR_INVALID_ARG;
-            }
-            std::vector<int32_t> rb(e->shard_world + 1);
-            for (int r = 0; r <= e->shard_world; ++r) rb[r] = 2 * std::min(std::max(e->shard_feat_begin[r], f_lo), f_hi + 1);
-            if ((rc = exchange_rows(e, EKF_XCHG_HP, e->d.HP, (size_t)e->ldP * hp_elem_bytes(e), rb, "the H.P rows of a RANSAC batch"))) return rc;
-            if (e->f32 && !e->exact && (rc = exchange_rows(e, EKF_XCHG_HPC, e->d.HPc, 16 * sizeof(double), rb, "their fp64 camera columns"))) return rc;
+    const int W = e->shard_world, me = e->shard_rank;
+    // Sharded EKF::step ("RANSAC: hypotheses are independent => shard hypotheses across GPUs, all-gather the support
+    // counts"): hypothesis h uses the H.P rows of ITS feature as gain columns, and those rows are with the feature's owner -- so every
+    // rank evaluates the hypotheses of the features it owns (one run [mb[me], mb[me + 1]) of the feature-ordered match list: no row of
+    // H.P travels) and the ranks all-gather a batch's support counts (4 bytes per hypothesis) and inlier masks (M bytes per
+    // hypothesis) before the sequential bookkeeping, which every rank then replays identically (1PointRansac.cpp:125-180).
+    const bool by_owner = lean && W > 1 && !e->hp_complete;
+    std::vector<int32_t> mb, rb;
+    if (by_owner) {
+        launch_shard_bounds(e, e->d.matches, M);
+        int rc = read_counts(e);
+        if (rc) return rc;
+        mb.assign(W + 1, 0);
+        for (int r = 0; r <= W; ++r) mb[r] = e->h_counts[CNT_SHARD0 + r];
+        if (mb[0] != 0 || mb[W] != M) {
+            e->err = "sharded RANSAC: the match list is not in feature order";
+            return EKF_ERR_INVALID_ARG;
         }
-        launch_ransac_batch(e, M, h0, batch);
+        rb.assign(W + 1, 0);
+    }
+    for (int h0 = 0; h0 < M; h0 += batch) {
+        if (by_owner) {
+            const int h1 = std::min(M, h0 + batch);
+            launch_ransac_hyp(e, M, h0, batch, nullptr, mb[me], mb[me + 1]);
+            for (int r = 0; r <= W; ++r) rb[r] = std::min(std::max(mb[r], h0), h1) - h0; // rows of the batch's tables by owner
+            int rc;
+            if ((rc = exchange_rows(e, EKF_XCHG_HYP_COUNT, e->d.hyp_count, sizeof(int), rb, "the support counts of a RANSAC batch"))) return rc;
+            if ((rc = exchange_rows(e, EKF_XCHG_HYP_FLAGS, e->d.hyp_flags, (size_t)e->mcap, rb, "the inlier masks of a RANSAC batch"))) return rc;
+            launch_ransac_select(e, M, h0, batch, nullptr, 0);
+        } else {
+            launch_ransac_batch(e, M, h0, batch);
+        }
         int rc = read_counts(e);
         if (rc) return rc;
         if (e->h_counts[CNT_RS_DONE]) break;
@@ -1421,7 +1493,9 @@ static int step_dev(EkfEngine *e, const EkfKeypoint *d_kps, const uint8_t *d_des
     tm.mark();
     // 4. matching (:337)
     int M = 0;
-    if ((rc = use_ncc ? match_ncc_dev(e, &M) : match_dev(e, d_kps, d_desc, n_kp, &M))) return rc;
+    if (lean) rc = match_sharded_dev(e, use_ncc, d_kps, d_desc, n_kp, &M); // every rank matches the predictions of its own features
+    else rc = use_ncc ? match_ncc_dev(e, &M) : match_dev(e, d_kps, d_desc, n_kp, &M);
+    if (rc) return rc;
     li.n_matches = M;
     tm.mark();
     // 6. 1-point RANSAC (:402); predictions/Jacobians are looked up by featureIndex (:368-392)

@@ -51,7 +51,7 @@ enum {
     CNT_RS_NEXT,      // RANSAC: next hypothesis to examine
     CNT_RS_DONE,      // RANSAC: loop finished
     CNT_NRESC,        // rescued count
-    CNT_AUX0,         // sharded filter: featureIndex of the first / last hypothesis of a RANSAC batch (k_slice_bounds)
+    CNT_AUX0,         // (free)
     CNT_AUX1,
     CNT_SHARD0,       // sharded filter: CNT_SHARD0 + r = first entry of a feature-sorted match list that rank r owns
                       // (r = 0 .. world, at most 16 ranks: slots 12 .. 28; k_shard_bounds)
@@ -223,6 +223,7 @@ struct EkfEngine {
     long long xchg_bytes_planes = 0;      // bytes of digit planes this rank received (tests assert them against the model)
     int hook_rc = 0;                     // its status (launch_update returns nothing)
     std::vector<int32_t> shard_rb;       // row boundaries of the gathered rows by owner (from CNT_SHARD0..)
+    std::vector<int32_t> slot_rb;        // sharded step: prediction slots of the last full prediction by owner (from CNT_SHARD0..)
     std::vector<int32_t> last_col_rb;    // column shares of the planes of B used by the last sharded update (ekf_shard_counters)
     void *xchg_user = nullptr;
     int n_cus = 256;           // compute units of the device (launch-shape decisions)
@@ -352,10 +353,16 @@ void launch_hp_rows(EkfEngine *e, const int *d_list, int n_list, bool count_pred
 void launch_match(EkfEngine *e, int n_pred, int n_kp, const int *d_npred = nullptr, bool with_ransac_init = false);
 // d_M != nullptr (RANSAC launchers): M is an upper bound, the number of matches is read on the device
 void launch_match_index(EkfEngine *e, int M, const int *d_M = nullptr);
-// sharded filter: per-rank boundaries of a feature-sorted match list -> counts[CNT_SHARD0 ..]; featureIndex of list[h0] and
-// list[h1 - 1] -> counts[CNT_AUX0], counts[CNT_AUX1]
+// sharded filter: per-rank boundaries of a feature-sorted match list -> counts[CNT_SHARD0 ..]
 void launch_shard_bounds(EkfEngine *e, const EkfMatch *list, int count);
-void launch_slice_bounds(EkfEngine *e, const EkfMatch *list, int h0, int h1);
+void launch_shard_bounds_idx(EkfEngine *e, const int *list, const int *d_count); // ... of a feature-index list whose length is on the device
+// sharded filter: matching and RANSAC hypotheses divided by feature ownership (kernels_match.hip, kernels_ncc.hip, kernels_ransac.hip)
+void launch_match_slots(EkfEngine *e, int n_kp, int s_lo, int s_hi);
+void launch_match_ncc_slots(EkfEngine *e, int s_lo, int s_hi);
+void launch_match_compact(EkfEngine *e, int n_pred);
+void launch_match_compact_slots(EkfEngine *e, int n_pred, const EkfKeypoint *d_slot_xy);
+void launch_ransac_hyp(EkfEngine *e, int M, int h0, int batch, const int *d_M, int h_lo, int h_hi);
+void launch_ransac_select(EkfEngine *e, int M, int h0, int batch, const int *d_M, int publish_seq);
 // publish_seq > 0: the batch's bookkeeping kernel also publishes the counter block (see publish_counts_block)
 void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M = nullptr, int publish_seq = 0);
 void launch_ransac_init(EkfEngine *e, int M);

@@ -13,9 +13,10 @@ namespace ekf {
 __global__ void __launch_bounds__(256)
 k_match(const int *plist, const double *uv_tab, const double *S_tab, const uint8_t *feat_desc,
         const EkfKeypoint *kps, const uint8_t *kdesc, int n_kp, double coef, int *mt_valid, int *mt_kp,
-        float *mt_dist, int desc_bytes, int desc_f32, const int *d_npred)
+        float *mt_dist, int desc_bytes, int desc_f32, const int *d_npred, int slot0)
 {
-    if (d_npred && (int)blockIdx.x >= *d_npred) return; // grid = upper bound, count on the device
+    // slot0: first prediction slot of this launch (a rank of a sharded filter matches the predictions of ITS features only)
+    if (d_npred && slot0 + (int)blockIdx.x >= *d_npred) return; // grid = upper bound, count on the device
     __shared__ Gate g;
     __shared__ uint32_t qd[1024]; // the map feature's descriptor: 8 words (CV_8U) or up to 1024 floats (CV_32F)
     constexpr int PASS = 8; // keypoints per thread and pass: their loads are in flight together, one barrier pair per pass
@@ -27,7 +28,7 @@ k_match(const int *plist, const double *uv_tab, const double *S_tab, const uint8
     __shared__ float s_dfront, s_dback;
     __shared__ double s_min;
 
-    const int k = blockIdx.x, tid = threadIdx.x;
+    const int k = slot0 + (int)blockIdx.x, tid = threadIdx.x;
     const int fi = plist[k];
     if (tid == 0) {
         float axes[2];
@@ -177,10 +178,32 @@ void launch_match(EkfEngine *e, int n_pred, int n_kp, const int *d_npred, bool w
     }
     k_match<<<n_pred, 256, 0, e->stream>>>(e->d.plist, e->d.pred_uv, e->d.pred_S, e->d.feat_desc, e->d.kps,
                                            e->d.kdesc, n_kp, e->cfg.par.matchingCompCoefSecondBestVSFirst,
-                                           e->d.mt_valid, e->d.mt_kp, e->d.mt_dist, e->desc_bytes, e->desc_f32 ? 1 : 0, d_npred);
+                                           e->d.mt_valid, e->d.mt_kp, e->d.mt_dist, e->desc_bytes, e->desc_f32 ? 1 : 0, d_npred, 0);
     k_match_compact<<<1, 1024, 0, e->stream>>>(e->d.plist, n_pred, e->d.mt_valid, e->d.mt_kp, e->d.mt_dist,
                                                e->d.kps, 0, e->d.matches, e->d.counts + CNT_NMATCH, d_npred,
                                                with_ransac_init ? e->d.counts : nullptr, e->d.match_of_feat, e->d.best_flags, e->N);
+}
+
+// Sharded filter ("Matching: features/ellipses independent => shard by feature ... all-gather match lists"): a rank
+// gates and matches the prediction slots [s_lo, s_hi) -- the predictions of the features it owns: the predicted list is in feature
+// order, so they are ONE run of slots -- into the per-slot tables; the ranks all-gather the tables (engine.cpp) and every rank
+// compacts the same complete tables into the same match list.
+void launch_match_slots(EkfEngine *e, int n_kp, int s_lo, int s_hi)
+{
+    if (s_hi <= s_lo) return;
+    k_match<<<s_hi - s_lo, 256, 0, e->stream>>>(e->d.plist, e->d.pred_uv, e->d.pred_S, e->d.feat_desc, e->d.kps, e->d.kdesc, n_kp,
+                                                e->cfg.par.matchingCompCoefSecondBestVSFirst, e->d.mt_valid, e->d.mt_kp, e->d.mt_dist,
+                                                e->desc_bytes, e->desc_f32 ? 1 : 0, nullptr, s_lo);
+}
+
+void launch_match_compact(EkfEngine *e, int n_pred)
+{
+    if (n_pred <= 0) {
+        (void)hipMemsetAsync(e->d.counts + CNT_NMATCH, 0, sizeof(int), e->stream);
+        return;
+    }
+    k_match_compact<<<1, 1024, 0, e->stream>>>(e->d.plist, n_pred, e->d.mt_valid, e->d.mt_kp, e->d.mt_dist, e->d.kps, 0, e->d.matches,
+                                               e->d.counts + CNT_NMATCH, nullptr, nullptr, nullptr, nullptr, 0);
 }
 
 void launch_match_compact_slots(EkfEngine *e, int n_pred, const EkfKeypoint *d_slot_xy)
@@ -317,23 +340,28 @@ __global__ void k_shard_bounds(const EkfMatch *list, int count, const int *feat_
     if (bad && r == world) counts[CNT_SHARD0 + r] = -1;
 }
 
+// ... the same for a list of feature indices whose length is on the device (the predicted list of a step: plist, counts[CNT_NPRED])
+__global__ void k_shard_bounds_idx(const int *list, const int *d_count, const int *feat_begin, int world, int *counts)
+{
+    const int r = threadIdx.x, count = *d_count;
+    const int f = r <= world ? feat_begin[r] : 0;
+    int lo = 0, hi = r <= world ? count : 0;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (list[mid] < f) lo = mid + 1;
+        else hi = mid;
+    }
+    if (r <= world) counts[CNT_SHARD0 + r] = lo;
+}
+
+void launch_shard_bounds_idx(EkfEngine *e, const int *list, const int *d_count)
+{
+    k_shard_bounds_idx<<<1, 64, 0, e->stream>>>(list, d_count, e->d.shard_feat, e->shard_world, e->d.counts);
+}
+
 void launch_shard_bounds(EkfEngine *e, const EkfMatch *list, int count)
 {
     k_shard_bounds<<<1, 64, 0, e->stream>>>(list, count, e->d.shard_feat, e->shard_world, e->d.counts);
-}
-
-__global__ void k_slice_bounds(const EkfMatch *list, int h0, int h1, int *counts)
-{
-    int lo = list[h0].featureIndex;
-    for (int i = h0; i + 1 < h1; ++i) // (a batch is 32 hypotheses) the slice between the two ends is only the batch's rows for a sorted list
-        if (list[i].featureIndex >= list[i + 1].featureIndex) lo = -1;
-    counts[CNT_AUX0] = lo;
-    counts[CNT_AUX1] = list[h1 - 1].featureIndex;
-}
-
-void launch_slice_bounds(EkfEngine *e, const EkfMatch *list, int h0, int h1)
-{
-    if (h1 > h0) k_slice_bounds<<<1, 1, 0, e->stream>>>(list, h0, h1, e->d.counts);
 }
 
 __global__ void __launch_bounds__(256) k_outlier_idx(const EkfMatch *src, int M, int *idx)

@@ -108,7 +108,7 @@ __device__ inline void block_argmax(double &key, int &idx, double *s_key, int *s
 
 __global__ void __launch_bounds__(256)
 k_ncc_match(Pyr pyr, const int *plist, const double *uv_tab, const double *S_tab, const uint8_t *tmpl,
-            int *mt_valid, EkfKeypoint *mt_xy, float *mt_dist)
+            int *mt_valid, EkfKeypoint *mt_xy, float *mt_dist, int slot0)
 {
     __shared__ Gate g;
     __shared__ int s_geom[4]; // c2x, c2y, rad
@@ -118,7 +118,7 @@ k_ncc_match(Pyr pyr, const int *plist, const double *uv_tab, const double *S_tab
     __shared__ double s_key[4];
     __shared__ int s_idx[4];
 
-    const int k = blockIdx.x, tid = threadIdx.x;
+    const int k = slot0 + (int)blockIdx.x, tid = threadIdx.x; // slot0: see launch_match_ncc_slots
     const int fi = plist[k];
     const double pu = uv_tab[2 * fi], pv = uv_tab[2 * fi + 1];
     if (tid == 0) {
@@ -216,8 +216,17 @@ void launch_match_ncc(EkfEngine *e, int n_pred)
         return;
     }
     k_ncc_match<<<n_pred, 256, 0, e->stream>>>(pyr_of(e), e->d.plist, e->d.pred_uv, e->d.pred_S, e->d.tmpl, e->d.mt_valid,
-                                               e->d.mt_xy, e->d.mt_dist);
+                                               e->d.mt_xy, e->d.mt_dist, 0);
     launch_match_compact_slots(e, n_pred, e->d.mt_xy);
+}
+
+// sharded filter: the NCC search of the prediction slots [s_lo, s_hi) only (see launch_match_slots, kernels_match.hip); the per-slot
+// tables are completed by an all-gather and compacted by launch_match_compact_slots on every rank
+void launch_match_ncc_slots(EkfEngine *e, int s_lo, int s_hi)
+{
+    if (s_hi <= s_lo) return;
+    k_ncc_match<<<s_hi - s_lo, 256, 0, e->stream>>>(pyr_of(e), e->d.plist, e->d.pred_uv, e->d.pred_S, e->d.tmpl, e->d.mt_valid, e->d.mt_xy,
+                                                    e->d.mt_dist, s_lo);
 }
 
 } // namespace ekf

@@ -19,13 +19,16 @@ __global__ void __launch_bounds__(HYP_THREADS)
 k_ransac_hyp(const double *st, CamD cam, double thr, const double *feat_pos, const int *feat_type,
              const int *feat_covpos, int N, const T *HP, int ld, const double *uv_tab, const double *S_tab,
              const EkfMatch *matches, int M, const int *match_of_feat, int h0, int *hyp_count, uint8_t *hyp_flags,
-             int mcap, const int *d_M)
+             int mcap, const int *d_M, int h_lo, int h_hi)
 {
     __shared__ double sx[13], sRt[9], sRinv[9], sw[2];
     __shared__ int s_cnt[HYP_THREADS / 64];
     if (d_M) M = *d_M; // the number of matches is only known on the device (step path without read-backs)
     const int h = h0 + blockIdx.x;
     if (h >= M) return;
+    // sharded filter: this rank evaluates the hypotheses [h_lo, h_hi) -- those of the features it owns, whose H P rows (the gain
+    // columns) it holds; the others' support counts and masks arrive by an all-gather (engine.cpp: ransac_dev)
+    if (h < h_lo || h >= h_hi) return;
     const int tid = threadIdx.x;
     const int fi = matches[h].featureIndex;
     const T *g0 = HP + (size_t)(2 * fi) * ld;
@@ -161,7 +164,8 @@ void launch_ransac_init(EkfEngine *e, int M)
     k_ransac_init<<<(n + 255) / 256, 256, 0, e->stream>>>(e->d.counts, e->d.match_of_feat, e->d.best_flags, e->N, M);
 }
 
-void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M, int publish_seq)
+// the hypotheses [h0, h0 + batch) restricted to [h_lo, h_hi) (whole batch: 0, INT_MAX)
+void launch_ransac_hyp(EkfEngine *e, int M, int h0, int batch, const int *d_M, int h_lo, int h_hi)
 {
     const int nb = batch; // hyp_flags rows are zeroed by their workgroups, hyp_count[b] is only read for launched hypotheses
     const double thr = e->cfg.par.ransacThresholdPredictDistance;
@@ -170,16 +174,26 @@ void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M,
                                                        e->d.feat_covpos, e->N, (const float *)e->d.HP, e->ldP,
                                                        e->d.pred_uv, e->d.pred_S, e->d.matches, M,
                                                        e->d.match_of_feat, h0, e->d.hyp_count, e->d.hyp_flags,
-                                                       e->mcap, d_M);
+                                                       e->mcap, d_M, h_lo, h_hi);
     else
         k_ransac_hyp<double><<<nb, e->N > 256 ? HYP_THREADS : 256, 0, e->stream>>>(e->d.state, e->cam, thr, e->d.feat_pos, e->d.feat_type,
                                                         e->d.feat_covpos, e->N, (const double *)e->d.HP, e->ldP,
                                                         e->d.pred_uv, e->d.pred_S, e->d.matches, M,
                                                         e->d.match_of_feat, h0, e->d.hyp_count, e->d.hyp_flags,
-                                                        e->mcap, d_M);
+                                                        e->mcap, d_M, h_lo, h_hi);
+}
+
+void launch_ransac_select(EkfEngine *e, int M, int h0, int batch, const int *d_M, int publish_seq)
+{
     k_ransac_select<<<1, 256, 0, e->stream>>>(e->d.counts, e->d.hyp_count, e->d.hyp_flags, e->d.best_flags, M, h0,
                                               batch, e->mcap, e->cfg.par.ransacAllInliersProbability, d_M, e->d_mirror,
                                               e->d_mirror ? publish_seq : 0);
+}
+
+void launch_ransac_batch(EkfEngine *e, int M, int h0, int batch, const int *d_M, int publish_seq)
+{
+    launch_ransac_hyp(e, M, h0, batch, d_M, 0, 0x7fffffff);
+    launch_ransac_select(e, M, h0, batch, d_M, publish_seq);
 }
 
 // ------------------------------------------------------------------------------------------------------ A9
