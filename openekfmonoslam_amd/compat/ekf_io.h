@@ -700,4 +700,58 @@ private:
 };
 
 } // namespace ekf_compat
+
+// ------------------------------------------------------------------------------ class EKF under the reference's own signatures
+// EKF(configurationFileName, outputPath), init(image), step(image)  (EKF/EKF.h:44-48) -- declared in ekf_compat.h, defined here
+// because they need the configuration loader and the output writer: class EKF drives an ImageEKF and shares its engine.
+#include "ekf_compat.h"
+
+#ifndef EKF_COMPAT_PRECISION
+#define EKF_COMPAT_PRECISION EKF_PRECISION_F64 // what EKF(configurationFileName, outputPath) creates its engine with (the reference computes in double)
+#endif
+
+namespace ekf_compat {
+inline Image imageFromMat(const cv::Mat &m)
+{
+    Image img;
+    if (m.empty()) return img;
+    img.width = m.cols;
+    img.height = m.rows;
+    img.channels = m.channels();
+    const size_t row = (size_t)m.cols * m.channels();
+    img.data.resize(row * m.rows);
+    for (int y = 0; y < m.rows; ++y) std::memcpy(&img.data[row * y], m.data + (size_t)y * m.step, row);
+    return img;
+}
+// a view (no copy): `img` must outlive it
+inline cv::Mat matFromImage(Image &img) { return cv::Mat(img.height, img.width, img.channels, img.data.data()); }
+inline void deleteImageEKF(ImageEKF *p) { delete p; }
+} // namespace ekf_compat
+
+inline EKF::EKF(const char *configurationFileName, const char *outputPath) : e_(0), steps_(0), drv_(0), drvDelete_(0)
+{
+    std::memset(&last_, 0, sizeof(last_));
+    drv_ = new ekf_compat::ImageEKF(configurationFileName, outputPath, EKF_COMPAT_PRECISION);
+    drvDelete_ = ekf_compat::deleteImageEKF;
+    e_ = drv_->engine();
+}
+
+inline void EKF::init(const cv::Mat &image)
+{
+    if (!drv_) throw ekf_compat::Error(EKF_ERR_INVALID_ARG, "EKF::init(image) needs the EKF(configurationFileName, outputPath) constructor");
+    drv_->init(ekf_compat::imageFromMat(image));
+    refreshLayout();
+    ekf_compat::download(e_, state, 0);
+    stateCovarianceMatrix.markStale(e_, ekf_state_dim(e_));
+}
+
+inline void EKF::step(const cv::Mat &image)
+{
+    if (!drv_) throw ekf_compat::Error(EKF_ERR_INVALID_ARG, "EKF::step(image) needs the EKF(configurationFileName, outputPath) constructor");
+    last_ = drv_->step(ekf_compat::imageFromMat(image));
+    ++steps_;
+    refreshLayout(); // the reference's public attributes are current after a step: `state` now, the covariance on first access
+    ekf_compat::download(e_, state, 0);
+    stateCovarianceMatrix.markStale(e_, ekf_state_dim(e_));
+}
 #endif // EKF_IO_H

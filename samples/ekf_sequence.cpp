@@ -24,12 +24,30 @@ int main(int argc, const char *argv[])
     try {
         ekf_compat::FileSequenceImageGenerator generator(argv[2], "", "png", first, last);
         generator.init();
-        ekf_compat::ImageEKF extendedKalmanFilter(argv[1], outputPath.c_str(), precision, threshold);
         ekf_compat::Image image = generator.getNextImage();
         if (image.empty()) {
             std::printf("No se puede iniciar Kalman Filter dado que no hay imagenes disponibles.\n");
             return 0;
         }
+        if (precision == EKF_PRECISION_F64 && threshold == 1e9) {
+            // the reference's own three lines (samples/EKF/main.cpp:76-131): EKF(config, outputPath), init(image), step(image)
+            EKF extendedKalmanFilter(argv[1], outputPath.c_str());
+            extendedKalmanFilter.init(ekf_compat::matFromImage(image));
+            std::printf("init: %d features\n", (int)extendedKalmanFilter.state.mapFeatures.size());
+            image = generator.getNextImage();
+            int steps = 0;
+            while (!image.empty()) {
+                extendedKalmanFilter.step(ekf_compat::matFromImage(image));
+                const EkfStepInfo &info = extendedKalmanFilter.lastStepInfo();
+                const double *x = extendedKalmanFilter.state.position;
+                std::printf("step %d: predicted %d matches %d li %d hi %d features %d  r = %.6f %.6f %.6f\n", ++steps, info.n_predicted,
+                            info.n_matches, info.n_inliers, info.n_rescued, (int)extendedKalmanFilter.state.mapFeatures.size(), x[0], x[1], x[2]);
+                image = generator.getNextImage();
+            }
+            return 0;
+        }
+        // (a detector threshold or the fp32 configuration asked for: the driver class with its extra constructor arguments)
+        ekf_compat::ImageEKF extendedKalmanFilter(argv[1], outputPath.c_str(), precision, threshold);
         extendedKalmanFilter.init(image);
         std::printf("init: %d features\n", ekf_num_features(extendedKalmanFilter.engine()));
         image = generator.getNextImage();

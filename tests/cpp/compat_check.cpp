@@ -3,10 +3,16 @@
 // Reads a scenario written by tests/test_gpu_compat.py, then
 //   (1) runs every frame through class EKF (device-resident), and
 //   (2) replays frame 0 through the reference's stage functions in the order of EKF::step (EKF.cpp:242-556),
-// printing the camera state, trace(P) and the step counters of both, which the Python test compares with the
+//   (4) replays it again through the call sequence of EKF.cpp:273-531 under the reference's OWN signatures -- the 4-argument
+//       matchPredictedFeatures(frame, features, predictions, matches) -- and checks the resident mode: the covariance travels to
+//       the device once for the whole sequence and comes back on first access,
+//   (5) the same sequence with the image-taking matchPredictedFeatures(const cv::Mat &, ...) (matcher mode B) when the scenario
+//       carries rendered frames,
+// printing the camera state, trace(P) and the step counters of each, which the Python test compares with the
 // ctypes path and the oracle.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "../../openekfmonoslam_amd/compat/ekf_compat.h"
 
@@ -29,6 +35,74 @@ static void report(const char *tag, const State &s, const Matd &P, const EkfStep
     std::printf(" trace %.17g fro %.17g", tr, std::sqrt(fro));
     if (info) std::printf(" counts %d %d %d %d %d", info->n_predicted, info->n_matches, info->n_hypotheses, info->n_inliers, info->n_rescued);
     std::printf("\n");
+}
+
+// The call sequence of EKF::step between the prediction and the second update (EKF.cpp:273-531), written against the reference's
+// signatures (StateAndCovariancePrediction.h:41, MeasurementPrediction.h:59, Matching.h:66, 1PointRansac.h:42, Update.h:48,
+// EKF.cpp:68).  FRAME: cv::Mat (image in, matcher mode B) or FrameKeypoints (the host ran the detector).
+template <class FRAME>
+static EkfStepInfo reference_step_sequence(State &state, Matd &stateCovarianceMatrix, const FRAME &image)
+{
+    VectorImageFeaturePrediction predictedDistortedFeatures;
+    VectorMatd predictedFeatureJacobians;
+    stateAndCovariancePrediction(state, stateCovarianceMatrix);
+    std::vector<int> mapFeatureIndexes;
+    VectorMapFeature unseenFeatures;
+    predictCameraMeasurements(state, stateCovarianceMatrix, state.mapFeatures, mapFeatureIndexes, predictedDistortedFeatures,
+                              predictedFeatureJacobians, unseenFeatures);
+    VectorFeatureMatch matches;
+    matchPredictedFeatures(image, state.mapFeatures, predictedDistortedFeatures, matches);
+    VectorImageFeaturePrediction predictedMatchedFeatures;
+    VectorMatd predictedMatchedJacobians;
+    for (size_t i = 0; i < matches.size(); ++i)
+        for (size_t k = 0; k < predictedDistortedFeatures.size(); ++k)
+            if (predictedDistortedFeatures[k]->featureIndex == matches[i]->featureIndex) {
+                predictedMatchedFeatures.push_back(predictedDistortedFeatures[k]);
+                predictedMatchedJacobians.push_back(predictedFeatureJacobians[k]);
+                break;
+            }
+    VectorFeatureMatch inlierMatches, outlierMatches;
+    VectorImageFeaturePrediction inlierPredictions;
+    VectorMatd inlierJacobians;
+    ransac(state, stateCovarianceMatrix, predictedMatchedFeatures, predictedMatchedJacobians, matches, inlierMatches, inlierPredictions,
+           inlierJacobians, outlierMatches);
+    update(state, stateCovarianceMatrix, inlierMatches, inlierPredictions, inlierJacobians);
+    VectorMapFeature outlierFeatures, unseenOutliers;
+    std::vector<int> outlierIndexes;
+    for (size_t i = 0; i < outlierMatches.size(); ++i) {
+        outlierFeatures.push_back(state.mapFeatures[outlierMatches[i]->featureIndex]);
+        outlierIndexes.push_back(outlierMatches[i]->featureIndex);
+    }
+    VectorImageFeaturePrediction outlierPredictions;
+    VectorMatd outlierJacobians;
+    if (!outlierFeatures.empty())
+        predictCameraMeasurements(state, stateCovarianceMatrix, outlierFeatures, outlierIndexes, outlierPredictions, outlierJacobians, unseenOutliers);
+    if (!outlierPredictions.empty() && outlierPredictions.size() < outlierMatches.size()) {
+        VectorFeatureMatch kept;
+        size_t j = 0;
+        for (size_t i = 0; i < outlierMatches.size() && j < outlierPredictions.size(); ++i)
+            if (outlierMatches[i]->featureIndex == outlierPredictions[j]->featureIndex) { ++j; kept.push_back(outlierMatches[i]); }
+        outlierMatches = kept;
+    }
+    VectorFeatureMatch rescuedMatches;
+    VectorImageFeaturePrediction rescuedPredictions;
+    VectorMatd rescuedJacobians;
+    if (!outlierMatches.empty() && !outlierPredictions.empty())
+        rescueOutliers(outlierMatches, outlierPredictions, outlierJacobians, rescuedMatches, rescuedPredictions, rescuedJacobians);
+    if (!rescuedMatches.empty()) update(state, stateCovarianceMatrix, rescuedMatches, rescuedPredictions, rescuedJacobians);
+    EkfStepInfo info;
+    std::memset(&info, 0, sizeof(info));
+    info.n_predicted = (int)predictedDistortedFeatures.size();
+    info.n_matches = (int)matches.size();
+    info.n_hypotheses = -1;
+    info.n_inliers = (int)inlierMatches.size();
+    info.n_rescued = (int)rescuedMatches.size();
+    for (size_t i = 0; i < predictedDistortedFeatures.size(); ++i) delete predictedDistortedFeatures[i];
+    for (size_t i = 0; i < predictedFeatureJacobians.size(); ++i) delete predictedFeatureJacobians[i];
+    for (size_t i = 0; i < outlierPredictions.size(); ++i) delete outlierPredictions[i];
+    for (size_t i = 0; i < outlierJacobians.size(); ++i) delete outlierJacobians[i];
+    for (size_t i = 0; i < matches.size(); ++i) delete matches[i];
+    return info;
 }
 
 int main(int argc, char **argv)
@@ -66,6 +140,21 @@ int main(int argc, char **argv)
         frames[t].descriptors.resize((size_t)K * EKF_DESC_BYTES);
         rd(f, frames[t].keypoints.data(), K);
         rd(f, frames[t].descriptors.data(), (size_t)K * EKF_DESC_BYTES);
+    }
+    // optional: rendered frames for the image-taking matcher -- width, height, then nframes + 1 gray images (t = 0 is the frame the
+    // templates are cut from) and the features' pixels in it
+    int32_t W = 0, H = 0;
+    std::vector<std::vector<unsigned char> > images;
+    std::vector<double> uv0;
+    if (fread(&W, sizeof(W), 1, f) == 1 && W > 0) {
+        rd(f, &H, 1);
+        images.resize(nframes + 1);
+        for (int t = 0; t <= nframes; ++t) {
+            images[t].resize((size_t)W * H);
+            rd(f, images[t].data(), images[t].size());
+        }
+        uv0.resize(2 * (size_t)N);
+        rd(f, uv0.data(), uv0.size());
     }
     std::fclose(f);
     try {
@@ -161,6 +250,44 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < oP.size(); ++i) delete oP[i];
         for (size_t i = 0; i < oJ.size(); ++i) delete oJ[i];
         for (size_t i = 0; i < matches.size(); ++i) delete matches[i];
+        // (4) the same frame through the reference's own signatures, resident mode
+        {
+            ekf_compat::Context &ctx = ekf_compat::Context::instance();
+            ctx.configure(cam, par, N + 8);
+            State st(seed);
+            Matd Pm = P0;
+            const unsigned long gen0 = Pm.hostGeneration();
+            const EkfStepInfo si = reference_step_sequence(st, Pm, frames[0]);
+            const long uploads = ctx.covarianceUploads();
+            const int stale = Pm.staleOnHost() ? 1 : 0, untouched = Pm.hostGeneration() == gen0 ? 1 : 0;
+            report("sequence", st, Pm, &si); // (reads P: pulled from the device here, once)
+            std::printf("sequence_aux covariance_uploads %ld stale_before_read %d host_untouched %d stale_after_read %d\n", uploads, stale,
+                        untouched, Pm.staleOnHost() ? 1 : 0);
+            // a host write to the covariance must reach the device before the next stage: scale P, predict, compare with the class path
+            for (int i = 0; i < Pm.rows; ++i)
+                for (int j = 0; j < Pm.cols; ++j) Pm[i][j] *= 1.0; // (a write as far as the wrapper can tell)
+            stateAndCovariancePrediction(st, Pm);
+            std::printf("sequence_aux2 covariance_uploads %ld\n", ctx.covarianceUploads());
+        }
+        // (5) image in: matchPredictedFeatures(const cv::Mat &, ...), matcher mode B
+        if (!images.empty()) {
+            ekf_compat::Context &ctx = ekf_compat::Context::instance();
+            ctx.configure(cam, par, N + 8);
+            State st(seed);
+            Matd Pm = P0;
+            std::vector<int32_t> idx(N);
+            for (int i = 0; i < N; ++i) idx[i] = i;
+            // the filter must be on the device before templates can be cut for its features
+            VectorImageFeaturePrediction pp;
+            VectorMapFeature un;
+            predictMeasurementState(st, st.mapFeatures, std::vector<int>(), pp, un);
+            for (size_t i = 0; i < pp.size(); ++i) delete pp[i];
+            ctx.captureTemplates(cv::Mat(H, W, 1, images[0].data()), idx, uv0);
+            const cv::Mat image(H, W, 1, images[1].data());
+            const EkfStepInfo si = reference_step_sequence(st, Pm, image);
+            report("sequence_image", st, Pm, &si);
+            std::printf("sequence_image_aux covariance_uploads %ld\n", ctx.covarianceUploads());
+        }
     } catch (const ekf_compat::Error &e) {
         std::fprintf(stderr, "ekf_compat error %d: %s\n", e.code, e.what());
         return 1;

@@ -33,6 +33,14 @@ def write_scenario(path, seq):
             f.write(np.array([len(kps)], dtype=np.int32).tobytes())
             f.write(np.ascontiguousarray(kps).tobytes())
             f.write(np.ascontiguousarray(desc, dtype=np.uint8).tobytes())
+        # rendered frames for the image-taking matchPredictedFeatures(const cv::Mat &, ...): t = 0 (templates) .. len(frames)
+        imgs = [seq.render_image(t) for t in range(len(seq.frames) + 1)]
+        h, w = imgs[0].shape[:2]
+        f.write(np.array([w, h], dtype=np.int32).tobytes())
+        for im in imgs:
+            assert im.ndim == 2 and im.dtype == np.uint8
+            f.write(np.ascontiguousarray(im).tobytes())
+        f.write(np.ascontiguousarray(seq.pixel_positions(0), dtype=np.float64).tobytes())
 
 
 def parse(line):
@@ -60,8 +68,9 @@ def test_compat_class_and_functions_match_ctypes_and_oracle(tmp_path, oracle_lib
     scen = os.path.join(str(tmp_path), "scenario.bin")
     write_scenario(scen, seq)
     out = subprocess.run([exe, scen], check=True, capture_output=True, text=True).stdout.strip().splitlines()
-    res = {ln.split()[0]: parse(ln) for ln in out if ln.startswith(("class", "functions", "mapmgmt "))}
-    assert set(res) == {"class", "functions", "mapmgmt"}
+    res = {ln.split()[0]: parse(ln) for ln in out if ln.startswith(("class", "functions", "mapmgmt ", "sequence ", "sequence_image "))}
+    assert set(res) == {"class", "functions", "mapmgmt", "sequence", "sequence_image"}
+    seq_aux = {ln.split()[0]: ln.split()[1:] for ln in out if ln.startswith(("sequence_aux", "sequence_image_aux"))}
     aux = [ln for ln in out if ln.startswith("mapmgmt_aux")][0].split()
 
     e = engine.EkfEngine(seq.cam, seq.par, 32, max_keypoints=256)
@@ -107,3 +116,27 @@ def test_compat_class_and_functions_match_ctypes_and_oracle(tmp_path, oracle_lib
     np.testing.assert_allclose(xf, xo, rtol=1e-8, atol=1e-10)
     assert abs(frof - np.linalg.norm(Po)) <= 1e-8 * frof
     assert (io.n_matches, io.n_inliers, io.n_rescued) == (cf[1], cf[3], cf[4])
+    # the call sequence of EKF.cpp:273-531 under the reference's OWN signatures (4-argument matchPredictedFeatures), resident mode:
+    # the same numbers as the explicit-filter form -- bitwise: the same device calls in the same order, only fewer transfers -- and
+    # the covariance went to the device ONCE for the eight stage calls, came back on the first host access, and went up again only
+    # after the host wrote to it
+    xs, trs, fros, cs = res["sequence"]
+    np.testing.assert_array_equal(xs, xf)
+    assert trs == trf and fros == frof and cs == cf
+    a = seq_aux["sequence_aux"]
+    assert dict(zip(a[0::2], map(int, a[1::2]))) == {"covariance_uploads": 1, "stale_before_read": 1, "host_untouched": 1, "stale_after_read": 0}
+    assert int(seq_aux["sequence_aux2"][1]) == 2
+    # image in: matchPredictedFeatures(const cv::Mat &, features, predictions, matches) = matcher mode B; against ekf_step_image
+    # through ctypes on the same frames
+    e3 = engine.EkfEngine(seq.cam, seq.par, 32, max_keypoints=256)
+    e3.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    e3.upload_image(seq.render_image(0))
+    e3.capture_templates(np.arange(seq.n_features), seq.pixel_positions(0).astype(np.float64))
+    i3 = e3.step_image(seq.render_image(1))
+    x3, _, P3 = e3.get_state()
+    xi, tri, froi, ci = res["sequence_image"]
+    np.testing.assert_allclose(xi, x3, rtol=1e-12, atol=1e-15)
+    assert abs(tri - np.trace(P3)) <= 1e-12 * abs(tri) and abs(froi - np.linalg.norm(P3)) <= 1e-12 * froi
+    assert (ci[0], ci[1], ci[3], ci[4]) == (i3.n_predicted, i3.n_matches, i3.n_inliers, i3.n_rescued)
+    assert i3.n_matches > 0.5 * seq.n_features
+    assert int(seq_aux["sequence_image_aux"][1]) == 1
