@@ -82,8 +82,11 @@ private:
 
 // ---------------------------------------------------------------------------------------------------- matrices
 class Matd;
+class State;
 namespace ekf_compat {
 inline void pull_matrix(const Matd *m); // fills a stale matrix from the engine that holds its current value (below)
+inline void matrix_destroyed(const Matd *m); // the resident engine forgets a covariance / a state whose object goes away (below)
+inline void state_destroyed(const State *s);
 }
 
 // cv::Mat_<double> as the path uses it (Core/Base.h:171): an owning row-major matrix.  Resident mode (see the header): a
@@ -91,9 +94,10 @@ inline void pull_matrix(const Matd *m); // fills a stale matrix from the engine 
 class Matd {
 public:
     int rows, cols;
-    Matd() : rows(0), cols(0), gen_(0), stale_(false), src_(0) {}
-    Matd(int r, int c) : rows(r), cols(c), d_((size_t)r * c, 0.0), gen_(0), stale_(false), src_(0) {}
-    Matd(const Matd &o) : rows(0), cols(0), gen_(0), stale_(false), src_(0) { *this = o; }
+    Matd() : rows(0), cols(0), gen_(0), stale_(false), src_(0), tracked_(false) {}
+    Matd(int r, int c) : rows(r), cols(c), d_((size_t)r * c, 0.0), gen_(0), stale_(false), src_(0), tracked_(false) {}
+    Matd(const Matd &o) : rows(0), cols(0), gen_(0), stale_(false), src_(0), tracked_(false) { *this = o; }
+    ~Matd() { if (tracked_) ekf_compat::matrix_destroyed(this); }
     Matd &operator=(const Matd &o)
     {
         if (this == &o) return *this;
@@ -135,6 +139,7 @@ public:
     }
     void pulled() const { stale_ = false; src_ = 0; }
     void forget() const { stale_ = false; src_ = 0; }              // the holder went away with a copy nobody asked for
+    void setTracked(bool t) const { tracked_ = t; }                // the resident engine holds a pointer to this object
 
 private:
     void hostRead() const { if (stale_) ekf_compat::pull_matrix(this); }
@@ -143,6 +148,7 @@ private:
     unsigned long gen_;
     mutable bool stale_;
     mutable EkfEngine *src_;
+    mutable bool tracked_;
 };
 typedef std::vector<Matd *> VectorMatd;
 
@@ -203,7 +209,12 @@ public:
         std::memcpy(R_, o.R_, sizeof(R_));
         for (size_t i = 0; i < o.mapFeatures.size(); ++i) addFeature(new MapFeature(*o.mapFeatures[i]));
     }
-    ~State() { removeAllFeatures(); }
+    ~State()
+    {
+        if (tracked_) ekf_compat::state_destroyed(this);
+        removeAllFeatures();
+    }
+    void setTracked(bool t) const { tracked_ = t; } // the resident engine of the free functions holds a pointer to this object
     void setOrientation(const double *q)
     { // State.cpp:131-139: copies q, recomputes R, never normalises
         for (int i = 0; i < 4; ++i) orientation[i] = q[i];
@@ -236,6 +247,7 @@ private:
     State &operator=(const State &);
     void init()
     {
+        tracked_ = false;
         std::memset(x_, 0, sizeof(x_));
         position = x_;
         orientation = x_ + 3;
@@ -246,6 +258,7 @@ private:
         setOrientation(q);
     }
     double x_[13], R_[9];
+    mutable bool tracked_;
 };
 
 class ImageFeaturePrediction {
@@ -332,12 +345,28 @@ inline void download(EkfEngine *e, State &s, Matd *P)
 
 // Replaces the ConfigurationManager singleton (Configuration/ConfigurationManager.h:45-64) for the two PODs the
 // hot path reads.  One process-wide engine serves the free functions and remembers whose filter it holds.
+class Context;
+inline Context *&context_alive() // the singleton while it exists (objects destroyed after it must not call into it)
+{
+    static Context *p = 0;
+    return p;
+}
+
 class Context {
 public:
     static Context &instance()
     {
         static Context c;
         return c;
+    }
+    // the caller's objects went out of scope: the engine keeps the filter, but no pointer to them
+    void forgetMatrix(const Matd *m)
+    {
+        if (rP_ == m) { rP_ = 0; live_ = false; }
+    }
+    void forgetState(const State *s)
+    {
+        if (rs_ == s) { rs_ = 0; live_ = false; }
     }
     void configure(const EkfCamera &cam, const EkfParams &par, int maxFeatures, int precision = EKF_PRECISION_F64)
     {
@@ -367,12 +396,15 @@ public:
         if (e_) ekf_engine_destroy(e_);
         e_ = 0;
         live_ = false;
-        rs_ = 0;
-        rP_ = 0;
+        track(0, 0);
         covUploads_ = 0;
         featGen_.clear();
     }
-    ~Context() { release(); }
+    ~Context()
+    {
+        release();
+        context_alive() = 0;
+    }
 
     // ---- resident mode -----------------------------------------------------------------------------------------------------
     // Makes the engine hold the caller's (state, P): nothing moves when it already does (same objects, no host write since).
@@ -387,12 +419,12 @@ public:
             if (rP_ && rP_ != P && rP_->staleOnHost() && rP_->holder() == e) pull_matrix(rP_); // somebody else's matrix: hand it back first
             upload(e, s, P); // (reads P: a matrix that is stale from THIS engine is pulled by the access and uploaded again)
             ++covUploads_;
-            rP_ = P;
+            track(&s, P);
             pgen_ = P->hostGeneration();
         } else {
             upload(e, s, 0); // the state was edited on the host (or is another object); the device covariance stays
+            track(&s, rP_);
         }
-        rs_ = &s;
         live_ = true;
         takeSnapshot(s);
         ++devGen_; // every device table is older than this filter
@@ -432,7 +464,16 @@ public:
     }
 
 private:
-    Context() : e_(0), live_(false), rs_(0), rP_(0), pgen_(0), devGen_(1), covUploads_(0) {}
+    Context() : e_(0), live_(false), rs_(0), rP_(0), pgen_(0), devGen_(1), covUploads_(0) { context_alive() = this; }
+    void track(const State *s, const Matd *P)
+    {
+        if (rs_ && rs_ != s) rs_->setTracked(false);
+        if (rP_ && rP_ != P) rP_->setTracked(false);
+        rs_ = s;
+        rP_ = P;
+        if (rs_) rs_->setTracked(true);
+        if (rP_) rP_->setTracked(true);
+    }
     void takeSnapshot(const State &s)
     {
         snap_.assign(s.x13(), s.x13() + 13);
@@ -465,6 +506,15 @@ private:
     std::vector<unsigned long> featGen_;
     long covUploads_;
 };
+
+inline void matrix_destroyed(const Matd *m)
+{
+    if (context_alive()) context_alive()->forgetMatrix(m);
+}
+inline void state_destroyed(const State *s)
+{
+    if (context_alive()) context_alive()->forgetState(s);
+}
 
 inline std::vector<EkfMatch> packMatches(const VectorFeatureMatch &m)
 {

@@ -272,7 +272,6 @@ def test_in_stream_exchange_with_several_ranks_through_a_mock_rccl(eng_mod, tmp_
     st = d["stats"]
     assert all(s_["mismatches"] == 0 for s_ in st)
     assert all(s_["groups"] == st[0]["groups"] and s_["groups"] > 0 for s_ in st)  # the exchange is collective
-    assert all(s_["sends"] == s_["recvs"] or world > 2 for s_ in st)
     assert sum(s_["sent"] for s_ in st) == sum(s_["received"] for s_ in st) > 0
     # a rank sends its block to EVERY peer: what it sends is (world - 1) x its share; what rank 0 receives is what the callback
     # transport pulled for rank 0
