@@ -376,6 +376,10 @@ k_p_update_i8(float *P, int ldp, int n, const int8_t *Bq, int ldq, size_t plane_
 #ifndef PX_ZERO_C
 #define PX_ZERO_C 1 // k_p_update_i8p: start a unit's accumulators with C = 0 in the first step's products instead of zeroing 160 registers
 #endif
+#ifndef PX_STORE_SLACK
+#define PX_STORE_SLACK 0 // k_p_update_i8p: 1 = no vmcnt wait in the first two steps behind an epilogue (its stores get two steps to drain);
+                         // measured: no difference (profiles/r06_pu_i8_dual.txt) -- off
+#endif
 #ifndef PX_PRIO
 #define PX_PRIO 0   // k_p_update_i8p: raised wave priority around the products of a step (measured)
 #endif
@@ -556,11 +560,17 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[x][L][r] = 0;
 #endif
-#define PXP_STEP(FULL_, FIRST_)                                                                                               \
+#define PXP_STEP(FULL_, FIRST_, T_)                                                                                           \
     {                                                                                                                         \
-        /* step g has landed (this wavefront's pieces): everything but the PX_S loads of step g + 1 is complete */            \
-        if (g + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PX_S) : "memory");                                        \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                 \
+        /* step g has landed (this wavefront's pieces): everything but the PX_S loads of step g + 1 is complete.           */ \
+        /* The first two steps of a unit behind an epilogue need no wait: their slabs were requested before that epilogue  */ \
+        /* and the epilogue waited for its old values of P, which are YOUNGER requests (the counter retires in order) --   */ \
+        /* and a wait here would be a wait for the epilogue's STORES (vmcnt counts them too): the first step of every unit */ \
+        /* stood until ~27 of its predecessor's 32 sixteen-byte stores had been acknowledged.                              */ \
+        if (!(PX_STORE_SLACK && ui > 0 && (T_) < 2 && !(PX_ABL & 1))) {                                                       \
+            if (g + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PX_S) : "memory");                                    \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                             \
+        }                                                                                                                     \
         if (!(PX_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); /* everyone's have; everyone has left buffer g - 1 */  \
         /* wavefronts w and w + 4 share a SIMD: one of them requests its pieces of step g + 2 before its products, the   */    \
         /* other after them, so that one multiplies while the other issues (an LDS-DMA costs 60-180 issue cycles)      */    \
@@ -572,8 +582,8 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
         ++g;                                                                                                                  \
     }
 #define PXP_LOOP(FULL_)                                                                                                       \
-    PXP_STEP(FULL_, (PX_ZERO_C != 0))                                                                                         \
-    for (int t = 1; t < nk; ++t) PXP_STEP(FULL_, false)
+    PXP_STEP(FULL_, (PX_ZERO_C != 0), 0)                                                                                      \
+    for (int t = 1; t < nk; ++t) PXP_STEP(FULL_, false, t)
         if (full) { PXP_LOOP(true) } else { PXP_LOOP(false) }
 #undef PXP_LOOP
 #undef PXP_STEP

@@ -1,0 +1,69 @@
+"""Two PROCESSES, one GPU, each stepping its own N = 1000 filter (EKF_PRECISION_F32_EXACT, persistent Cholesky sweep) for `frames`
+frames at the same time: the situation in which a persistent sweep may find the other process's workgroups on the CUs it needs,
+time out, and -- round 6 -- be run again on the launch-per-panel path without the caller seeing anything
+(csrc/engine.cpp: recover_failed_update).  Each worker reports the errors that surfaced (must be none), its retry count and a
+checksum of its final state; the parent checks that both filters ended bitwise where a filter running ALONE ends.
+    python scripts/two_processes_one_gpu.py [frames=200] [N=1000]"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def worker(frames, N, tag):
+    import numpy as np
+
+    from openekfmonoslam_amd import engine
+    from openekfmonoslam_amd.synth import SyntheticSequence
+
+    seq = SyntheticSequence(N, frames)
+    e = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=engine.PRECISION_F32_EXACT)
+    e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    e.upload_frames(seq.frames)
+    e.set_async_errors(True)
+    errors, retries_in_info, t0 = [], 0, time.perf_counter()
+    for t in range(frames):
+        try:
+            i = e.step_frame(t)
+            retries_in_info += i.n_sweep_retries
+            if i.status:
+                errors.append((t, int(i.status)))
+        except engine.EkfError as ex:
+            errors.append((t, ex.code))
+    try:
+        e.synchronize()
+    except engine.EkfError as ex:
+        errors.append((frames, ex.code))
+    dt = time.perf_counter() - t0
+    x, fp, P = e.get_state()
+    h = hashlib.sha256(np.ascontiguousarray(x).tobytes() + np.ascontiguousarray(fp).tobytes() + np.ascontiguousarray(P).tobytes()).hexdigest()
+    print(json.dumps({"tag": tag, "frames": frames, "errors": errors, "sweep_retries": e.sweep_retries, "retries_in_step_info": retries_in_info,
+                      "updates_per_s": frames / dt, "state_sha256": h}))
+
+
+def main():
+    if len(sys.argv) > 3 and sys.argv[1] == "--worker":
+        return worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+
+    def run(tags):
+        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(frames), str(N), t], stdout=subprocess.PIPE, text=True)
+              for t in tags]
+        return [json.loads([ln for ln in p.communicate()[0].splitlines() if ln.startswith("{")][-1]) for p in ps]
+
+    alone = run(["alone"])[0]
+    both = run(["a", "b"])
+    ok = (not alone["errors"] and all(not b["errors"] for b in both)
+          and all(b["state_sha256"] == alone["state_sha256"] for b in both))
+    print(json.dumps({"alone": alone, "together": both, "no_error_surfaced_and_bitwise_equal_to_alone": ok}, indent=1))
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
