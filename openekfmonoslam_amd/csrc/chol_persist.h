@@ -36,7 +36,7 @@ struct SweepCtl {
 };
 constexpr int PS_NBC = B_SWEEP_MAX / NB + 2;        // block rows of the flag tables: 64 panels + the nu row + 1
 constexpr unsigned PS_EPOCH_STEP = 128;             // flag values of one sweep stay below this
-constexpr long long PS_TIMEOUT_TICKS = 3000000ll;   // 30 ms of the 100 MHz constant clock
+constexpr long long PS_TIMEOUT_TICKS = 500000ll;    // 5 ms of the 100 MHz constant clock (a sweep of 2048 rows takes ~1 ms; round 5: 30 ms)
 constexpr int PS_BATCH = 4;                         // panels a tile worker applies to one tile per task in the L form
 constexpr int PS_CACHE = 4;                         // tiles a tile worker keeps in LDS between their panels (the rest live in S)
 inline size_t sweep_ctl_bytes() { return sizeof(SweepCtl) + sizeof(unsigned) * 2 * PS_NBC * PS_NBC; }

@@ -1320,6 +1320,9 @@ static int recover_failed_update(EkfEngine *e, int *status)
     e->h_counts[CNT_ERR] = 0;
     e->p_exact_sym = e->last_update_sym; // (the frozen downdate did not symmetrise an uploaded P)
     if (code == EKF_ERR_TIMEOUT && e->last_update_persist && e->last_update_M > 0) {
+        e->ps_backoff_len = std::min(std::max(64, 2 * e->ps_backoff_len), 4096); // see engine.h
+        e->ps_backoff = e->ps_backoff_len;
+        e->ps_ok_streak = 0;
         ++e->force_launches;
         int rc = update_dev(e, e->last_update_M, e->last_update_cov, false);
         --e->force_launches;

@@ -236,6 +236,10 @@ struct EkfEngine {
     // filter untouched (filter_frozen), so the update is run again from the same P on the launch-per-panel sweep
     int force_launches = 0;               // > 0: updates use the launch-per-panel sweep whatever sweep_mode says (the retry itself)
     int sweep_retries = 0;                // updates re-run this way since the engine was created (ekf_get_sweep_retries)
+    // back-off (EKF_SWEEP_AUTO only): a device that another process shares makes persistent sweeps time out again and again, 5 ms each;
+    // after a time-out the next ps_backoff updates take the launch-per-panel sweep, twice as many after every further time-out (64 ..
+    // 4096), and 256 persistent sweeps in a row without one forget the history
+    int ps_backoff = 0, ps_backoff_len = 0, ps_ok_streak = 0;
     int last_update_M = 0;                // matches of the last update enqueued (its list is still in d.msel)
     bool last_update_cov = true;          // ... a covariance update (false: updateOnlyState)
     bool last_update_sym = false;         // p_exact_sym as it was before that update

@@ -1655,12 +1655,17 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
     // on, where the launch-per-panel sweep switches to two panels per launch) its B workers take several blocks each and it loses:
     // N = 2000, 20.4 against 14.0 us per panel (profiles/r05_bench_n2000_f32x_persistent.json)
     if (persist && sweep_mode == EKF_SWEEP_AUTO && n_pad >= 8192) persist = false;
+    if (persist && sweep_mode == EKF_SWEEP_AUTO && e->ps_backoff > 0) { // recent time-outs (a shared device): engine.h
+        --e->ps_backoff;
+        persist = false;
+    }
     // its grid must fit the device's resident workgroups -- decided HERE, before the gather / assembly launch leaves the first
     // block's factorisation to the chain workgroup (a device partition with few CUs: the launch-per-panel sweep instead)
     PsLayout ps_layout{};
     if constexpr (sizeof(TB) == 8) {
         if (persist) persist = planes_b ? persist_layout<true>(e, m, cb1 - cb0, ps_layout) : persist_layout<false>(e, m, n_pad / NB, ps_layout);
     } else persist = false;
+    if (persist && ++e->ps_ok_streak >= 256) e->ps_backoff_len = 0;
     e->last_update_M = M; // what a retry needs (engine.cpp: recover_failed_update)
     e->last_update_cov = update_cov;
     e->last_update_sym = e->p_exact_sym;

@@ -3,7 +3,11 @@ frames at the same time: the situation in which a persistent sweep may find the 
 time out, and -- round 6 -- be run again on the launch-per-panel path without the caller seeing anything
 (csrc/engine.cpp: recover_failed_update).  Each worker reports the errors that surfaced (must be none), its retry count and a
 checksum of its final state; the parent checks that both filters ended bitwise where a filter running ALONE ends.
-    python scripts/two_processes_one_gpu.py [frames=200] [N=1000]"""
+A retried update runs the launch-per-panel sweep -- the same arithmetic in another order of fp64 operations -- so the filters agree to
+rounding, not bitwise: 1e-8 for the fp64 engine; for the fp32-stored one the comparison is held to 1e-4 at 200 frames, the drift horizon
+of fp32 storage itself (two fp32-stored filters that differ in one rounding are 1e-5 ... 6e-5 apart after 175-250 frames, DESIGN.md
+section 6 item 4).
+    python scripts/two_processes_one_gpu.py [frames=200] [N=1000] [precision=2]"""
 import hashlib
 import json
 import os
@@ -15,14 +19,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def worker(frames, N, tag):
+def worker(frames, N, tag, precision):
     import numpy as np
 
     from openekfmonoslam_amd import engine
     from openekfmonoslam_amd.synth import SyntheticSequence
 
     seq = SyntheticSequence(N, frames)
-    e = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=engine.PRECISION_F32_EXACT)
+    e = engine.EkfEngine(seq.cam, seq.par, N, max_keypoints=len(seq.frames[0][0]) + 64, precision=precision)
     e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
     e.upload_frames(seq.frames)
     e.set_async_errors(True)
@@ -42,26 +46,43 @@ def worker(frames, N, tag):
     dt = time.perf_counter() - t0
     x, fp, P = e.get_state()
     h = hashlib.sha256(np.ascontiguousarray(x).tobytes() + np.ascontiguousarray(fp).tobytes() + np.ascontiguousarray(P).tobytes()).hexdigest()
+    np.savez(f"/tmp/two_proc_{tag}.npz", x=x, fp=fp, P=P)
     print(json.dumps({"tag": tag, "frames": frames, "errors": errors, "sweep_retries": e.sweep_retries, "retries_in_step_info": retries_in_info,
                       "updates_per_s": frames / dt, "state_sha256": h}))
 
 
 def main():
     if len(sys.argv) > 3 and sys.argv[1] == "--worker":
-        return worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+        return worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]))
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    precision = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    tol = 1e-8 if precision == 0 else 1e-4
 
     def run(tags):
-        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(frames), str(N), t], stdout=subprocess.PIPE, text=True)
+        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(frames), str(N), t, str(precision)], stdout=subprocess.PIPE, text=True)
               for t in tags]
         return [json.loads([ln for ln in p.communicate()[0].splitlines() if ln.startswith("{")][-1]) for p in ps]
 
     alone = run(["alone"])[0]
     both = run(["a", "b"])
-    ok = (not alone["errors"] and all(not b["errors"] for b in both)
-          and all(b["state_sha256"] == alone["state_sha256"] for b in both))
-    print(json.dumps({"alone": alone, "together": both, "no_error_surfaced_and_bitwise_equal_to_alone": ok}, indent=1))
+    # a retried update runs the launch-per-panel sweep: the same arithmetic in another order of fp64 operations, so the filters agree
+    # to rounding, not bitwise (bitwise only when nothing was retried)
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from parity_metric import over_tolerance, parity_report
+
+    ref = np.load("/tmp/two_proc_alone.npz")
+    diffs = []
+    for b in both:
+        z = np.load(f"/tmp/two_proc_{b['tag']}.npz")
+        be = parity_report(z["x"], z["fp"], z["P"], ref["x"], ref["fp"], ref["P"])
+        diffs.append({"worst": max(be.values()), "tolerance": tol, "over_tolerance": over_tolerance(be, tol, N, componentwise=True)})
+    # (not bitwise even without a retry: the persistent sweep's tile workers take a panel in its L form or its S form by what is
+    # published when they look -- the same mathematics in an order that depends on timing, 1e-13 apart in fp64)
+    ok = not alone["errors"] and all(not b["errors"] for b in both) and all(not d["over_tolerance"] for d in diffs)
+    print(json.dumps({"alone": alone, "together": both, "difference_to_alone": diffs, "precision": precision, "no_error_surfaced_and_within_tolerance_of_alone": ok}, indent=1))
     sys.exit(0 if ok else 1)
 
 
