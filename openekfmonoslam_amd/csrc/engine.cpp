@@ -136,7 +136,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
                     d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.W, d.Wf, d.G, d.LL, d.LLf, d.Tbuf, d.gates, d.cell_resp, d.cell_xy,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.sq_part, d.diag_save, d.cam_part, d.cam_save, d.HPc, d.Gc, d.Bc, d.zvec, d.yvec,
-                    e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq, d.sweep_ctl, d.pu_ctr, d.Bq, d.Bexp, d.Lq, d.Lexp, d.Grow, d.Pdiag, d.Bstage, d.Wq, d.Gq, d.Wexp, d.Gexp};
+                    e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq, d.sweep_ctl, d.pu_ctr, d.Bq, d.Bexp, d.Bz, d.Lq, d.Lexp, d.Grow, d.Pdiag, d.Bstage, d.Wq, d.Gq, d.Wexp, d.Gexp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &kv : e->pu_tables)
@@ -267,6 +267,8 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
             e->bq_rows = round_up((int)mcap, 64) + 64;
             if ((st = dalloc(&d.Bq, (size_t)PX_S * e->bq_rows * e->ldP)) != hipSuccess) return fail(st, "hipMalloc Bq");
             if ((st = dalloc(&d.Bexp, (size_t)e->ldP)) != hipSuccess) return fail(st, "hipMalloc Bexp");
+            e->bz_stride = e->bq_rows / 16;
+            if ((st = dalloc(&d.Bz, (size_t)(e->ldP / 32 + 8) * e->bz_stride)) != hipSuccess) return fail(st, "hipMalloc Bz");
             {   // rows of B from digit planes (chol_bplanes.h): planes of L for the sweeps that form B
                 e->lq_nbk = (std::min((int)mcap, B_SWEEP_MAX) + NB - 1) / NB + 2;
                 if ((st = dalloc(&d.Lq, (size_t)PX_S * e->lq_nbk * e->lq_nbk * 1024)) != hipSuccess) return fail(st, "hipMalloc Lq");

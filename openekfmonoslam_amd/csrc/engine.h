@@ -145,6 +145,8 @@ struct DeviceArrays {
     unsigned *pu_ctr = nullptr; // exact downdate, two workgroups per CU (k_p_update_i8d): unit counters, two sets of eight (one per XCD list)
     int8_t *Bq = nullptr;       // EKF_PRECISION_F32_EXACT: PX_S digit planes of B, each [bq_rows / 16][ldP][16] bytes (kernels_pexact.hip)
     int *Bexp = nullptr;        // its column scales (biased exponents), ldP ints
+    uint8_t *Bz = nullptr;      // ... and which 16-row x 32-column pieces of digit plane 0 hold anything but zeros: [column / 32][bz_stride] bytes
+                                // (written with the planes' last reader before the downdate, k_dx_planes / k_slice_B; read by k_p_update_i8p)
     int8_t *Lq = nullptr;       // digit planes of L for the rows of B formed from planes (chol_bplanes.h): PX_S x lq_nbk^2 KB
     int *Lexp = nullptr;        // row scales of L (biased exponents)
     int *Grow = nullptr;        // row of the H P table behind every gathered row (k_gather without the copy)
@@ -257,6 +259,7 @@ struct EkfEngine {
     std::map<long long, std::pair<void *, int>> pu_tables; // built work lists of the downdate: key -> (device list, units per XCD)
     int pu_per_xcd = 0;
     int bq_rows = 0;          // rows of B a digit plane holds (multiple of 64)
+    int bz_stride = 0;        // 16-row groups per column block of d.Bz (= bq_rows / 16)
     int lq_nbk = 0;           // 32-row blocks per side of the digit planes of L
     int bstage_rows = 0;      // rows of B the exchange image of the planes holds (sharded exact configuration)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> px_events; // exact configuration: end of the sweep -> start of the downdate (inverse, GEMM, digit planes, dx, state)

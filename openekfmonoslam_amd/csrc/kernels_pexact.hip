@@ -64,18 +64,39 @@ k_col_exp(const double *B, int ld, int m, int n_pad, const double *Bc, int *bexp
     if (hi >> 20) atomicMax(&bexp[j], hi >> 20);
 }
 
+// ------------------------------------------------------------------------------------------------ zero pieces of plane 0
+// Digit plane 0 holds the top byte of the 38-bit integers.  A column's scale is set by its largest entry -- a feature's own measurement
+// rows, ~300 x its typical entry -- so for everything else the top byte is 0: on the bench's N = 1000 frames 99.8 % of plane 0 is zero
+// and only 13 % (low-innovation update) / 33 % (high-innovation update) of its 32-row x 32-column pieces hold anything at all.  Nine
+// of the downdate's fifteen digit products have a plane-0 operand; a product whose operand piece is all zeros adds exact zeros, so the
+// downdate skips it (k_p_update_i8p: 30 -> ~14-18 MFMAs per step and wavefront) -- same integer sums, bit for bit.  This table says
+// which pieces are not all zero: one byte per (32-column block, 16-row group), written by the last pass over the planes before the
+// downdate (k_dx_planes; k_slice_B where the planes are cut from an fp64 B) -- every byte a launch of the downdate reads was written
+// by that pass of the same update.  Called by all (active) lanes of a wavefront whose lanes 0..31 / 32..63 hold 32 consecutive
+// columns each, for one 16-row group kb.
+__device__ __forceinline__ void px_flag_plane0(uint8_t *bz, int bz_stride, int col, int kb, bool nonzero)
+{
+    const unsigned long long bal = __ballot(nonzero);
+    const int lane = threadIdx.x & 63;
+    const unsigned half = (unsigned)(bal >> (lane & 32));
+    const unsigned long long act = __ballot(true);
+    // the first active lane of each half writes (the last block of columns may be ragged)
+    const unsigned acth = (unsigned)(act >> (lane & 32));
+    if (acth != 0u && (lane & 31) == (int)__builtin_ctz(acth)) bz[(size_t)(col >> 5) * bz_stride + kb] = half != 0u ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------------ digit planes
 // One thread per (16-row group kb, column): reads B[16 kb .. 16 kb + 15][column] (the wavefront reads 512 contiguous bytes
 // per row), writes 16 bytes per plane at Bq[s][kb][column][0..15] (the wavefront writes 1 KB contiguous per plane).
 // Workgroup = 64 columns x 4 row groups; grid (n_pad / 64, m_k / 64).  Rows >= m are zero.
 __global__ void __launch_bounds__(256)
 k_slice_B(const double *B, int ld, int m, int m_k, const double *Bc, const int *bexp, int8_t *Bq, int ldq, size_t plane_stride, int c_lo,
-          int c_hi)
+          int c_hi, uint8_t *bz, int bz_stride)
 {
     const int col = (c_lo / 64) * 64 + blockIdx.x * 64 + (threadIdx.x & 63);
-    if (col < c_lo || col >= c_hi) return; // (row-sharded engines cut their own columns only)
     const int kb = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (kb * 16 >= m_k) return;
+    if (kb * 16 >= m_k) return; // (uniform in the wavefront)
+    if (col < c_lo || col >= c_hi) return; // (row-sharded engines cut their own columns only)
     const bool cam = Bc && col < 13;
     double v[16];
 #pragma unroll
@@ -103,6 +124,7 @@ k_slice_B(const double *B, int ld, int m, int m_k, const double *Bc, const int *
         uint4 o = make_uint4(w[s][0], w[s][1], w[s][2], w[s][3]);
         *(uint4 *)(Bq + (size_t)s * plane_stride + ((size_t)kb * ldq + col) * 16) = o;
     }
+    if (bz) px_flag_plane0(bz, bz_stride, col, kb, (w[0][0] | w[0][1] | w[0][2] | w[0][3]) != 0u);
 }
 
 // ------------------------------------------------------------------------------------------------ sharded filter
@@ -151,7 +173,7 @@ k_planes_move(int8_t *Bq, size_t b_stride, int ldq, int m16, int c_lo, int c_hi,
 
 __global__ void __launch_bounds__(256)
 k_dx_planes(const int8_t *Bq, size_t b_stride, int ldq, int m16, int n, const int *bexp, const double *z, double *part, int ldpart,
-            const double *st)
+            const double *st, uint8_t *bz, int bz_stride)
 {
     const int j = blockIdx.x * 256 + threadIdx.x, ks = blockIdx.y;
     // the quaternion as it is before this update, for k_apply_normalize (whose workgroups each need it while one of them rewrites it)
@@ -170,6 +192,8 @@ k_dx_planes(const int8_t *Bq, size_t b_stride, int ldq, int m16, int n, const in
         uint4 d[PX_S];
 #pragma unroll
         for (int s = 0; s < PX_S; ++s) d[s] = nx[s];
+        // (this pass sees every byte of the planes right before the downdate: it leaves the table of non-zero pieces of plane 0)
+        if (bz) px_flag_plane0(bz, bz_stride, j, kb, (d[0].x | d[0].y | d[0].z | d[0].w) != 0u);
         if (kb + 1 < kb1) {
 #pragma unroll
             for (int s = 0; s < PX_S; ++s) nx[s] = *(const uint4 *)(Bq + (size_t)s * b_stride + ((size_t)(kb + 1) * ldq + j) * 16);
@@ -194,7 +218,7 @@ void launch_slice_columns(EkfEngine *e, int m, int c_lo, int c_hi)
     if (c_hi <= c_lo) return;
     const int nb = (c_hi - (c_lo / 64) * 64 + 63) / 64;
     k_slice_B<<<dim3(nb, (m_k + 63) / 64), 256, 0, e->stream>>>((const double *)e->d.A, e->ldP, m, m_k, nullptr, e->d.Bexp, e->d.Bq, e->ldP,
-                                                              (size_t)e->bq_rows * e->ldP, c_lo, c_hi);
+                                                              (size_t)e->bq_rows * e->ldP, c_lo, c_hi, nullptr, 0);
 }
 
 void launch_diag_extract(EkfEngine *e, float *diag)
@@ -218,7 +242,7 @@ void launch_dx_planes(EkfEngine *e, int m_k)
 {
     const size_t b_stride = (size_t)e->bq_rows * e->ldP;
     k_dx_planes<<<dim3((e->n + 255) / 256, DX_SPLIT), 256, 0, e->stream>>>(e->d.Bq, b_stride, e->ldP, m_k / 16, e->n, e->d.Bexp, e->d.zvec,
-                                                                        e->d.dx_part, e->ldP, e->d.state);
+                                                                        e->d.dx_part, e->ldP, e->d.state, e->d.Bz, e->bz_stride);
 }
 
 // ------------------------------------------------------------------------------------------------ the downdate
@@ -376,6 +400,9 @@ k_p_update_i8(float *P, int ldp, int n, const int8_t *Bq, int ldq, size_t plane_
 #ifndef PX_ZERO_C
 #define PX_ZERO_C 1 // k_p_update_i8p: start a unit's accumulators with C = 0 in the first step's products instead of zeroing 160 registers
 #endif
+#ifndef PX_SKIP_ZERO
+#define PX_SKIP_ZERO 1 // k_p_update_i8p: leave out the products whose plane-0 operand piece is all zeros (px_flag_plane0, px_step_ring_z)
+#endif
 #ifndef PX_STORE_SLACK
 #define PX_STORE_SLACK 0 // k_p_update_i8p: 1 = no vmcnt wait in the first two steps behind an epilogue (its stores get two steps to drain);
                          // measured: no difference (profiles/r06_pu_i8_dual.txt) -- off
@@ -442,6 +469,67 @@ __device__ __forceinline__ void px_step_ring(unsigned ldsA, unsigned ldsB, v16i 
 #undef PX_GROUP
 }
 
+// The same step with the all-zero pieces of digit plane 0 left out (px_flag_plane0): za0 / za1 / zb say that the plane-0 piece of the
+// wavefront's first / second block of A rows / of its B columns is all zeros at this step -- then the five products a_0 b_t of that
+// block (the four a_s b_0, s >= 1) add exact zeros and are neither fetched nor multiplied: 12 MFMAs instead of 30 where all three
+// are zero (most steps: the non-zero pieces follow the matched features' own rows along a band).  Same sums, bit for bit.
+// LDS reads complete in order, so "all but the last k reads" does not care how many optional reads came before them.
+template <bool FULL>
+__device__ __forceinline__ void px_step_ring_z(unsigned ldsA, unsigned ldsB, v16i (&acc)[2][PX_S], bool za0, bool za1, bool zb)
+{
+    const v4i zero4 = {0, 0, 0, 0};
+    v4i b0 = zero4, b1, b2, b3, b4, a[2][2];
+    a[0][0] = zero4;
+    a[0][1] = zero4;
+    PX_DS_READ(b1, ldsB, 4096 + 8192);
+    PX_DS_READ(b2, ldsB, 4096 + 2 * 8192);
+    PX_DS_READ(b3, ldsB, 4096 + 3 * 8192);
+    PX_DS_READ(b4, ldsB, 4096 + 4 * 8192);
+    if (!zb) PX_DS_READ(b0, ldsB, 4096);
+    if (!za0) PX_DS_READ(a[0][0], ldsA, 0);
+    if (FULL && !za1) PX_DS_READ(a[0][1], ldsA, 512);
+    PX_DS_READ(a[1][0], ldsA, 8192);
+    if (FULL) PX_DS_READ(a[1][1], ldsA, 8192 + 512);
+    if (FULL) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(a[0][0]), "+v"(a[0][1]));
+    else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(a[0][0]));
+    {
+        const v4i bb[PX_S] = {b0, b1, b2, b3, b4};
+        if (!za0) {
+#pragma unroll
+            for (int t = 0; t < PX_S; ++t)
+                if (!(t == 0 && zb)) acc[0][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][0], bb[t], acc[0][t], 0, 0, 0);
+        }
+        if (FULL && !za1) {
+#pragma unroll
+            for (int t = 0; t < PX_S; ++t)
+                if (!(t == 0 && zb)) acc[1][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][1], bb[t], acc[1][t], 0, 0, 0);
+        }
+    }
+#define PXZ_GROUP(s_, cur, nxt)                                                                                               \
+    if (s_ + 1 < PX_S) {                                                                                                      \
+        PX_DS_READ(a[nxt][0], ldsA, (s_ + 1) * 8192);                                                                         \
+        if (FULL) PX_DS_READ(a[nxt][1], ldsA, (s_ + 1) * 8192 + 512);                                                         \
+        if (FULL) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a[cur][0]), "+v"(a[cur][1]));                                    \
+        else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a[cur][0]));                                                          \
+    } else {                                                                                                                  \
+        if (FULL) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[cur][0]), "+v"(a[cur][1]));                                    \
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[cur][0]));                                                          \
+    }                                                                                                                         \
+    {                                                                                                                         \
+        const v4i bb[PX_S] = {b0, b1, b2, b3, b4};                                                                            \
+        _Pragma("unroll") for (int t = 0; t < PX_S - s_; ++t) {                                                               \
+            if (t == 0 && zb) continue;                                                                                       \
+            acc[0][s_ + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[cur][0], bb[t], acc[0][s_ + t], 0, 0, 0);                \
+            if (FULL) acc[1][s_ + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[cur][1], bb[t], acc[1][s_ + t], 0, 0, 0);      \
+        }                                                                                                                     \
+    }
+    PXZ_GROUP(1, 1, 0)
+    PXZ_GROUP(2, 0, 1)
+    PXZ_GROUP(3, 1, 0)
+    PXZ_GROUP(4, 0, 1)
+#undef PXZ_GROUP
+}
+
 // ---------------------------------------------------------------------------------- the downdate, persistent form
 // One workgroup per CU walks its share of the unit list (units slot, slot + slots, ... of its XCD's list: what the hardware
 // dispatcher does with one-unit workgroups when every unit takes the same time).  What this buys over k_p_update_i8:
@@ -463,7 +551,8 @@ constexpr int PX_RING = 3;
 template <bool RECT, typename TP = float>
 __global__ void __launch_bounds__(512, 2)
 k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq, int ldq, size_t plane_stride, int m_k,
-               const int *__restrict__ bexp, int per_xcd, const int4 *__restrict__ units, int slots, RowMap rm, const int *__restrict__ counts)
+               const int *__restrict__ bexp, int per_xcd, const int4 *__restrict__ units, int slots, RowMap rm, const int *__restrict__ counts,
+               const uint8_t *__restrict__ bz, int bz_stride)
 {
     constexpr int TM = 128, MB = 32, SLAB = PX_S * 8192;
     constexpr int ST = MB + 4; // row stride of the epilogue's staging image: 16-byte aligned rows
@@ -551,8 +640,23 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
             const int c = (tid < TM ? I0 : J0 - TM) + tid;
             sExp[ui & 1][tid] = c < n ? bexp[c] - 1022 : 0;
         }
+        // which steps of this unit find an all-zero piece of digit plane 0 in the wavefront's two blocks of A rows and in its block of
+        // B columns (px_flag_plane0): lane t looks at step t's two 16-row groups; bit t set = something there.  Units of more than 64
+        // steps (updates above 2048 rows) multiply everything.
+        unsigned long long nzA0 = ~0ull, nzA1 = ~0ull, nzB = ~0ull;
+        const bool skipz = PX_SKIP_ZERO && bz != nullptr && nk <= 64;
+        if (skipz) {
+            const int cbA = (I0 + rbase) >> 5, cbB = (J0 + wc * MB) >> 5;
+            const unsigned short *pa = reinterpret_cast<const unsigned short *>(bz + (size_t)cbA * bz_stride);
+            const unsigned short *pb = reinterpret_cast<const unsigned short *>(bz + (size_t)cbB * bz_stride);
+            const bool on = lane < nk;
+            const unsigned fa0 = on ? pa[lane] : 0u, fa1 = on ? pa[(bz_stride >> 1) + lane] : 0u, fb = on ? pb[lane] : 0u;
+            nzA0 = __ballot(fa0 != 0u);
+            nzA1 = __ballot(fa1 != 0u);
+            nzB = __ballot(fb != 0u);
+        }
         v16i acc[2][PX_S];
-#if !PX_ZERO_C // (PX_ZERO_C: the unit's first step starts the accumulators with the constant 0 as C: no 160 moves per unit and wavefront)
+#if !PX_ZERO_C || PX_SKIP_ZERO // (PX_ZERO_C: the unit's first step starts the accumulators with the constant 0 as C; not with skipped products)
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -576,13 +680,17 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
         /* other after them, so that one multiplies while the other issues (an LDS-DMA costs 60-180 issue cycles)      */    \
         if (!late && !(PX_ABL & 2)) { PXP_ISSUE() }                                                                           \
         if (PX_PRIO) __builtin_amdgcn_s_setprio(2);                                                                           \
+        if (PX_SKIP_ZERO) {                                                                                                   \
+            const bool za0_ = !((nzA0 >> ((T_) & 63)) & 1ull), za1_ = !((nzA1 >> ((T_) & 63)) & 1ull), zb_ = !((nzB >> ((T_) & 63)) & 1ull);       \
+            px_step_ring_z<FULL_>(ring_lds + (g % PX_RING) * SLAB + offA, ring_lds + (g % PX_RING) * SLAB + offB, acc, za0_, za1_, zb_); \
+        } else                                                                                                                \
         px_step_ring<FULL_, 8192, 4096, FIRST_>(ring_lds + (g % PX_RING) * SLAB + offA, ring_lds + (g % PX_RING) * SLAB + offB, acc); \
         if (PX_PRIO) __builtin_amdgcn_s_setprio(0);                                                                           \
         if (late && !(PX_ABL & 2)) { PXP_ISSUE() }                                                                            \
         ++g;                                                                                                                  \
     }
 #define PXP_LOOP(FULL_)                                                                                                       \
-    PXP_STEP(FULL_, (PX_ZERO_C != 0), 0)                                                                                      \
+    PXP_STEP(FULL_, (PX_ZERO_C != 0 && !PX_SKIP_ZERO), 0)                                                                     \
     for (int t = 1; t < nk; ++t) PXP_STEP(FULL_, false, t)
         if (full) { PXP_LOOP(true) } else { PXP_LOOP(false) }
 #undef PXP_LOOP
@@ -1446,13 +1554,13 @@ void launch_b_gemm_planes(EkfEngine *e, int m, int c_lo, int c_hi)
     // digit planes of W' (columns = rows of inv(L)) and of G, each with its columns' true scales
     (void)hipMemsetAsync(e->d.Wexp, 0, sizeof(int) * (size_t)ldw, s);
     k_col_exp<<<dim3((mw_pad + 255) / 256, PX_KSPLIT), 256, 0, s>>>(e->d.W, ldw, m, mw_pad, nullptr, e->d.Wexp);
-    k_slice_B<<<dim3(mw_pad / 64, (m_k + 63) / 64), 256, 0, s>>>(e->d.W, ldw, m, m_k, nullptr, e->d.Wexp, e->d.Wq, ldw, w_stride, 0, mw_pad);
+    k_slice_B<<<dim3(mw_pad / 64, (m_k + 63) / 64), 256, 0, s>>>(e->d.W, ldw, m, m_k, nullptr, e->d.Wexp, e->d.Wq, ldw, w_stride, 0, mw_pad, nullptr, 0);
     const int tj0 = c_lo / 128, tiles_j = (std::min(c_hi, n_pad) + 127) / 128 - tj0;
     const int g_lo = tj0 * 128, g_hi = (tj0 + tiles_j) * 128;
     (void)hipMemsetAsync(e->d.Gexp, 0, sizeof(int) * (size_t)ld, s);
     k_col_exp<<<dim3((n_pad + 255) / 256, PX_KSPLIT), 256, 0, s>>>((const double *)e->d.G, ld, m, n_pad, nullptr, e->d.Gexp);
     k_slice_B<<<dim3((g_hi - g_lo) / 64, (m_k + 63) / 64), 256, 0, s>>>((const double *)e->d.G, ld, m, m_k, nullptr, e->d.Gexp, e->d.Gq, ld, g_stride,
-                                                                      g_lo, g_hi);
+                                                                      g_lo, g_hi, nullptr, 0);
     const int tiles_i = (m + 127) / 128;
     const int n_units = tiles_i * tiles_j;
     k_b_gemm_i8p<<<std::min(e->n_cus, n_units), 512, 0, s>>>(e->d.Wq, ldw, w_stride, e->d.Wexp, e->d.Gq, ld, g_stride, e->d.Gexp, e->d.Bq,
@@ -1497,7 +1605,7 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bo
         (void)hipMemsetAsync(e->d.Bexp, 0, sizeof(int) * (size_t)ld, s);
         k_col_exp<<<dim3((n_pad + 255) / 256, PX_KSPLIT), 256, 0, s>>>(B, ld, m, n_pad, Bc, e->d.Bexp);
     }
-    if (!planes_ready) k_slice_B<<<dim3(n_pad / 64, (m_k + 63) / 64), 256, 0, s>>>(B, ld, m, m_k, Bc, e->d.Bexp, e->d.Bq, ld, plane_stride, 0, n_pad);
+    if (!planes_ready) k_slice_B<<<dim3(n_pad / 64, (m_k + 63) / 64), 256, 0, s>>>(B, ld, m, m_k, Bc, e->d.Bexp, e->d.Bq, ld, plane_stride, 0, n_pad, e->d.Bz, e->bz_stride);
     const int nt = (n + 127) / 128;
     const bool rect = e->shard_world > 1;
     const int owned = e->rm.r1 - e->rm.r0;
@@ -1555,8 +1663,8 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bo
     if (!e->f32) { // fp64-stored P (EKF_PRECISION_F64_EXACT): the persistent kernel with the fp64 epilogue; an arbitrary upload is
                    // symmetrised first (0.5 (P + P') - B'B = 0.5 ((P - B'B) + (P - B'B)'): B'B is symmetric)
         if (!e->p_exact_sym && !rect) k_symmetrize_P<<<dim3((n + 255) / 256, n), 256, 0, s>>>((double *)e->d.P, ld, n);
-        if (rect) k_p_update_i8p<true, double><<<e->n_cus, 512, 0, s>>>((double *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts);
-        else k_p_update_i8p<false, double><<<e->n_cus, 512, 0, s>>>((double *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts);
+        if (rect) k_p_update_i8p<true, double><<<e->n_cus, 512, 0, s>>>((double *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts, e->d.Bz, e->bz_stride);
+        else k_p_update_i8p<false, double><<<e->n_cus, 512, 0, s>>>((double *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts, e->d.Bz, e->bz_stride);
     } else
     if (!e->p_exact_sym && !rect) k_p_update_i8<true><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->d.counts);
     else if (g_px_variant == 1 || PX_S != 5) k_p_update_i8<false><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->d.counts);
@@ -1565,8 +1673,8 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bo
     else if (g_px_variant == 3 && rect) k_p_update_i8q<true><<<e->n_cus, 256, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts);
     else if (g_px_variant == 3) k_p_update_i8q<false><<<e->n_cus, 256, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts);
 #endif
-    else if (rect) k_p_update_i8p<true><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts);
-    else k_p_update_i8p<false><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts);
+    else if (rect) k_p_update_i8p<true><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts, e->d.Bz, e->bz_stride);
+    else k_p_update_i8p<false><<<e->n_cus, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts, e->d.Bz, e->bz_stride);
 #endif
     bool launched = true;
     {   // a launch that the runtime refuses (resources) would leave P silently un-downdated

@@ -78,17 +78,24 @@ int main(int argc, char **argv)
     hipMalloc(&e.d.Bq, (size_t)PX_S * m_cap * ld);
     hipMalloc(&e.d.Bexp, sizeof(int) * ld);
     hipMemset(e.d.Bq, 0, (size_t)PX_S * m_cap * ld);
+    e.bz_stride = m_cap / 16; // the table of non-zero pieces of plane 0 (k_slice_B writes it, k_p_update_i8p skips by it)
+    hipMalloc(&e.d.Bz, (size_t)(ld / 32 + 8) * e.bz_stride);
+    hipMemset(e.d.Bz, 0, (size_t)(ld / 32 + 8) * e.bz_stride);
+    // PX_BENCH_RATIO: a column's typical entry = its largest / ratio (the engine's frames: ~300; default sqrt(m): a dense plane 0)
+    const double ratio_env = getenv("PX_BENCH_RATIO") ? atof(getenv("PX_BENCH_RATIO")) : 0.0;
     e.timing = true;
 
     int rc = 0;
     for (int m : ms) {
-        const double amp = 1.0 / sqrt((double)m);
+        const double amp = ratio_env > 0.0 ? 1.0 / ratio_env : 1.0 / sqrt((double)m);
         for (int k = 0; k < m_cap; ++k)
             for (int j = 0; j < ld; ++j) {
                 double v = 0.0;
                 if (k < m && j < n) {
                     v = cscale[j] * amp * drand();
-                    if ((k * 131 + j * 17) % 97 == 0) v = cscale[j] * drand(); // spike
+                    if (ratio_env > 0.0) { // a feature's own measurement rows: along the band k ~ m j / n
+                        if (std::abs(k - (int)((long long)j * m / n)) <= 1) v = cscale[j] * (0.5 + 0.5 * fabs(drand()));
+                    } else if ((k * 131 + j * 17) % 97 == 0) v = cscale[j] * drand(); // spike
                 }
                 hB[(size_t)k * ld + j] = v;
                 hBf[(size_t)k * ld + j] = (float)v;
