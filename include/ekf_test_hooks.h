@@ -20,6 +20,9 @@ extern "C" {
 int ekf_debug_stall_next_sweep(EkfEngine *e);
 /* ... the same for the persistent sweep AFTER the next `skip` ones (skip = 1: the second update of the next EKF::step). */
 int ekf_debug_stall_sweep_after(EkfEngine *e, int skip);
+/* Exact configurations: how many 16-row x 32-column pieces of digit plane 0 of B held anything but zeros in the LAST update, of how
+ * many (the downdate skips the digit products of the all-zero ones: csrc/kernels_pexact.hip, px_flag_plane0). */
+int ekf_debug_plane0_pieces(EkfEngine *e, int *nonzero, int *total);
 
 #ifdef __cplusplus
 }

@@ -2063,6 +2063,23 @@ int ekf_debug_stall_next_sweep(EkfEngine *e) // include/ekf_test_hooks.h
     return EKF_OK;
 }
 
+int ekf_debug_plane0_pieces(EkfEngine *e, int *nonzero, int *total)
+{
+    if (!e || !nonzero || !total || !e->d.Bz) return EKF_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const int cbs = (e->n + 31) / 32, groups = (2 * e->last_update_M + 15) / 16;
+    std::vector<uint8_t> row((size_t)e->bz_stride);
+    int nz = 0;
+    for (int c = 0; c < cbs; ++c) {
+        HIPCHK(hipMemcpy(row.data(), e->d.Bz + (size_t)c * e->bz_stride, (size_t)groups, hipMemcpyDeviceToHost));
+        for (int k = 0; k < groups; ++k) nz += row[k] ? 1 : 0;
+    }
+    *nonzero = nz;
+    *total = cbs * groups;
+    return EKF_OK;
+}
+
 int ekf_debug_stall_sweep_after(EkfEngine *e, int skip)
 {
     if (!e || skip < 0) return EKF_ERR_INVALID_ARG;

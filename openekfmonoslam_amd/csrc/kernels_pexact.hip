@@ -655,6 +655,11 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
             nzA1 = __ballot(fa1 != 0u);
             nzB = __ballot(fb != 0u);
         }
+        // a unit takes the skipping form of the step when at least a quarter of its plane-0 pieces are zero: on a fresh map 85-90 % of
+        // them are, once the filter has converged the columns of B are flat and 20-40 % are (profiles/r06_plane0_pieces.txt) -- and the
+        // skipping step costs ~4 % where it has nothing to skip (its optional reads and branches)
+        const int n_zero = skipz ? (nk - __popcll(nzA0)) + (full ? nk - __popcll(nzA1) : 0) + (nk - __popcll(nzB)) : 0;
+        const bool sparse_unit = __builtin_amdgcn_readfirstlane(skipz && 4 * n_zero >= (full ? 3 : 2) * nk ? 1 : 0) != 0;
         v16i acc[2][PX_S];
 #if !PX_ZERO_C || PX_SKIP_ZERO // (PX_ZERO_C: the unit's first step starts the accumulators with the constant 0 as C; not with skipped products)
 #pragma unroll
@@ -664,7 +669,7 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[x][L][r] = 0;
 #endif
-#define PXP_STEP(FULL_, FIRST_, T_)                                                                                           \
+#define PXP_STEP(FULL_, FIRST_, T_, SPARSE_)                                                                                         \
     {                                                                                                                         \
         /* step g has landed (this wavefront's pieces): everything but the PX_S loads of step g + 1 is complete.           */ \
         /* The first two steps of a unit behind an epilogue need no wait: their slabs were requested before that epilogue  */ \
@@ -680,7 +685,7 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
         /* other after them, so that one multiplies while the other issues (an LDS-DMA costs 60-180 issue cycles)      */    \
         if (!late && !(PX_ABL & 2)) { PXP_ISSUE() }                                                                           \
         if (PX_PRIO) __builtin_amdgcn_s_setprio(2);                                                                           \
-        if (PX_SKIP_ZERO) {                                                                                                   \
+        if (PX_SKIP_ZERO && (SPARSE_)) {                                                                                      \
             const bool za0_ = !((nzA0 >> ((T_) & 63)) & 1ull), za1_ = !((nzA1 >> ((T_) & 63)) & 1ull), zb_ = !((nzB >> ((T_) & 63)) & 1ull);       \
             px_step_ring_z<FULL_>(ring_lds + (g % PX_RING) * SLAB + offA, ring_lds + (g % PX_RING) * SLAB + offB, acc, za0_, za1_, zb_); \
         } else                                                                                                                \
@@ -689,10 +694,14 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
         if (late && !(PX_ABL & 2)) { PXP_ISSUE() }                                                                            \
         ++g;                                                                                                                  \
     }
-#define PXP_LOOP(FULL_)                                                                                                       \
-    PXP_STEP(FULL_, (PX_ZERO_C != 0 && !PX_SKIP_ZERO), 0)                                                                     \
-    for (int t = 1; t < nk; ++t) PXP_STEP(FULL_, false, t)
-        if (full) { PXP_LOOP(true) } else { PXP_LOOP(false) }
+#define PXP_LOOP(FULL_, SPARSE_)                                                                                              \
+    PXP_STEP(FULL_, (PX_ZERO_C != 0 && !PX_SKIP_ZERO), 0, SPARSE_)                                                            \
+    for (int t = 1; t < nk; ++t) PXP_STEP(FULL_, false, t, SPARSE_)
+        if (sparse_unit) {
+            if (full) { PXP_LOOP(true, true) } else { PXP_LOOP(false, true) }
+        } else {
+            if (full) { PXP_LOOP(true, false) } else { PXP_LOOP(false, false) }
+        }
 #undef PXP_LOOP
 #undef PXP_STEP
         if (PX_ABL & 1) {

@@ -120,6 +120,7 @@ ABI = {
 TEST_HOOKS = {
     "ekf_debug_stall_next_sweep": (_i, [_vp]),
     "ekf_debug_stall_sweep_after": (_i, [_vp, _i]),
+    "ekf_debug_plane0_pieces": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
 }
 
 # int fn(void *user, int what, void *device_base, size_t row_bytes, const int32_t *row_begin, int world, int rank)
@@ -316,6 +317,12 @@ class EkfEngine:
     def stall_sweep(self, skip=0):
         """test hook (include/ekf_test_hooks.h): the persistent sweep after the next `skip` ones runs without its chain workgroup"""
         self._chk(self.L.ekf_debug_stall_sweep_after(self.h, int(skip)))
+
+    def plane0_pieces(self):
+        """test hook: (non-zero, all) 16 x 32 pieces of digit plane 0 of B in the last update (exact configurations)"""
+        a, b = _i(0), _i(0)
+        self._chk(self.L.ekf_debug_plane0_pieces(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_update_path(self, path):
         """0: by size, 1: B = inv(L) H P inside the Cholesky sweep, 2: explicit inverse + GEMM (ekf_engine.h)"""

@@ -21,6 +21,9 @@ $B --workload n1000_f32x --sweep-mode 4 > "$out/bench_n1000_f32x_launches.json" 
 $B --workload n200_f64 --sweep-mode 4 --steps 60 --warmup 10 > "$out/bench_n200_f64_launches.json" 2> /dev/null
 $B --matcher ncc --workload n2000_f32x --steps 20 --warmup 5 > "$out/bench_n2000_f32x_ncc.json" 2> /dev/null
 $B --emulate-shards 4 --workload n2000_f32x --steps 6 --warmup 2 --no-cpu-baseline > "$out/bench_n2000_f32x_emulated4.json" 2> /dev/null
+# round 6: how much of digit plane 0 is zero on the bench's frames; two processes sharing the GPU (no error may surface)
+timeout 300 python scripts/plane0_stats.py 1000 30 2>/dev/null | grep -v amdgpu.ids > "$out/plane0_pieces.txt"
+timeout 600 python scripts/two_processes_one_gpu.py 200 1000 2 > "$out/two_processes_one_gpu.txt" 2>&1
 # the downdate kernel alone: variants (0 persistent, 1 first version), bitwise check against the CPU, ablations at m = 298 / 1014 when built
 bash scripts/pu_i8_micro.sh > "$out/pu_i8_bench.txt" 2>&1
 # timelines of the persistent sweep: only when the debug build is there (scripts/build_trace_variant.sh)
