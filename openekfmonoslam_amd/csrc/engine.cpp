@@ -319,8 +319,10 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
     ALLOC(d.msel, cap);
     ALLOC(d.mout, cap);
     ALLOC(d.match_of_feat, cap);
-    ALLOC(d.hyp_count, (size_t)e->cfg.ransac_batch);
-    ALLOC(d.hyp_flags, (size_t)e->cfg.ransac_batch * mcap);
+    // (a frame's first batch is ransac_batch hypotheses; the batches behind it -- a fresh map needs hundreds of hypotheses -- are
+    // RANSAC_WIDE_FACTOR times wider: one workgroup per hypothesis, and 32 workgroups leave seven eighths of the chip idle)
+    ALLOC(d.hyp_count, (size_t)e->cfg.ransac_batch * RANSAC_WIDE_FACTOR);
+    ALLOC(d.hyp_flags, (size_t)e->cfg.ransac_batch * RANSAC_WIDE_FACTOR * mcap);
     ALLOC(d.best_flags, mcap);
     // tiles of the GEMM-shaped kernels read whole 128-wide slabs: leading dimensions and row counts carry slack
     e->ldW = round_up((int)mcap, 128) + 128;
@@ -1219,7 +1221,8 @@ static int ransac_dev(EkfEngine *e, int M, bool lean = false)
         }
         rb.assign(W + 1, 0);
     }
-    for (int h0 = 0; h0 < M; h0 += batch) {
+    for (int h0 = 0, nb = batch; h0 < M; h0 += nb, nb = batch * RANSAC_WIDE_FACTOR) {
+        const int batch = nb; // (this batch's width: the first one narrow -- a converged filter ends inside it --, the others wide)
         if (by_owner) {
             const int h1 = std::min(M, h0 + batch);
             launch_ransac_hyp(e, M, h0, batch, nullptr, mb[me], mb[me + 1]);
@@ -1608,8 +1611,8 @@ restart:
     e->n_pred = np;
     li.n_predicted = np;
     li.n_matches = M;
-    for (int h0 = batch; !e->h_counts[CNT_RS_DONE] && h0 < M; h0 += batch) {
-        launch_ransac_batch(e, M, h0, batch);
+    for (int h0 = batch, nb = batch * RANSAC_WIDE_FACTOR; !e->h_counts[CNT_RS_DONE] && h0 < M; h0 += nb) {
+        launch_ransac_batch(e, M, h0, nb); // (wide batches behind the first: see ransac_dev)
         if ((rc = read_counts(e))) return rc;
     }
     int ni = 0, no = 0;

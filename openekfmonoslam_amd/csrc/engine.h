@@ -19,6 +19,7 @@ constexpr int NB = 32;          // Cholesky panel width
 constexpr int LD_ALIGN = 128;   // leading dimensions are multiples of this many elements
 constexpr int B_SWEEP_MAX = 2048; // rows of S up to which B = inv(L) G is formed inside the sweep's launches
 constexpr int DX_SPLIT = 16;    // k-splits of the dx = B' z reduction
+constexpr int RANSAC_WIDE_FACTOR = 8; // hypotheses per launch behind a frame's first batch, in units of cfg.ransac_batch (engine.cpp)
 #ifndef PX_S_VALUE
 #define PX_S_VALUE 5
 #endif
