@@ -646,11 +646,17 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
         unsigned long long nzA0 = ~0ull, nzA1 = ~0ull, nzB = ~0ull;
         const bool skipz = PX_SKIP_ZERO && bz != nullptr && nk <= 64;
         if (skipz) {
-            const int cbA = (I0 + rbase) >> 5, cbB = (J0 + wc * MB) >> 5;
-            const unsigned short *pa = reinterpret_cast<const unsigned short *>(bz + (size_t)cbA * bz_stride);
-            const unsigned short *pb = reinterpret_cast<const unsigned short *>(bz + (size_t)cbB * bz_stride);
+            // (a block of 32 columns of B is one column block of the table -- or, on a row-sharded engine whose owned rows do not
+            // start on a multiple of 32, straddles two: then both count)
             const bool on = lane < nk;
-            const unsigned fa0 = on ? pa[lane] : 0u, fa1 = on ? pa[(bz_stride >> 1) + lane] : 0u, fb = on ? pb[lane] : 0u;
+            auto piece = [&](int col) -> unsigned {
+                const unsigned short *pz = reinterpret_cast<const unsigned short *>(bz + (size_t)(col >> 5) * bz_stride);
+                unsigned f = on ? pz[lane] : 0u;
+                if (RECT && (col & 31)) f |= on ? pz[(bz_stride >> 1) + lane] : 0u;
+                return f;
+            };
+            const int colA = I0 + rbase;
+            const unsigned fa0 = piece(colA), fa1 = piece(colA + MB), fb = piece(J0 + wc * MB);
             nzA0 = __ballot(fa0 != 0u);
             nzA1 = __ballot(fa1 != 0u);
             nzB = __ballot(fb != 0u);
