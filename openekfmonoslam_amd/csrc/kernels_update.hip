@@ -39,7 +39,7 @@ __device__ __forceinline__ void
 gather_body(const int bx, const int by, const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
             const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
             double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, int *bexp, const TP *Pdiag, int ldpd,
-            int n, int *grow)
+            int n, int *grow, int scale_shift)
 {
     // grow != nullptr (exact configuration, rows of B from digit planes): the rows are NOT copied -- their consumers (k_assemble_S,
     // b_rows_planes) read H P through the row map grow[row] = row of H P, -1 for the zero rows m .. m_pad; the launch then has
@@ -52,7 +52,9 @@ gather_body(const int bx, const int by, const EkfMatch *matches, int M, int m_pa
             const int per = (n_pad + m_pad - 1) / m_pad;
             for (int j = row * per + threadIdx.x; j < min((row + 1) * per, n_pad); j += 256) {
                 const double pjj = j < n ? (double)Pdiag[(size_t)j * ldpd + j] : 0.0;
-                bexp[j] = pjj > 0.0 ? ilogb(sqrt(pjj) * 1.001) + 1 + 1022 : 1022;
+                // (+ scale_shift bits of head-room, engine.h px_scale_shift: the top digit plane of B is then almost all zeros and the
+                // downdate skips its products, px_flag_plane0)
+                bexp[j] = pjj > 0.0 ? ilogb(sqrt(pjj) * 1.001) + 1 + 1022 + scale_shift : 1022;
             }
         }
     } else if (bexp && row == 0) {
@@ -106,10 +108,10 @@ __global__ void __launch_bounds__(256)
 k_gather(const EkfMatch *matches, int M, int m_pad, const T *HP, T *A, int ld, int n_pad, const double *uv_tab,
          const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
          double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, int *bexp, const TP *Pdiag, int ldpd,
-         int n, int *grow)
+         int n, int *grow, int scale_shift)
 {
     gather_body<T, TP>((int)blockIdx.x, (int)blockIdx.y, matches, M, m_pad, HP, A, ld, n_pad, uv_tab, Hs_tab, Hf_tab, feat_type, feat_covpos, nu, mHs, mHf,
-                       mpos, mdim, HPc, Gc, bexp, Pdiag, ldpd, n, grow);
+                       mpos, mdim, HPc, Gc, bexp, Pdiag, ldpd, n, grow, scale_shift);
 }
 
 // sum over the four lanes of a quad, in every lane: two DPP quad permutes (lane ^ 1, lane ^ 2) -- register moves, where
@@ -245,7 +247,7 @@ k_gather_assemble(int mb, int gxg, const EkfMatch *matches, int M, int m_pad, co
                   const double *Hs_tab, const double *Hf_tab, const int *feat_type, const int *feat_covpos, double *nu,
                   double *mHs, double *mHf, int *mpos, int *mdim, const double *HPc, double *Gc, int *bexp, const TP *Pdiag, int ldpd,
                   int n, int *grow, double pixel_err, double *S, int ldS, double *V, double *W, float *Wf, int ldw, int *counts, int *lexp,
-                  int duties)
+                  int duties, int scale_shift)
 {
     const int id = (int)blockIdx.x;
     if (id < mb * mb) {
@@ -255,7 +257,7 @@ k_gather_assemble(int mb, int gxg, const EkfMatch *matches, int M, int m_pad, co
     } else {
         const int g = id - mb * mb;
         gather_body<T, TP>(g % gxg, g / gxg, matches, M, m_pad, HP, A, ld, n_pad, uv_tab, Hs_tab, Hf_tab, feat_type, feat_covpos, nu, mHs, mHf, mpos,
-                           mdim, HPc, Gc, bexp, Pdiag, ldpd, n, grow);
+                           mdim, HPc, Gc, bexp, Pdiag, ldpd, n, grow, scale_shift);
     }
 }
 
@@ -1683,15 +1685,15 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             // gather and the assembly of S in one launch (the assembly reads the prediction tables, not the gather's output)
             const int mb = (M + 15) / 16;
             int *gr = planes_b ? e->d.Grow : nullptr;
-#define GA_TAIL n, gr, e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts, planes_b ? e->d.Lexp : nullptr, persist ? 0 : 1
+#define GA_TAIL n, gr, e->cfg.cam.pixelErrorX, e->d.S, ldS, V, W, Wf, ldw, e->d.counts, planes_b ? e->d.Lexp : nullptr, persist ? 0 : 1, e->px_scale_shift
             if (apriori) k_gather_assemble<TB, T><<<mb * mb + (int)(grid.x * grid.y), 256, 0, s>>>(mb, (int)grid.x, GATHER_ARGS, (const T *)e->d.P, ld, GA_TAIL);
             else k_gather_assemble<TB, float><<<mb * mb + (int)(grid.x * grid.y), 256, 0, s>>>(mb, (int)grid.x, GATHER_ARGS, (const float *)nullptr, 0, GA_TAIL);
 #undef GA_TAIL
         } else if (apriori && !sharded) // a-priori column scales from the diagonal of the covariance itself
-            k_gather<TB, T><<<grid, 256, 0, s>>>(GATHER_ARGS, (const T *)e->d.P, ld, n, planes_b || sym_g ? e->d.Grow : nullptr);
+            k_gather<TB, T><<<grid, 256, 0, s>>>(GATHER_ARGS, (const T *)e->d.P, ld, n, planes_b || sym_g ? e->d.Grow : nullptr, e->px_scale_shift);
         else
             k_gather<TB, float><<<grid, 256, 0, s>>>(GATHER_ARGS, apriori ? e->d.Pdiag : nullptr, 0, n,
-                                                    (planes_b && !sharded) || sym_g ? e->d.Grow : nullptr);
+                                                    (planes_b && !sharded) || sym_g ? e->d.Grow : nullptr, e->px_scale_shift);
 #undef GATHER_ARGS
         if (planes_b && !sharded) G = (TB *)e->d.HP; // the consumers read H P through the row map (sym_g: G is formed by k_g_cols below)
     }
