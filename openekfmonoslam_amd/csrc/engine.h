@@ -261,11 +261,11 @@ struct EkfEngine {
     int pu_per_xcd = 0;
     int bq_rows = 0;          // rows of B a digit plane holds (multiple of 64)
     int bz_stride = 0;        // 16-row groups per column block of d.Bz (= bq_rows / 16)
-    int px_scale_shift = 0;   // bits of head-room added to the a-priori column scales of B (exponent of sqrt(P_jj)): 2 on an fp32-stored
-                              // covariance -- the 38-bit integers become 36-bit ones, still 60 x finer than the fp32 rounding of the result,
-                              // and digit plane 0 is then ~95 % zero pieces on converged and fresh maps alike, which the downdate skips
-                              // (kernels_pexact.hip: px_flag_plane0); 0 on an fp64-stored one, where the digits ARE the precision.
-                              // EKF_PX_SCALE_SHIFT in the environment overrides (measurements)
+    int px_scale_shift = 0;   // bits of head-room added to the a-priori column scales of B (exponent of sqrt(P_jj)); EKF_PX_SCALE_SHIFT in the
+                              // environment sets it (a measurement knob).  With 1 / 2 bits digit plane 0 is 82 / 95-97 % zero pieces on converged
+                              // maps too and the downdate skips their products: 1187 -> 1266 updates/s at N = 1000 -- but the 38-bit integers are
+                              // then 37- / 36-bit ones, and the far features' inverse depths need every bit: one bit puts one of the five
+                              // N = 1000 scenes at 1.12e-5 component-wise, two bits N = 2000 at 1.9e-5 (profiles/r06_scale_shift.txt).  Left at 0.
     int lq_nbk = 0;           // 32-row blocks per side of the digit planes of L
     int bstage_rows = 0;      // rows of B the exchange image of the planes holds (sharded exact configuration)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> px_events; // exact configuration: end of the sweep -> start of the downdate (inverse, GEMM, digit planes, dx, state)
