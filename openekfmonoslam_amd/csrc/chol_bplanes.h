@@ -39,6 +39,7 @@ struct BPlanes {
     const int *grow = nullptr; // row of the H P table behind every row of G (-1: a zero row), see k_gather; null: G is a copy
     int bcol0 = 0;             // first column block of this rank (row-sharded engines form their own blocks only)
     int no_fp64 = 0;           // the rows of B are not stored in fp64 (dx = B'z comes from the planes, k_dx_planes)
+    int *counts = nullptr;     // the engine's counter block: a row of B that does not fit its a-priori column scale raises CNT_ERR (digit_planes.h)
 };
 
 // Digit planes of TWO 32 x 32 blocks of L (rows i0a.. and i0b.., columns k0 .. k0 + kb - 1, in LDS; n_blk = 1: the first
@@ -189,7 +190,7 @@ __device__ __forceinline__ void b_rows_planes(const BPlanes &bp, const double *G
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = 16 * kh + 4 * qr + i;
-            const unsigned long long dw = px_digit_word(k0 + row < m ? sO[row][col] : 0.0, sh);
+            const unsigned long long dw = px_digit_word_checked(k0 + row < m ? sO[row][col] : 0.0, sh, bp.counts);
 #pragma unroll
             for (int s = 0; s < PX_S; ++s) w[s] |= px_digit_byte(dw, s) << (8 * i);
         }
@@ -343,7 +344,7 @@ __device__ __forceinline__ void b_pair_rows_planes(const BPlanes &bp, const doub
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = 16 * kh + 4 * qr + i;
-                const unsigned long long dw = px_digit_word(kr0 + row < m ? sO[row][col] : 0.0, sh);
+                const unsigned long long dw = px_digit_word_checked(kr0 + row < m ? sO[row][col] : 0.0, sh, bp.counts);
 #pragma unroll
                 for (int s = 0; s < PX_S; ++s) w[s] |= px_digit_byte(dw, s) << (8 * i);
             }

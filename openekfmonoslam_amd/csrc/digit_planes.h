@@ -15,6 +15,19 @@ __device__ __forceinline__ unsigned long long px_digit_word(double v, int sh)
     return ((unsigned long long)X + K) ^ K; // byte (PX_S - 1 - s) = digit s as int8
 }
 
+// ... for the rows of B under an A-PRIORI column scale (|B_kj| <= sqrt(P_jj), chol_bplanes.h): the bound holds for a positive
+// semi-definite P; a covariance uploaded with |P_ij| > sqrt(P_ii P_jj) (or a NaN) breaks it, and digits that wrap would downdate P with
+// garbage in silence.  An integer that does not fit the PX_S digits raises the sticky code EKF_ERR_NON_FINITE instead -- the kernels
+// behind the sweep then leave the filter untouched (engine.h: filter_frozen) and the update reports it.
+__device__ __forceinline__ unsigned long long px_digit_word_checked(double v, int sh, int *counts)
+{
+    constexpr unsigned long long K = PX_S == 5 ? 0x8080808080ull : (PX_S == 6 ? 0x808080808080ull : 0x80808080ull);
+    const long long X = __double2ll_rn(ldexp(v, sh));
+    const long long lim = 1ll << (8 * PX_S - 1);
+    if (counts && !(X > -lim && X < lim)) atomicMax(&counts[CNT_ERR], (int)EKF_ERR_NON_FINITE);
+    return ((unsigned long long)X + K) ^ K;
+}
+
 // digit s of the word
 __device__ __forceinline__ unsigned px_digit_byte(unsigned long long w, int s) { return (unsigned)(w >> (8 * (PX_S - 1 - s))) & 255u; }
 

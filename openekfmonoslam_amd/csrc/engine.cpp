@@ -1345,7 +1345,9 @@ static int recover_failed_update(EkfEngine *e, int *status)
     } else {
         *status = code;
     }
-    e->err = *status == EKF_ERR_TIMEOUT ? "the persistent Cholesky sweep timed out" : "S = H P H' + R is not positive definite";
+    e->err = *status == EKF_ERR_TIMEOUT ? "the persistent Cholesky sweep timed out"
+             : (*status == EKF_ERR_NON_FINITE ? "a row of B = inv(L) H P does not fit its a-priori column scale (covariance not positive semi-definite, or not finite)"
+                                              : "S = H P H' + R is not positive definite");
     return EKF_OK;
 }
 

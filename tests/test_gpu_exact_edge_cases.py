@@ -231,6 +231,37 @@ def test_indefinite_innovation_covariance_is_reported_exact(eng_mod, seq12):
     assert np.array_equal(x0, x1) and np.array_equal(fp0, fp1) and np.array_equal(P0, P1)
 
 
+@pytest.mark.parametrize("mode", [pytest.param(2, id="persistent"), pytest.param(4, id="launches")])
+def test_rows_of_B_that_do_not_fit_their_column_scale_are_reported_exact(eng_mod, seq50, mode):
+    """Round-5 review item 6: the rows of B are cut into digits under an A-PRIORI column scale, |B_kj| <= sqrt(P_jj) -- true for a
+    positive semi-definite P.  A covariance uploaded with |P_ij| > sqrt(P_ii P_jj) breaks the bound; digits that wrap would downdate P
+    with garbage in silence.  The cut now raises EKF_ERR_NON_FINITE (4), the kernels behind the sweep leave the filter untouched, and
+    the update reports it.  One inverse depth with variance 1e-20 but covariances of 1e-6 with the camera position: S stays
+    positive definite, the rows of B of that column are ~1e6 x their scale."""
+    seq = seq50
+    e = eng_mod.EkfEngine(seq.cam, seq.par, 64, max_keypoints=512, precision=EXACT)
+    e.set_sweep_mode(mode)
+    P = np.array(seq.P0, copy=True)
+    j = 13 + 6 * 3 + 5
+    P[j, j] = 1e-20
+    P[j, :3] = P[:3, j] = 1e-6
+    e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, P)
+    e.predict()
+    preds, _, _ = e.predict_measurements()
+    m = _matches_from_predictions(preds, 40)
+    x0, fp0, P0 = e.get_state()
+    with pytest.raises(eng_mod.EkfError) as ei:
+        e.update(m)
+    assert ei.value.code == 4, ei.value
+    x1, fp1, P1 = e.get_state()
+    assert np.array_equal(x0, x1) and np.array_equal(fp0, fp1) and np.array_equal(P0, P1)
+    # the engine is usable afterwards: a proper covariance, the same update
+    e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+    e.predict()
+    e.predict_measurements()
+    e.update(m)
+
+
 @pytest.mark.parametrize("path", [pytest.param(1, id="sweep"), pytest.param(2, id="gemm")])
 def test_n200_exact_frames_vs_oracle(eng_mod, oracle_lib, path):
     """BASELINE configs[1] map size in the exact configuration, three frames, both ways of forming B"""
