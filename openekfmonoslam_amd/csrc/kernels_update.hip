@@ -1625,6 +1625,7 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
         bp.Lq = e->d.Lq; bp.nbk = e->lq_nbk; bp.l_stride = (size_t)e->lq_nbk * e->lq_nbk * 1024; bp.lexp = e->d.Lexp;
         bp.grow = sharded ? nullptr : e->d.Grow;
         bp.counts = e->d.counts;
+        bp.n_live = n;
         bp.no_fp64 = 1; // dx = B'z from the planes: the fp64 rows of B (8 bytes per element written, then read by k_dx_partial) never exist
     }
     if (planes_b || shard_cols) {
