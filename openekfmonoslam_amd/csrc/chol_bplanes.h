@@ -40,7 +40,8 @@ struct BPlanes {
     int bcol0 = 0;             // first column block of this rank (row-sharded engines form their own blocks only)
     int no_fp64 = 0;           // the rows of B are not stored in fp64 (dx = B'z comes from the planes, k_dx_planes)
     int *counts = nullptr;     // the engine's counter block: a row of B that does not fit its a-priori column scale raises CNT_ERR (digit_planes.h)
-    int n_live = 0;            // ... checked for the state's columns only (the padding columns of a block may hold stale rows of H P: never stored into P)
+    int c_live0 = 0, n_live = 0; // ... checked for the columns [c_live0, n_live) only: the state's columns this engine forms B for (the padding columns of a
+                               // block, and on a row-sharded rank the neighbour's columns of a straddling block, may hold stale rows of H P: never used)
 };
 
 // Digit planes of TWO 32 x 32 blocks of L (rows i0a.. and i0b.., columns k0 .. k0 + kb - 1, in LDS; n_blk = 1: the first
@@ -191,7 +192,7 @@ __device__ __forceinline__ void b_rows_planes(const BPlanes &bp, const double *G
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = 16 * kh + 4 * qr + i;
-            const unsigned long long dw = px_digit_word_checked(k0 + row < m ? sO[row][col] : 0.0, sh, c0 + col < bp.n_live ? bp.counts : nullptr);
+            const unsigned long long dw = px_digit_word_checked(k0 + row < m ? sO[row][col] : 0.0, sh, (c0 + col >= bp.c_live0 && c0 + col < bp.n_live) ? bp.counts : nullptr);
 #pragma unroll
             for (int s = 0; s < PX_S; ++s) w[s] |= px_digit_byte(dw, s) << (8 * i);
         }
@@ -345,7 +346,7 @@ __device__ __forceinline__ void b_pair_rows_planes(const BPlanes &bp, const doub
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = 16 * kh + 4 * qr + i;
-                const unsigned long long dw = px_digit_word_checked(kr0 + row < m ? sO[row][col] : 0.0, sh, c0 + col < bp.n_live ? bp.counts : nullptr);
+                const unsigned long long dw = px_digit_word_checked(kr0 + row < m ? sO[row][col] : 0.0, sh, (c0 + col >= bp.c_live0 && c0 + col < bp.n_live) ? bp.counts : nullptr);
 #pragma unroll
                 for (int s = 0; s < PX_S; ++s) w[s] |= px_digit_byte(dw, s) << (8 * i);
             }

@@ -458,7 +458,7 @@ __device__ __forceinline__ bool ps_b_rows_planes(const bool CHAINED, const PsArg
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = 16 * kh + 4 * qr + i;
-            const unsigned long long dw = px_digit_word_checked(k0 + row < m ? sO[row][col] : 0.0, sh, c0 + col < bp.n_live ? a.counts : nullptr);
+            const unsigned long long dw = px_digit_word_checked(k0 + row < m ? sO[row][col] : 0.0, sh, (c0 + col >= bp.c_live0 && c0 + col < bp.n_live) ? a.counts : nullptr);
 #pragma unroll
             for (int s = 0; s < PX_S; ++s) w[s] |= px_digit_byte(dw, s) << (8 * i);
         }

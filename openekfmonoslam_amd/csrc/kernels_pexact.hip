@@ -1432,7 +1432,7 @@ k_p_update_i8q(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__
 __global__ void __launch_bounds__(512, 2)
 k_b_gemm_i8p(const int8_t *__restrict__ Wq, int ldw, size_t w_stride, const int *__restrict__ wexp, const int8_t *__restrict__ Gq, int ldq,
              size_t g_stride, const int *__restrict__ gexp, int8_t *__restrict__ Bq, size_t b_stride, const int *__restrict__ bexp, int m,
-             int tiles_j, int tj0, int n_units_total, int *counts, int n_live)
+             int tiles_j, int tj0, int n_units_total, int *counts, int c_live0, int n_live)
 {
     constexpr int TM = 128, MB = 32, SLAB = PX_S * 8192;
     __shared__ __attribute__((aligned(16))) unsigned char ring[PX_RING * SLAB];
@@ -1534,7 +1534,7 @@ k_b_gemm_i8p(const int8_t *__restrict__ Wq, int ldw, size_t w_stride, const int 
                     for (int L = PX_S - 2; L >= 0; --L) tsum = fma(tsum, 1.0 / 256.0, (double)acc[x][L][r]);
                     const int gi = I0 + rbase + x * MB + li;
                     const double v = gi < m ? ldexp(tsum, se[rbase + x * MB + li] + ej - 12) : 0.0;
-                    const unsigned long long dw = px_digit_word_checked(v, shb, gj < n_live ? counts : nullptr);
+                    const unsigned long long dw = px_digit_word_checked(v, shb, (gj >= c_live0 && gj < n_live) ? counts : nullptr);
 #pragma unroll
                     for (int s = 0; s < PX_S; ++s) sBy[wv][s][idx][li - 16 * h] = (unsigned char)px_digit_byte(dw, s);
                 }
@@ -1579,7 +1579,7 @@ void launch_b_gemm_planes(EkfEngine *e, int m, int c_lo, int c_hi)
     const int tiles_i = (m + 127) / 128;
     const int n_units = tiles_i * tiles_j;
     k_b_gemm_i8p<<<std::min(e->n_cus, n_units), 512, 0, s>>>(e->d.Wq, ldw, w_stride, e->d.Wexp, e->d.Gq, ld, g_stride, e->d.Gexp, e->d.Bq,
-                                                           (size_t)e->bq_rows * ld, e->d.Bexp, m, tiles_j, tj0, n_units, e->d.counts, e->n);
+                                                           (size_t)e->bq_rows * ld, e->d.Bexp, m, tiles_j, tj0, n_units, e->d.counts, c_lo, std::min(e->n, c_hi));
 }
 
 // ------------------------------------------------------------------------------------------------ launcher

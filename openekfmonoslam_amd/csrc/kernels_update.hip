@@ -1641,6 +1641,8 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
                 cb0 = col_rb[e->shard_rank] / NB;
                 cb1 = (col_rb[e->shard_rank + 1] + NB - 1) / NB;
                 bp.bcol0 = cb0;
+                bp.c_live0 = col_rb[e->shard_rank]; // (the saturation check of the cut: this rank's own columns)
+                bp.n_live = std::min(n, (int)col_rb[e->shard_rank + 1]);
             }
             // the diagonal of P behind the a-priori column scales: every rank's own entries, then all of them
             launch_diag_extract(e, e->d.Pdiag);
