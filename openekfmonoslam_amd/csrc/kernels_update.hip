@@ -1712,9 +1712,10 @@ static void update_impl(EkfEngine *e, int M, bool update_cov)
             // (rows of B in the sweep: the rank's 32-column blocks; inverse + GEMM: its 128-column tiles, rounded outwards like the GEMM's)
             const int c_lo = planes_b ? cb0 * NB : col_rb[e->shard_rank] / 128 * 128;
             const int c_hi = planes_b ? cb1 * NB : std::min(n_pad, round_up(col_rb[e->shard_rank + 1], 128));
-            // the transposed image of the own block columns of S for the exchange: W where the sweep forms B (nobody reads it there), the
-            // scratch of the triangular inverse where W will hold inv(L)' (its other triangle must stay zero)
-            double *St = planes_b ? e->d.W : e->d.Tbuf;
+            // the transposed image of the own block columns of S for the exchange: the scratch of the triangular inverse
+            // (always the inverse's scratch: round 5 used W below 2048 rows, which left W's other triangle dirty for a LATER update that
+            // takes the inverse + GEMM route -- W = inv(L)' must be zero there; found by the saturation check of the cut, round 6)
+            double *St = e->d.Tbuf;
             const int b_lo = e->shard_rb[e->shard_rank] / 2, b_hi = e->shard_rb[e->shard_rank + 1] / 2;
             if (c_lo > 0) k_g_cols<T><<<dim3(1, (m_pad + 63) / 64), 256, 0, s>>>((const T *)e->d.P, ld, e->rm, n, M, e->d.mHs, e->d.mHf, e->d.mpos,
                                                                           e->d.mdim, (double *)G, ld, 0, NB, m_pad);

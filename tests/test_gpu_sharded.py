@@ -278,6 +278,38 @@ def test_in_stream_exchange_with_several_ranks_through_a_mock_rccl(eng_mod, tmp_
     assert st[0]["received"] == d["callback_bytes_rank0"], (st[0], d["callback_bytes_rank0"])
 
 
+def test_a_large_update_after_smaller_ones_on_a_sharded_exact_engine(eng_mod):
+    """Regression (round 6, found by the saturation check of the digit cut): on a row-sharded exact engine an update of at most 2048 rows
+    kept the exchange image of S's columns in W, and a LATER update above 2048 rows -- the inverse + GEMM route, which needs W = inv(L)'
+    with zeros in its other triangle -- formed B from the dirt.  N = 1300 on three ranks: frames 0 and 1 (the second frame's
+    low-innovation update is a sweep-route update of ~1500 rows), then the initial filter again and frame 0 once more (its
+    high-innovation update has ~2200 rows: the GEMM route) -- the same engines must end where fresh ones end after frame 0."""
+    N, world = 1300, 3
+    seq = SyntheticSequence(N, 2)
+    P0 = _sym(seq.P0)
+    kw = dict(max_keypoints=4 * N + 64, precision=2)
+
+    def frame0_after(prior_frames):
+        grp = LocalShardGroup(seq.cam, seq.par, N, world, **kw)
+        grp.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, P0)
+        infos = grp.run(lambda r, e: [e.step(*seq.frames[t]) for t in range(prior_frames)])
+        if prior_frames:
+            assert 2 * infos[0][1].n_inliers <= 2048 < 2 * infos[0][0].n_rescued, (infos[0][1].n_inliers, infos[0][0].n_rescued)
+            grp.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, P0)
+        i0 = grp.run(lambda r, e: e.step(*seq.frames[0]))
+        x, fp, P = grp.get_state()
+        grp.close()
+        return i0[0], x, fp, P
+
+    ia, xa, fpa, Pa = frame0_after(2)
+    ib, xb, fpb, Pb = frame0_after(0)
+    for f in INFO_FIELDS:
+        assert getattr(ia, f) == getattr(ib, f), f
+    np.testing.assert_array_equal(xa, xb)
+    np.testing.assert_array_equal(fpa, fpb)
+    np.testing.assert_array_equal(Pa, Pb)
+
+
 def test_stage_calls_after_a_sharded_step_complete_the_table(eng_mod):
     """ekf_update on a caller-ordered match list (stateless stage call) after a step: the engine completes the H.P table first
     (the step left it with the owners' rows only) -- result equal to the unsharded engine's."""
