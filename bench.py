@@ -543,6 +543,12 @@ def main():
                                           "stays priced against the derived 5033",
                     "note": "`traffic` is read from the committed PMC passes over this bench's own frames (traffic_source), not "
                             "collected in this run; `achieved` and `avg_launch_ms` are HIP events of this run on the engine's stream",
+                    "nominal_ops_note": "`achieved` counts the NOMINAL 15 digit products per multiply-add.  The kernel leaves out the "
+                                        "products whose plane-0 operand piece (16 rows x 32 columns) is all zeros -- the integer sums "
+                                        "are the same bit for bit -- so on frames with many such pieces (a fresh map: the n5000 "
+                                        "workloads' first frames, profiles/r06_plane0_pieces.txt) `achieved` is an effective rate, above "
+                                        "what the MFMA pipe executed; on the headline's frames 35-90 % of the pieces are non-zero and a "
+                                        "unit with less than a quarter of zero pieces takes the dense step",
                     "int8_ops_per_launch": PX_PRODUCTS * flops,
                     "fp32_equivalent_tflops": ach,
                     "fp32_equivalent_note": "algorithmic n^2 m flop / launch time: comparable with the fp32 MFMA kernel's "

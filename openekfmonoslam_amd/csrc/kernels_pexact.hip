@@ -33,6 +33,7 @@ namespace ekf {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------ column scales
 // bexp[j] = max over k of the biased exponent field of B[k][j] (0 for an all-zero column): |B_kj| < 2^(bexp - 1022).
@@ -561,6 +562,8 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
     __shared__ __attribute__((aligned(16))) float sTall[8 * MB * ST];
     __shared__ int sExp[2][2 * TM];
     __shared__ int sMeta[2];
+    constexpr int PX_ZCH = 8; // chunks of 64 steps whose zero-piece masks a wavefront keeps
+    __shared__ unsigned long long sZ[8 * 3 * PX_ZCH];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv >> 2, wc = wv & 3;
@@ -641,30 +644,54 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
             sExp[ui & 1][tid] = c < n ? bexp[c] - 1022 : 0;
         }
         // which steps of this unit find an all-zero piece of digit plane 0 in the wavefront's two blocks of A rows and in its block of
-        // B columns (px_flag_plane0): lane t looks at step t's two 16-row groups; bit t set = something there.  Units of more than 64
-        // steps (updates above 2048 rows) multiply everything.
+        // B columns (px_flag_plane0): lane t looks at step 64 c + t's two 16-row groups; bit t of chunk c's mask set = something
+        // there.  The masks of chunk 0 stay in scalar registers; a unit of more than 64 steps (an update above 2048 rows) parks the
+        // others in the wavefront's corner of sZ and fetches the next three every 64 steps.  Units of more than 64 PX_ZCH steps
+        // (updates above 16384 rows) multiply everything.
         unsigned long long nzA0 = ~0ull, nzA1 = ~0ull, nzB = ~0ull;
-        const bool skipz = PX_SKIP_ZERO && bz != nullptr && nk <= 64;
+        const int n_ch = (nk + 63) >> 6;
+        const bool skipz = PX_SKIP_ZERO && bz != nullptr && n_ch <= PX_ZCH;
+        const unsigned sz_lds = (unsigned)(size_t)(lptr_t)&sZ[wv * 3 * PX_ZCH];
+        int n_zero = 0;
         if (skipz) {
             // (a block of 32 columns of B is one column block of the table -- or, on a row-sharded engine whose owned rows do not
             // start on a multiple of 32, straddles two: then both count)
-            const bool on = lane < nk;
-            auto piece = [&](int col) -> unsigned {
-                const unsigned short *pz = reinterpret_cast<const unsigned short *>(bz + (size_t)(col >> 5) * bz_stride);
-                unsigned f = on ? pz[lane] : 0u;
-                if (RECT && (col & 31)) f |= on ? pz[(bz_stride >> 1) + lane] : 0u;
-                return f;
-            };
             const int colA = I0 + rbase;
-            const unsigned fa0 = piece(colA), fa1 = piece(colA + MB), fb = piece(J0 + wc * MB);
-            nzA0 = __ballot(fa0 != 0u);
-            nzA1 = __ballot(fa1 != 0u);
-            nzB = __ballot(fb != 0u);
+            for (int c = n_ch - 1; c >= 0; --c) {
+                const int step = 64 * c + lane;
+                const bool on = step < nk;
+                auto piece = [&](int col) -> unsigned {
+                    const unsigned short *pz = reinterpret_cast<const unsigned short *>(bz + (size_t)(col >> 5) * bz_stride);
+                    unsigned f = on ? pz[step] : 0u;
+                    if (RECT && (col & 31)) f |= on ? pz[(bz_stride >> 1) + step] : 0u;
+                    return f;
+                };
+                const unsigned fa0 = piece(colA), fa1 = piece(colA + MB), fb = piece(J0 + wc * MB);
+                nzA0 = __ballot(fa0 != 0u);
+                nzA1 = __ballot(fa1 != 0u);
+                nzB = __ballot(fb != 0u);
+                const int cnt = nk - 64 * c < 64 ? nk - 64 * c : 64;
+                n_zero += (cnt - __popcll(nzA0)) + (full ? cnt - __popcll(nzA1) : 0) + (cnt - __popcll(nzB));
+                if (n_ch > 1) { // (every lane writes the same three words; asm: see px_step_ring on LDS accesses the compiler can see)
+                    asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:%4\n\tds_write_b64 %0, %3 offset:%5"
+                                 :: "v"(sz_lds + 8u * c), "v"(nzA0), "v"(nzA1), "v"(nzB), "n"(8 * PX_ZCH), "n"(16 * PX_ZCH) : "memory");
+                }
+            }
         }
+        auto z_fetch = [&](int c) { // chunk c's three masks back from sZ (this wavefront wrote them; LDS is in order per wavefront)
+            v2u a, b, d;
+            asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:%4\n\tds_read_b64 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(a), "=&v"(b), "=&v"(d) : "v"(sz_lds + 8u * c), "n"(8 * PX_ZCH), "n"(16 * PX_ZCH) : "memory");
+            auto u64 = [](v2u v) {
+                return (unsigned long long)__builtin_amdgcn_readfirstlane(v[0]) | ((unsigned long long)__builtin_amdgcn_readfirstlane(v[1]) << 32);
+            };
+            nzA0 = u64(a);
+            nzA1 = u64(b);
+            nzB = u64(d);
+        };
         // a unit takes the skipping form of the step when at least a quarter of its plane-0 pieces are zero: on a fresh map 85-90 % of
         // them are, once the filter has converged the columns of B are flat and 20-40 % are (profiles/r06_plane0_pieces.txt) -- and the
         // skipping step costs ~4 % where it has nothing to skip (its optional reads and branches)
-        const int n_zero = skipz ? (nk - __popcll(nzA0)) + (full ? nk - __popcll(nzA1) : 0) + (nk - __popcll(nzB)) : 0;
         const bool sparse_unit = __builtin_amdgcn_readfirstlane(skipz && 4 * n_zero >= (full ? 3 : 2) * nk ? 1 : 0) != 0;
         v16i acc[2][PX_S];
 #if !PX_ZERO_C || PX_SKIP_ZERO // (PX_ZERO_C: the unit's first step starts the accumulators with the constant 0 as C; not with skipped products)
@@ -692,6 +719,7 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
         if (!late && !(PX_ABL & 2)) { PXP_ISSUE() }                                                                           \
         if (PX_PRIO) __builtin_amdgcn_s_setprio(2);                                                                           \
         if (PX_SKIP_ZERO && (SPARSE_)) {                                                                                      \
+            if ((T_) > 0 && ((T_) & 63) == 0) z_fetch((T_) >> 6);                                                             \
             const bool za0_ = !((nzA0 >> ((T_) & 63)) & 1ull), za1_ = !((nzA1 >> ((T_) & 63)) & 1ull), zb_ = !((nzB >> ((T_) & 63)) & 1ull);       \
             px_step_ring_z<FULL_>(ring_lds + (g % PX_RING) * SLAB + offA, ring_lds + (g % PX_RING) * SLAB + offB, acc, za0_, za1_, zb_); \
         } else                                                                                                                \
