@@ -136,7 +136,7 @@ void ekf_engine_destroy(EkfEngine *e)
                     d.mt_valid,  d.mt_kp,     d.mt_dist,   d.matches,     d.msel,      d.mout,     d.match_of_feat,
                     d.hyp_count, d.hyp_flags, d.best_flags, d.A,          d.S,         d.nu,       d.Dinv,     d.W, d.Wf, d.G, d.LL, d.LLf, d.Tbuf, d.gates, d.cell_resp, d.cell_xy,
                     d.mHs,       d.mHf,       d.mpos,      d.mdim,        d.dx_part,   d.mask,     d.preds_out, d.sq_part, d.diag_save, d.cam_part, d.cam_save, d.HPc, d.Gc, d.Bc, d.zvec, d.yvec,
-                    e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq, d.sweep_ctl, d.pu_ctr, d.Bq, d.Bexp, d.Bz, d.Lq, d.Lexp, d.Grow, d.Pdiag, d.Bstage, d.Wq, d.Gq, d.Wexp, d.Gexp};
+                    e->frames.kps, e->frames.desc, d.mt_xy, d.tmpl, e->img.px[0], e->img.px[1], e->img.px[2], e->img.px2[0], e->img.px2[1], e->img.px2[2], e->img.raw, e->img.seq, d.sweep_ctl, d.pu_ctr, d.Bq, d.Bexp, d.Bz, d.Lq, d.Lexp, d.Grow, d.Pdiag, d.Bstage, d.Wq, d.Gq, d.Wexp, d.Gexp, d.Wz, d.Gz};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &kv : e->pu_tables)
@@ -282,6 +282,9 @@ static int create_impl(const EkfEngineConfig *cfg, int rank, int world, EkfEngin
                 if ((st = dalloc(&d.Gq, (size_t)PX_S * e->bq_rows * e->ldP)) != hipSuccess) return fail(st, "hipMalloc Gq");
                 if ((st = dalloc(&d.Wexp, (size_t)round_up((int)mcap, 128) + 128)) != hipSuccess) return fail(st, "hipMalloc Wexp");
                 if ((st = dalloc(&d.Gexp, (size_t)e->ldP)) != hipSuccess) return fail(st, "hipMalloc Gexp");
+                // their tables of non-zero pieces of plane 0 (k_slice_B writes them, k_b_gemm_i8p reads them)
+                if ((st = dalloc(&d.Wz, (size_t)((round_up((int)mcap, 128) + 128) / 32 + 8) * e->bz_stride)) != hipSuccess) return fail(st, "hipMalloc Wz");
+                if ((st = dalloc(&d.Gz, (size_t)(e->ldP / 32 + 8) * e->bz_stride)) != hipSuccess) return fail(st, "hipMalloc Gz");
             }
             if (world > 1) { // sharded: the diagonal table and the exchange image of the planes (rows of B up to B_SWEEP_MAX)
                 if ((st = dalloc(&d.Pdiag, (size_t)e->ldP)) != hipSuccess) return fail(st, "hipMalloc Pdiag");

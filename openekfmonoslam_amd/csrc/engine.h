@@ -148,6 +148,7 @@ struct DeviceArrays {
     int *Bexp = nullptr;        // its column scales (biased exponents), ldP ints
     uint8_t *Bz = nullptr;      // ... and which 16-row x 32-column pieces of digit plane 0 hold anything but zeros: [column / 32][bz_stride] bytes
                                 // (written with the planes' last reader before the downdate, k_dx_planes / k_slice_B; read by k_p_update_i8p)
+    uint8_t *Wz = nullptr, *Gz = nullptr; // the same tables for the planes of inv(L)' and of G (B = inv(L) G above B_SWEEP_MAX rows)
     int8_t *Lq = nullptr;       // digit planes of L for the rows of B formed from planes (chol_bplanes.h): PX_S x lq_nbk^2 KB
     int *Lexp = nullptr;        // row scales of L (biased exponents)
     int *Grow = nullptr;        // row of the H P table behind every gathered row (k_gather without the copy)

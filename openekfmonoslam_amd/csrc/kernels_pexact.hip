@@ -541,6 +541,39 @@ __device__ __forceinline__ void px_step_ring_z(unsigned ldsA, unsigned ldsB, v16
 //     the old values are requested when the unit starts (32 registers), the new ones leave as fire-and-forget stores.
 constexpr int PX_RING = 3;
 
+// Zero-piece masks of a unit (px_flag_plane0's table): lane t of a wavefront looks at step 64 c + t's two 16-row groups of one block
+// of 32 columns; a ballot makes the chunk's 64-bit mask (bit t set = something there).  Chunk 0 stays in scalar registers, the
+// others are parked in the wavefront's 24 PX_ZCH bytes of LDS and fetched back every 64 steps -- through asm: an LDS access the
+// compiler can see makes it drain the LDS-DMA ring first (see px_step_ring).
+constexpr int PX_ZCH = 8; // chunks of 64 steps whose masks a wavefront keeps: units of up to 512 steps (16384 rows)
+__device__ __forceinline__ unsigned px_piece_flags(const uint8_t *bz, int bz_stride, int col, int step, bool on, bool straddle)
+{
+    const unsigned short *pz = reinterpret_cast<const unsigned short *>(bz + (size_t)(col >> 5) * bz_stride);
+    unsigned f = on ? pz[step] : 0u;
+    // (a block of 32 columns is one column block of the table -- or, on a row-sharded engine whose owned rows do not start on a
+    // multiple of 32, straddles two: then both count)
+    if (straddle && (col & 31)) f |= on ? pz[(bz_stride >> 1) + step] : 0u;
+    return f;
+}
+__device__ __forceinline__ void px_zmask_park(unsigned addr, unsigned long long a0, unsigned long long a1, unsigned long long b)
+{ // (every lane writes the same three words)
+    asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:%4\n\tds_write_b64 %0, %3 offset:%5"
+                 :: "v"(addr), "v"(a0), "v"(a1), "v"(b), "n"(8 * PX_ZCH), "n"(16 * PX_ZCH) : "memory");
+}
+__device__ __forceinline__ void px_zmask_fetch(unsigned addr, unsigned long long &a0, unsigned long long &a1, unsigned long long &b)
+{ // (this wavefront wrote them; LDS is in order per wavefront)
+    v2u x, y, z;
+    asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:%4\n\tds_read_b64 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x), "=&v"(y), "=&v"(z) : "v"(addr), "n"(8 * PX_ZCH), "n"(16 * PX_ZCH) : "memory");
+    auto u64 = [](v2u v) {
+        return (unsigned long long)__builtin_amdgcn_readfirstlane(v[0]) | ((unsigned long long)__builtin_amdgcn_readfirstlane(v[1]) << 32);
+    };
+    a0 = u64(x);
+    a1 = u64(y);
+    b = u64(z);
+}
+
+
 // RECT (row-sharded storage; see k_p_update): the rank owns row tiles, not a triangle -- tile row 0 is the replicated
 // camera block (13 live rows), tile row t >= 1 holds the owned global rows rm.r0 + (t - 1) TM ..., stored from local row
 // rm.base on; every (row tile, column tile) pair is computed and written in place, nothing is mirrored.  The integer sums of
@@ -562,8 +595,7 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
     __shared__ __attribute__((aligned(16))) float sTall[8 * MB * ST];
     __shared__ int sExp[2][2 * TM];
     __shared__ int sMeta[2];
-    constexpr int PX_ZCH = 8; // chunks of 64 steps whose zero-piece masks a wavefront keeps
-    __shared__ unsigned long long sZ[8 * 3 * PX_ZCH];
+    __shared__ unsigned long long sZ[8 * 3 * PX_ZCH]; // zero-piece masks of the later chunks of a long unit, per wavefront
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv >> 2, wc = wv & 3;
@@ -644,51 +676,28 @@ k_p_update_i8p(TP *__restrict__ P, int ldp, int n, const int8_t *__restrict__ Bq
             sExp[ui & 1][tid] = c < n ? bexp[c] - 1022 : 0;
         }
         // which steps of this unit find an all-zero piece of digit plane 0 in the wavefront's two blocks of A rows and in its block of
-        // B columns (px_flag_plane0): lane t looks at step 64 c + t's two 16-row groups; bit t of chunk c's mask set = something
-        // there.  The masks of chunk 0 stay in scalar registers; a unit of more than 64 steps (an update above 2048 rows) parks the
-        // others in the wavefront's corner of sZ and fetches the next three every 64 steps.  Units of more than 64 PX_ZCH steps
-        // (updates above 16384 rows) multiply everything.
+        // B columns (px_piece_flags above).  Units of more than 64 PX_ZCH steps (updates above 16384 rows) multiply everything.
         unsigned long long nzA0 = ~0ull, nzA1 = ~0ull, nzB = ~0ull;
         const int n_ch = (nk + 63) >> 6;
         const bool skipz = PX_SKIP_ZERO && bz != nullptr && n_ch <= PX_ZCH;
         const unsigned sz_lds = (unsigned)(size_t)(lptr_t)&sZ[wv * 3 * PX_ZCH];
         int n_zero = 0;
         if (skipz) {
-            // (a block of 32 columns of B is one column block of the table -- or, on a row-sharded engine whose owned rows do not
-            // start on a multiple of 32, straddles two: then both count)
             const int colA = I0 + rbase;
-            for (int c = n_ch - 1; c >= 0; --c) {
+            for (int c = n_ch - 1; c >= 0; --c) { // (downwards: chunk 0's masks are the ones left in the registers)
                 const int step = 64 * c + lane;
                 const bool on = step < nk;
-                auto piece = [&](int col) -> unsigned {
-                    const unsigned short *pz = reinterpret_cast<const unsigned short *>(bz + (size_t)(col >> 5) * bz_stride);
-                    unsigned f = on ? pz[step] : 0u;
-                    if (RECT && (col & 31)) f |= on ? pz[(bz_stride >> 1) + step] : 0u;
-                    return f;
-                };
-                const unsigned fa0 = piece(colA), fa1 = piece(colA + MB), fb = piece(J0 + wc * MB);
+                const unsigned fa0 = px_piece_flags(bz, bz_stride, colA, step, on, RECT), fa1 = px_piece_flags(bz, bz_stride, colA + MB, step, on, RECT);
+                const unsigned fb = px_piece_flags(bz, bz_stride, J0 + wc * MB, step, on, RECT);
                 nzA0 = __ballot(fa0 != 0u);
                 nzA1 = __ballot(fa1 != 0u);
                 nzB = __ballot(fb != 0u);
                 const int cnt = nk - 64 * c < 64 ? nk - 64 * c : 64;
                 n_zero += (cnt - __popcll(nzA0)) + (full ? cnt - __popcll(nzA1) : 0) + (cnt - __popcll(nzB));
-                if (n_ch > 1) { // (every lane writes the same three words; asm: see px_step_ring on LDS accesses the compiler can see)
-                    asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:%4\n\tds_write_b64 %0, %3 offset:%5"
-                                 :: "v"(sz_lds + 8u * c), "v"(nzA0), "v"(nzA1), "v"(nzB), "n"(8 * PX_ZCH), "n"(16 * PX_ZCH) : "memory");
-                }
+                if (n_ch > 1) px_zmask_park(sz_lds + 8u * c, nzA0, nzA1, nzB);
             }
         }
-        auto z_fetch = [&](int c) { // chunk c's three masks back from sZ (this wavefront wrote them; LDS is in order per wavefront)
-            v2u a, b, d;
-            asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:%4\n\tds_read_b64 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(a), "=&v"(b), "=&v"(d) : "v"(sz_lds + 8u * c), "n"(8 * PX_ZCH), "n"(16 * PX_ZCH) : "memory");
-            auto u64 = [](v2u v) {
-                return (unsigned long long)__builtin_amdgcn_readfirstlane(v[0]) | ((unsigned long long)__builtin_amdgcn_readfirstlane(v[1]) << 32);
-            };
-            nzA0 = u64(a);
-            nzA1 = u64(b);
-            nzB = u64(d);
-        };
+        auto z_fetch = [&](int c) { px_zmask_fetch(sz_lds + 8u * c, nzA0, nzA1, nzB); };
         // a unit takes the skipping form of the step when at least a quarter of its plane-0 pieces are zero: on a fresh map 85-90 % of
         // them are, once the filter has converged the columns of B are flat and 20-40 % are (profiles/r06_plane0_pieces.txt) -- and the
         // skipping step costs ~4 % where it has nothing to skip (its optional reads and branches)
@@ -1460,12 +1469,14 @@ k_p_update_i8q(float *__restrict__ P, int ldp, int n, const int8_t *__restrict__
 __global__ void __launch_bounds__(512, 2)
 k_b_gemm_i8p(const int8_t *__restrict__ Wq, int ldw, size_t w_stride, const int *__restrict__ wexp, const int8_t *__restrict__ Gq, int ldq,
              size_t g_stride, const int *__restrict__ gexp, int8_t *__restrict__ Bq, size_t b_stride, const int *__restrict__ bexp, int m,
-             int tiles_j, int tj0, int n_units_total, int *counts, int c_live0, int n_live)
+             int tiles_j, int tj0, int n_units_total, int *counts, int c_live0, int n_live, const uint8_t *__restrict__ wz,
+             const uint8_t *__restrict__ gz, int bz_stride)
 {
     constexpr int TM = 128, MB = 32, SLAB = PX_S * 8192;
     __shared__ __attribute__((aligned(16))) unsigned char ring[PX_RING * SLAB];
     __shared__ __attribute__((aligned(16))) unsigned char sBy[8][PX_S][MB][16]; // per wavefront: digit bytes [plane][column][16 rows]
     __shared__ int sExp[2][2 * TM];
+    __shared__ unsigned long long sZ[8 * 3 * PX_ZCH]; // zero-piece masks (k_p_update_i8p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv >> 2, wc = wv & 3;
@@ -1535,14 +1546,49 @@ k_b_gemm_i8p(const int8_t *__restrict__ Wq, int ldw, size_t w_stride, const int 
             for (int L = 0; L < PX_S; ++L)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[x][L][r] = 0;
-        for (int t = 0; t < nk; ++t, ++g) {
-            if (g + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PX_S) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (!late) { BG_ISSUE() }
-            px_step_ring<true>(ring_lds + (g % PX_RING) * SLAB + offA, ring_lds + (g % PX_RING) * SLAB + offB, acc);
-            if (late) { BG_ISSUE() }
+        // zero pieces of plane 0 of W' (the wavefront's two blocks of rows of inv(L)) and of G (its block of columns), as in the
+        // downdate: inv(L) and G = H P have their large entries at the matched features' own rows and columns on a fresh map
+        unsigned long long nzA0 = ~0ull, nzA1 = ~0ull, nzB = ~0ull;
+        const int n_ch = (nk + 63) >> 6;
+        const bool skipz = PX_SKIP_ZERO && wz != nullptr && n_ch <= PX_ZCH;
+        const unsigned sz_lds = (unsigned)(size_t)(lptr_t)&sZ[wv * 3 * PX_ZCH];
+        int n_zero = 0;
+        if (skipz) {
+            for (int c = n_ch - 1; c >= 0; --c) {
+                const int step = 64 * c + lane;
+                const bool on = step < nk;
+                const unsigned fa0 = px_piece_flags(wz, bz_stride, I0 + rbase, step, on, false);
+                const unsigned fa1 = px_piece_flags(wz, bz_stride, I0 + rbase + MB, step, on, false);
+                const unsigned fb = px_piece_flags(gz, bz_stride, J0 + wc * MB, step, on, false);
+                nzA0 = __ballot(fa0 != 0u);
+                nzA1 = __ballot(fa1 != 0u);
+                nzB = __ballot(fb != 0u);
+                const int cnt = nk - 64 * c < 64 ? nk - 64 * c : 64;
+                n_zero += 3 * cnt - __popcll(nzA0) - __popcll(nzA1) - __popcll(nzB);
+                if (n_ch > 1) px_zmask_park(sz_lds + 8u * c, nzA0, nzA1, nzB);
+            }
         }
+        const bool sparse_unit = __builtin_amdgcn_readfirstlane(skipz && 4 * n_zero >= 3 * nk ? 1 : 0) != 0;
+#define BG_STEP(SPARSE_)                                                                                                      \
+    {                                                                                                                         \
+        if (g + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PX_S) : "memory");                                        \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                       \
+        if (!late) { BG_ISSUE() }                                                                                             \
+        if (SPARSE_) {                                                                                                        \
+            if (t > 0 && (t & 63) == 0) px_zmask_fetch(sz_lds + 8u * (t >> 6), nzA0, nzA1, nzB);                              \
+            const bool za0_ = !((nzA0 >> (t & 63)) & 1ull), za1_ = !((nzA1 >> (t & 63)) & 1ull), zb_ = !((nzB >> (t & 63)) & 1ull); \
+            px_step_ring_z<true>(ring_lds + (g % PX_RING) * SLAB + offA, ring_lds + (g % PX_RING) * SLAB + offB, acc, za0_, za1_, zb_); \
+        } else                                                                                                                \
+            px_step_ring<true>(ring_lds + (g % PX_RING) * SLAB + offA, ring_lds + (g % PX_RING) * SLAB + offB, acc);          \
+        if (late) { BG_ISSUE() }                                                                                              \
+    }
+        if (sparse_unit) {
+            for (int t = 0; t < nk; ++t, ++g) BG_STEP(true)
+        } else {
+            for (int t = 0; t < nk; ++t, ++g) BG_STEP(false)
+        }
+#undef BG_STEP
         // epilogue: B_ij = 2^(e_i + e_j - 12) sum_L acc_L 256^-L, cut with the a-priori scale of column j into PX_S digit bytes, through
         // the wavefront's byte image [plane][column][row] into the planes' 16-byte groups (16 consecutive rows of one column)
         const int *se = sExp[ui & 1];
@@ -1597,17 +1643,19 @@ void launch_b_gemm_planes(EkfEngine *e, int m, int c_lo, int c_hi)
     // digit planes of W' (columns = rows of inv(L)) and of G, each with its columns' true scales
     (void)hipMemsetAsync(e->d.Wexp, 0, sizeof(int) * (size_t)ldw, s);
     k_col_exp<<<dim3((mw_pad + 255) / 256, PX_KSPLIT), 256, 0, s>>>(e->d.W, ldw, m, mw_pad, nullptr, e->d.Wexp);
-    k_slice_B<<<dim3(mw_pad / 64, (m_k + 63) / 64), 256, 0, s>>>(e->d.W, ldw, m, m_k, nullptr, e->d.Wexp, e->d.Wq, ldw, w_stride, 0, mw_pad, nullptr, 0);
+    k_slice_B<<<dim3(mw_pad / 64, (m_k + 63) / 64), 256, 0, s>>>(e->d.W, ldw, m, m_k, nullptr, e->d.Wexp, e->d.Wq, ldw, w_stride, 0, mw_pad, e->d.Wz,
+                                                                e->bz_stride);
     const int tj0 = c_lo / 128, tiles_j = (std::min(c_hi, n_pad) + 127) / 128 - tj0;
     const int g_lo = tj0 * 128, g_hi = (tj0 + tiles_j) * 128;
     (void)hipMemsetAsync(e->d.Gexp, 0, sizeof(int) * (size_t)ld, s);
     k_col_exp<<<dim3((n_pad + 255) / 256, PX_KSPLIT), 256, 0, s>>>((const double *)e->d.G, ld, m, n_pad, nullptr, e->d.Gexp);
     k_slice_B<<<dim3((g_hi - g_lo) / 64, (m_k + 63) / 64), 256, 0, s>>>((const double *)e->d.G, ld, m, m_k, nullptr, e->d.Gexp, e->d.Gq, ld, g_stride,
-                                                                      g_lo, g_hi, nullptr, 0);
+                                                                      g_lo, g_hi, e->d.Gz, e->bz_stride);
     const int tiles_i = (m + 127) / 128;
     const int n_units = tiles_i * tiles_j;
     k_b_gemm_i8p<<<std::min(e->n_cus, n_units), 512, 0, s>>>(e->d.Wq, ldw, w_stride, e->d.Wexp, e->d.Gq, ld, g_stride, e->d.Gexp, e->d.Bq,
-                                                           (size_t)e->bq_rows * ld, e->d.Bexp, m, tiles_j, tj0, n_units, e->d.counts, c_lo, std::min(e->n, c_hi));
+                                                           (size_t)e->bq_rows * ld, e->d.Bexp, m, tiles_j, tj0, n_units, e->d.counts, c_lo, std::min(e->n, c_hi),
+                                                           e->d.Wz, e->d.Gz, e->bz_stride);
 }
 
 // ------------------------------------------------------------------------------------------------ launcher
