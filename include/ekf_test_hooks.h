@@ -23,6 +23,10 @@ int ekf_debug_stall_sweep_after(EkfEngine *e, int skip);
 /* Exact configurations: how many 16-row x 32-column pieces of digit plane 0 of B held anything but zeros in the LAST update, of how
  * many (the downdate skips the digit products of the all-zero ones: csrc/kernels_pexact.hip, px_flag_plane0). */
 int ekf_debug_plane0_pieces(EkfEngine *e, int *nonzero, int *total);
+/* on != 0: the exact downdate and the int8 GEMM B = inv(L) G multiply EVERY digit product, the tables of zero pieces are not
+ * consulted (they are still written).  The results must be the same bit for bit either way -- which is what the suite checks with
+ * two engines on the same frames (tests/test_gpu_exact_edge_cases.py). */
+int ekf_debug_dense_products(EkfEngine *e, int on);
 
 #ifdef __cplusplus
 }

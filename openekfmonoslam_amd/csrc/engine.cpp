@@ -2073,6 +2073,13 @@ int ekf_debug_stall_next_sweep(EkfEngine *e) // include/ekf_test_hooks.h
     return EKF_OK;
 }
 
+int ekf_debug_dense_products(EkfEngine *e, int on)
+{
+    if (!e) return EKF_ERR_INVALID_ARG;
+    e->px_dense = on != 0;
+    return EKF_OK;
+}
+
 int ekf_debug_plane0_pieces(EkfEngine *e, int *nonzero, int *total)
 {
     if (!e || !nonzero || !total || !e->d.Bz) return EKF_ERR_INVALID_ARG;

@@ -262,6 +262,7 @@ struct EkfEngine {
     int pu_per_xcd = 0;
     int bq_rows = 0;          // rows of B a digit plane holds (multiple of 64)
     int bz_stride = 0;        // 16-row groups per column block of d.Bz (= bq_rows / 16)
+    bool px_dense = false;    // include/ekf_test_hooks.h: the downdate and the int8 GEMM multiply every digit product (the tables are not consulted)
     int px_scale_shift = 0;   // bits of head-room added to the a-priori column scales of B (exponent of sqrt(P_jj)); EKF_PX_SCALE_SHIFT in the
                               // environment sets it (a measurement knob).  With 1 / 2 bits digit plane 0 is 82 / 95-97 % zero pieces on converged
                               // maps too and the downdate skips their products: 1187 -> 1266 updates/s at N = 1000 -- but the 38-bit integers are

@@ -121,6 +121,7 @@ TEST_HOOKS = {
     "ekf_debug_stall_next_sweep": (_i, [_vp]),
     "ekf_debug_stall_sweep_after": (_i, [_vp, _i]),
     "ekf_debug_plane0_pieces": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "ekf_debug_dense_products": (_i, [_vp, _i]),
 }
 
 # int fn(void *user, int what, void *device_base, size_t row_bytes, const int32_t *row_begin, int world, int rank)
@@ -323,6 +324,10 @@ class EkfEngine:
         a, b = _i(0), _i(0)
         self._chk(self.L.ekf_debug_plane0_pieces(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def dense_products(self, on=True):
+        """test hook: the exact downdate / int8 GEMM multiply every digit product (the zero-piece tables are not consulted)"""
+        self._chk(self.L.ekf_debug_dense_products(self.h, 1 if on else 0))
 
     def set_update_path(self, path):
         """0: by size, 1: B = inv(L) H P inside the Cholesky sweep, 2: explicit inverse + GEMM (ekf_engine.h)"""

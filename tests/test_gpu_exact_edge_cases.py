@@ -310,6 +310,33 @@ def test_concurrent_exact_engines_give_the_sequential_result(eng_mod):
             assert np.array_equal(np.asarray(a), np.asarray(b)), k
 
 
+@pytest.mark.parametrize("nfeat,frames,precision", [pytest.param(1000, 3, EXACT, id="n1000_f32_stored"), pytest.param(1400, 2, EXACT, id="n1400_above_2048_rows"),
+                                                    pytest.param(1400, 2, 3, id="n1400_f64_stored")])
+def test_skipping_the_zero_pieces_of_plane_0_changes_no_bit(eng_mod, nfeat, frames, precision):
+    """the downdate (and, above 2048 rows, the int8 GEMM B = inv(L) G) leave out the digit products whose plane-0 operand piece is
+    all zeros; with the hook that makes them multiply everything (include/ekf_test_hooks.h) the state, every feature and P must be
+    the same bit for bit.  Fresh maps: most pieces ARE zero, the skipping step is the one that runs; N = 1400: updates of ~2500
+    rows, whose zero-piece masks span several 64-step chunks.  (Launch-per-panel sweep: the persistent one orders its sums by arrival.)"""
+    seq = SyntheticSequence(nfeat, frames)
+    out = []
+    for dense in (False, True):
+        e = eng_mod.EkfEngine(seq.cam, seq.par, nfeat + 8, max_keypoints=len(seq.frames[0][0]) + 64, precision=precision)
+        e.set_sweep_mode(4)
+        e.dense_products(dense)
+        e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
+        infos = [e.step(*seq.frames[t]) for t in range(frames)]
+        nz, tot = e.plane0_pieces()
+        out.append((e.get_state(), [(int(i.n_inliers), int(i.n_rescued)) for i in infos], nz, tot))
+        e.close()
+    (sa, ia, nz, tot), (sb, ib, _, _) = out
+    assert ia == ib
+    if nfeat > 1024:
+        assert 2 * max(ia[0]) > 2048, ia  # an update above 2048 rows was among them
+    assert tot > 0 and 2 * nz < tot, (nz, tot)  # the data did have zero pieces to skip
+    for a, b in zip(sa, sb):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 def test_exact_configuration_refuses_maps_whose_int32_level_sums_could_wrap(eng_mod):
     """kernels_pexact.hip: the int32 level sums of the exact downdate are exact while 5 * 2^14 * m < 2^31, i.e. up to 26208 rows of
     B (round-4 ADVICE): ekf_engine_create returns EKF_ERR_INVALID_ARG for EKF_PRECISION_F32_EXACT with 2 * max_features above that,
