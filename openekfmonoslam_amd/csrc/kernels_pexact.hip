@@ -1653,9 +1653,14 @@ void launch_b_gemm_planes(EkfEngine *e, int m, int c_lo, int c_hi)
                                                                       g_lo, g_hi, e->d.Gz, e->bz_stride);
     const int tiles_i = (m + 127) / 128;
     const int n_units = tiles_i * tiles_j;
+#if PX_S_VALUE == 5
     k_b_gemm_i8p<<<std::min(e->n_cus, n_units), 512, 0, s>>>(e->d.Wq, ldw, w_stride, e->d.Wexp, e->d.Gq, ld, g_stride, e->d.Gexp, e->d.Bq,
                                                            (size_t)e->bq_rows * ld, e->d.Bexp, m, tiles_j, tj0, n_units, e->d.counts, c_lo, std::min(e->n, c_hi),
                                                            e->px_dense ? nullptr : e->d.Wz, e->d.Gz, e->bz_stride);
+#else // (builds with another digit count are accuracy experiments on the rows-of-B-in-the-sweep path only)
+    (void)n_units;
+    e->hook_rc = EKF_ERR_INVALID_ARG;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ launcher
@@ -1751,12 +1756,19 @@ void launch_p_update_exact(EkfEngine *e, int m, bool use_bc, bool exps_ready, bo
         e->pu_parity ^= 1;
 #endif
     } else
+#if PX_S_VALUE == 5
     if (!e->f32) { // fp64-stored P (EKF_PRECISION_F64_EXACT): the persistent kernel with the fp64 epilogue; an arbitrary upload is
                    // symmetrised first (0.5 (P + P') - B'B = 0.5 ((P - B'B) + (P - B'B)'): B'B is symmetric)
         if (!e->p_exact_sym && !rect) k_symmetrize_P<<<dim3((n + 255) / 256, n), 256, 0, s>>>((double *)e->d.P, ld, n);
         if (rect) k_p_update_i8p<true, double><<<e->n_cus, 512, 0, s>>>((double *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts, e->px_dense ? nullptr : e->d.Bz, e->bz_stride);
         else k_p_update_i8p<false, double><<<e->n_cus, 512, 0, s>>>((double *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->n_cus / 8, e->rm, e->d.counts, e->px_dense ? nullptr : e->d.Bz, e->bz_stride);
     } else
+#else
+    if (!e->f32) { // (other digit counts: fp32-stored P only)
+        e->hook_rc = EKF_ERR_INVALID_ARG;
+        return;
+    }
+#endif
     if (!e->p_exact_sym && !rect) k_p_update_i8<true><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->d.counts);
     else if (g_px_variant == 1 || PX_S != 5) k_p_update_i8<false><<<grid, 512, 0, s>>>((float *)e->d.P, ld, n, e->d.Bq, ld, plane_stride, m_k, e->d.Bexp, e->pu_per_xcd, tm, e->d.counts);
 #if PX_S_VALUE == 5
