@@ -284,13 +284,19 @@ def test_exact_drift_over_90_frames(eng_mod, oracle_lib):
     print("exact configuration after 90 frames:", {k: f"{v:.2e}" for k, v in be.items()})
 
 
-def test_concurrent_exact_engines_give_the_sequential_result(eng_mod):
-    """two exact engines stepped from two host threads (their own streams, work lists and digit-plane buffers): bit for bit the
-    result of running them one after the other"""
+@pytest.mark.parametrize("mode", [pytest.param(4, id="launches_bitwise"), pytest.param(2, id="persistent")])
+def test_concurrent_exact_engines_give_the_sequential_result(eng_mod, mode):
+    """two exact engines stepped from two host threads (their own streams, work lists and digit-plane buffers) give the result of
+    running them one after the other.  With the launch-per-panel sweep: bit for bit.  With the persistent sweep (the default): to
+    1e-12 -- its tile tasks are picked up by arrival, and which role applies a panel to a tile first decides the last bit of an fp64
+    sum of S; a sweep that timed out under the other engine's kernels is run again on the launch-per-panel path, whose sums are
+    grouped differently again.  scripts/concurrency_probe.py: 2 of 3000 concurrent runs differ from the run alone, in the last bits of
+    x (1e-16 relative), none of 3000 with the launch-per-panel sweep."""
     seq = SyntheticSequence(300, 4)
 
     def run(out, k):
         e = eng_mod.EkfEngine(seq.cam, seq.par, 300, max_keypoints=len(seq.frames[0][0]) + 64, precision=EXACT)
+        e.set_sweep_mode(mode)
         e.set_state(seq.x13, seq.feature_pos, seq.feature_type, seq.feature_desc, seq.P0)
         for t in range(4):
             e.step(*seq.frames[t])
@@ -307,7 +313,11 @@ def test_concurrent_exact_engines_give_the_sequential_result(eng_mod):
         t.join()
     for k in (1, 2):
         for a, b in zip(ref[0], got[k]):
-            assert np.array_equal(np.asarray(a), np.asarray(b)), k
+            a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+            if mode == 4:
+                assert np.array_equal(a, b), k
+            else:
+                assert np.max(np.abs(a - b)) <= 1e-12 * max(np.max(np.abs(a)), 1e-300), k
 
 
 @pytest.mark.parametrize("nfeat,frames,precision", [pytest.param(1000, 3, EXACT, id="n1000_f32_stored"), pytest.param(1400, 2, EXACT, id="n1400_above_2048_rows"),

@@ -96,6 +96,8 @@ def test_staged_images_equal_direct_steps(eng_mod, oracle_lib):
     seq = SyntheticSequence(50, 3)
     e1, _ = _with_templates(eng_mod, oracle_lib, seq)
     e2, _ = _with_templates(eng_mod, oracle_lib, seq)
+    for e in (e1, e2):
+        e.set_sweep_mode(4)  # bitwise run-to-run comparisons need the launch-per-panel sweep (the persistent one batches by arrival)
     imgs = [seq.render_image(t) for t in range(1, 4)]
     e2.upload_images(imgs)
     for t in range(3):
