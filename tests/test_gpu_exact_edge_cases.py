@@ -315,9 +315,9 @@ def test_concurrent_exact_engines_give_the_sequential_result(eng_mod, mode):
         for a, b in zip(ref[0], got[k]):
             a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
             if mode == 4:
-                assert np.array_equal(a, b), k
+                assert np.array_equal(a, b), (k, float(np.max(np.abs(a - b))))
             else:
-                assert np.max(np.abs(a - b)) <= 1e-12 * max(np.max(np.abs(a)), 1e-300), k
+                assert np.max(np.abs(a - b)) <= 1e-12 * max(np.max(np.abs(a)), 1e-300), (k, float(np.max(np.abs(a - b))))
 
 
 @pytest.mark.parametrize("nfeat,frames,precision", [pytest.param(1000, 3, EXACT, id="n1000_f32_stored"), pytest.param(1400, 2, EXACT, id="n1400_above_2048_rows"),
