@@ -355,6 +355,33 @@ def committed_pmc_traffic(workload):
     return None, None, {}
 
 
+def committed_pmc_executed(workload):
+    """int8 MFMA operations the downdate kernel EXECUTED per launch, from the committed rocprofv3 PMC summary of this workload
+    (SQ_INSTS_VALU_MFMA_MOPS_I8, counted in units of 512 operations -- with that unit the counter reproduces the MFMA-busy fraction of
+    the same passes: scripts/profile_summary.py pmc_sq).  The nominal count (`achieved`) includes the skipped zero-piece products and
+    excludes tile padding; this one is what went through the pipe."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "profiles", f"r*_pmc_sq_p_update_{workload}.csv")), reverse=True):
+        with open(path) as f:
+            for line in f:
+                if line.startswith("SQ_INSTS_VALU_MFMA_MOPS_I8,"):
+                    _, n, mean, mlong, mshort, dlong, dshort = line.strip().split(",")
+                    ops = {"long": 512.0 * float(mlong), "short": 512.0 * float(mshort)}
+                    us = {"long": float(dlong), "short": float(dshort)}
+                    out = {"source": os.path.relpath(path, here), "launches": int(n)}
+                    for c in ("long", "short"):
+                        out[f"int8_ops_per_launch_{c}"] = ops[c]
+                        out[f"tops_{c}"] = ops[c] / (us[c] * 1e-6) / 1e12
+                        out[f"frac_{c}"] = out[f"tops_{c}"] / PEAK_I8_TOPS
+                    out["tops"] = (ops["long"] + ops["short"]) / ((us["long"] + us["short"]) * 1e-6) / 1e12
+                    out["frac"] = out["tops"] / PEAK_I8_TOPS
+                    out["note"] = ("executed int8 MFMA operations per launch under the profiler (long / short = the low- / high-innovation "
+                                   "updates), read from the committed PMC passes over this bench's own frames -- not collected in this run")
+                    return out
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -549,6 +576,7 @@ def main():
                                         "workloads' first frames, profiles/r06_plane0_pieces.txt) `achieved` is an effective rate, above "
                                         "what the MFMA pipe executed; on the headline's frames 35-90 % of the pieces are non-zero and a "
                                         "unit with less than a quarter of zero pieces takes the dense step",
+                    "executed_from_pmc": committed_pmc_executed(args.workload) if args.matcher == "descriptors" else None,
                     "int8_ops_per_launch": PX_PRODUCTS * flops,
                     "fp32_equivalent_tflops": ach,
                     "fp32_equivalent_note": "algorithmic n^2 m flop / launch time: comparable with the fp32 MFMA kernel's "
