@@ -626,6 +626,7 @@ def main():
                                + ("; rows of B = inv(L) H P in the same launch" + ("" if persistent else "es") if sw["flops_b"] > 0 else "; B by inverse + GEMM afterwards")
                                + (", fp64" if exact else "") + ")"),
                     "launches": sw["launches"],
+                    "sweep_retries": eng.sweep_retries if hasattr(eng, "sweep_retries") else None,  # updates re-run after a timed-out persistent sweep, whole run
                     "us_per_launch": 1e3 * sw["ms"] / max(sw["launches"], 1),
                     "bound": "latency (a chain of dependent 32 x 32 factorisations" + (" and hand-offs inside one launch)" if persistent else ", one launch each)"),
                     "us_per_panel": 1e3 * sw["ms"] / sw["panels"],
